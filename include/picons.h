@@ -1,0 +1,234 @@
+/* picons.h - C ABI of libpicons.so: the MI355X (gfx950) hot path of the semi-supervised
+ * video action-detection train step (AKASH2907/pi-consistency-activity-detection).
+ *
+ * The reference has NO native/FFI layer: its boundary is the Python module
+ * surface.  This ABI sits underneath that surface; each entry cites the reference call site
+ * (an ATen op launched from Python) it replaces.
+ *
+ * Conventions
+ *  - extern "C", plain pointers + POD descriptors, no torch types.  All tensor pointers are
+ *    DEVICE pointers to fp32 unless stated.  Activations are NDHWC (channels innermost) with
+ *    an explicit channel stride `ld*` so a kernel can read/write a channel slice of a wider
+ *    tensor (torch.cat becomes free); the pointer passed already includes the channel offset.
+ *  - Ownership: the caller owns every buffer incl. workspaces; the library allocates nothing,
+ *    keeps no pointers between calls, and only enqueues work on the hipStream_t it is given
+ *    (never the null stream implicitly, no device sync).  Entries are re-entrant.
+ *  - Errors: int return, 0 = ok, negative = PC_E_*; message via pc_last_error() (thread-local).
+ *    Nothing throws across the ABI or calls exit().
+ */
+#ifndef PICONS_H
+#define PICONS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pc_stream;            /* hipStream_t */
+
+#define PC_OK            0
+#define PC_E_ARG        -1          /* bad descriptor / unsupported shape */
+#define PC_E_LAUNCH     -2          /* hip launch error */
+#define PC_E_NODEVICE   -3
+
+#define PC_ACT_NONE 0
+#define PC_ACT_RELU 1
+#define PC_ACT_SIGMOID 2
+
+#define PC_F_ACCUM   1              /* out += result (dgrad into a tensor with several consumers) */
+#define PC_F_BIAS    2
+#define PC_F_CSCALE  4              /* multiply by cscale[n][co] (Dropout3d draw, capsules_ucf101.py:428,507) */
+#define PC_F_BNPART  8              /* emit per-block BatchNorm partial sums (sum, sumsq) */
+
+int         pc_version(void);
+const char* pc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Generalised gather-GEMM convolution (fp32 MFMA v_mfma_f32_32x32x2_f32, LDS-tiled).
+ *   out[n, q*ostr+ooff, co] = act( bias[co] + sum_{a,b,c} sum_ci
+ *        in[n, q*istr + ioff0 + (a,b,c)*istep, ci] * w[co][wtap(a,b,c)][ci] ) * cscale[n][co]
+ *   wtap = ((wk0_t + a*wkstep_t)*KH + wk0_h + b*wkstep_h)*KW + wk0_w + c*wkstep_w
+ * Weight layout [Co][KT*KH*KW][ldw] (taps then channels innermost).  One descriptor covers
+ *   nn.Conv3d/Conv2d forward incl. TF-SAME padding folded in (pytorch_i3d.py:112-115; capsules_ucf101.py:44-45,490,497,501),
+ *   conv dgrad (stride 1: mirrored taps; stride s: one launch per output-parity class),
+ *   nn.ConvTranspose2d/3d forward as sub-pixel parity classes (capsules_ucf101.py:486,495,499,504),
+ *   and ConvTranspose dgrad (= strided conv).
+ * Requires Ci % 4 == 0, ldi % 4 == 0, ldw % 4 == 0 (float4 loads). */
+typedef struct pc_conv_desc {
+    int32_t N;
+    int32_t Ti, Hi, Wi, Ci, ldi;
+    int32_t Tq, Hq, Wq;
+    int32_t To, Ho, Wo, Co, ldo;
+    int32_t ostr[3], ooff[3];
+    int32_t istr[3], ntap[3], ioff0[3], istep[3];
+    int32_t wk0[3], wkstep[3];
+    int32_t KT, KH, KW, ldw;
+    int32_t act, flags;
+    int32_t groups;                 /* >=1: rows are tiled per batch group (N/groups samples each) so BatchNorm
+                                       partials never straddle the two forward passes of one step */
+} pc_conv_desc;
+
+/* bnpart: [pc_conv_bnpart_rows(d)][2][Co] partial (sum, sumsq) over output rows, or NULL */
+int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const float* bias,
+                const float* cscale, float* out, float* bnpart, pc_stream s);
+int pc_conv_bnpart_rows(const pc_conv_desc* d);
+
+/* Weight gradient:  g[m][ (a,b,c) , cs ] += sum_{n,q} D[n,q,m] * S[n, q*istr+ioff0+(a,b,c)*istep, cs]
+ * D dense over the lattice (Tq,Hq,Wq), S gathered.  g layout [Cd][ntap_t*ntap_h*ntap_w][Cs],
+ * accumulated with fp32 atomics (g must be initialised).  Conv3d wgrad: D=dY, S=X;
+ * ConvTranspose wgrad: D=X, S=dOut.  (replaces ATen convolution_backward's weight branch.) */
+typedef struct pc_wgrad_desc {
+    int32_t N;
+    int32_t Tq, Hq, Wq, Cd, ldd;
+    int32_t Ts, Hs, Ws, Cs, lds;
+    int32_t istr[3], ntap[3], ioff0[3], istep[3];
+    int32_t splitk;                 /* 0 = choose */
+} pc_wgrad_desc;
+int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm3d(train) + ReLU (pytorch_i3d.py:116-119; eps 1e-3, momentum 0.01 at :80).
+ * `groups`: the two forward passes of one step (main_ucf101.py:85-86) run as one batch whose
+ * rows split into `groups` equal row ranges with separate batch statistics; running stats
+ * are updated once per group, in order (as the reference's two sequential forwards do). */
+/* partials [groups][nparts_per_group][2][C] (sum, sumsq from pc_conv_fwd) -> stat[groups][4][C] =
+ * mean, invstd, scale=gamma*invstd, shift=beta-mean*scale; running stats updated if non-NULL. */
+int pc_bn_finalize(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
+                   const float* gamma, const float* beta, float eps, float momentum,
+                   float* running_mean, float* running_var, float* stat, pc_stream s);
+/* y[r][c] = relu?(z[r][c]*scale[g(r)][c]+shift[g(r)][c]) */
+int pc_bn_apply(const float* z, int ldz, const float* stat, int C, int64_t rows, int groups, float* y,
+                int ldy, int relu, pc_stream s);
+/* eval mode: stat[4][C] from running stats */
+int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean,
+                    const float* running_var, float eps, int C, float* stat, pc_stream s);
+/* backward: dy (grad after ReLU, row stride lddy), z -> dz; dgamma/dbeta (+)= if accum.
+ * ws: >= pc_bn_bwd_ws_floats(rows,C,groups) floats. */
+int64_t pc_bn_bwd_ws_floats(int64_t rows, int C, int groups);
+int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, const float* stat, int C,
+              int64_t rows, int groups, int relu, float* dz, int lddz, float* dgamma, float* dbeta,
+              int accum, float* ws, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * MaxPool3d with TF-SAME zero padding (pytorch_i3d.py:21-45); argmax kept for the backward. */
+typedef struct pc_pool_desc {
+    int32_t N, Ti, Hi, Wi, C, ldi;
+    int32_t To, Ho, Wo, ldo;
+    int32_t k[3], s[3], padf[3];
+} pc_pool_desc;
+int pc_maxpool_fwd(const pc_pool_desc* d, const float* x, float* y, uint8_t* argmax, pc_stream s);
+int pc_maxpool_bwd(const pc_pool_desc* d, const float* dy, const uint8_t* argmax, float* dx,
+                   int accum, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Elementwise helpers */
+/* y[n,pos,c] = x[n,pos,c] * scale[n][c]  (Dropout3d, capsules_ucf101.py:428; also its backward) */
+int pc_channel_scale(const float* x, int ldx, const float* scale, int N, int64_t pos_per_n, int C,
+                     float* y, int ldy, int accum, pc_stream s);
+/* dz = dy * act'(y) ; dbias[c] (+)= sum dz   (bias+ReLU / bias+sigmoid / bias-only epilogues) */
+int64_t pc_act_bwd_ws_floats(int64_t rows, int C);
+int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, int act, int C, int64_t rows,
+               float* dz, int lddz, float* dbias, int accum, float* ws, pc_stream s);
+/* NCDHW (reference layout, main_ucf101.py:52-59 input clips) -> NDHWC with C padded to Cpad;
+ * flipw mirrors W (torch.flip(.,[4]), main_ucf101.py:100). src may be fp32 or fp64. */
+int pc_ncdhw_to_ndhwc(const void* src, int src_is_f64, int N, int C, int64_t thw, int W, int Cpad,
+                      int flipw, float* dst, pc_stream s);
+int pc_ndhwc_to_ncdhw(const float* src, int ld, int N, int C, int64_t thw, float* dst, pc_stream s);
+/* dst[b][c][r] (+)= src[b][r][c] through 32x32 LDS tiles.  Every weight / weight-gradient
+ * re-layout between the reference's OI(T)HW / IO(T)HW state_dict layout and the kernels'
+ * [O][taps][I] / [I][taps][O] layouts is one call of this (see plan.py). */
+int pc_transpose_batched(const float* src, int batch, int R, int Cc, int64_t src_batch_stride,
+                         int src_ld, float* dst, int64_t dst_batch_stride, int dst_ld, int accum,
+                         pc_stream s);
+int pc_fill(float* p, int64_t n, float v, pc_stream s);
+int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Capsule head (capsules_ucf101.py:290-331, 108-211): votes + 3-iteration EM routing, one
+ * wave per spatial position, votes recomputed from poses and W held in LDS.
+ *  x      [npos][B*17]   primary caps output (poses B*16 then activations B)
+ *  W      [B][C][4][4], beta_u [C][16], beta_a [C]
+ *  out    [npos][C*17]   (mu C*16 then a_out C)
+ * backward: hand-derived reverse of all iterations (autograd equivalent), per-block partial
+ * parameter grads in ws then reduced; dW/dbeta_u/dbeta_a accumulated (+=). */
+int64_t pc_em_ws_floats(int npos, int B, int C);
+int pc_em_routing_fwd(const float* x, const float* W, const float* beta_u, const float* beta_a,
+                      int npos, int B, int C, float* out, pc_stream s);
+int pc_em_routing_bwd(const float* x, const float* W, const float* beta_u, const float* beta_a,
+                      const float* dout, int npos, int B, int C, float* dx, float* dW,
+                      float* dbeta_u, float* dbeta_a, float* ws, pc_stream s);
+
+/* class-capsule masking (capsules_ucf101.py:438-484):
+ *  actor_prediction[b][c] = mean_pos act; mask row: labeled -> one-hot(cls), unlabeled ->
+ *  ones (mode 0) or one-hot(argmax pred) (mode 1); eval (mode 2): argmax for all rows.
+ *  masked[b,pos,c*16+h] = pose * mask[b][c];  mask is written out for the backward. */
+int pc_class_mask_fwd(const float* caps, int Bn, int npos_per_b, int C, const float* cls,
+                      const int32_t* labeled, int mode, float* actor_pred, float* mask,
+                      float* masked, pc_stream s);
+/* dcaps = [dmasked*mask , dactor_pred/npos_per_b] */
+int pc_class_mask_bwd(const float* dmasked, const float* dactor_pred, const float* mask, int Bn,
+                      int npos_per_b, int C, float* dcaps, pc_stream s);
+
+/* `smooth` ConvTranspose3d(128->1,k3,p1) second stage (capsules_ucf101.py:373,509): the 27 tap
+ * projections proj[n,t,h,w,32] (from pc_conv_fwd with Co=27) are summed at their offsets:
+ *  out[n,t,h,w] = bias + sum_tap proj[n, (t,h,w)+pad-k(tap), tap]   and the adjoint. */
+int pc_tapsum_fwd(const float* proj, int N, int T, int H, int W, const float* bias, float* out, pc_stream s);
+int pc_tapsum_bwd(const float* dout, int N, int T, int H, int W, float* dproj, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused loss: everything main_ucf101.py:89-148 computes from (output, flip_op, loc_msk):
+ * BCEWithLogits + Dice on labeled rows, equal-weight L2, bv (utils/helpers.py:8-67) and gv
+ * (:70-95) attentive masks with their weighted MSE, combined as the reference does, plus
+ * d(total)/d(output), d(total)/d(flip_op).  Masks are detached, like the reference's numpy. */
+typedef struct pc_loss_desc {
+    int32_t B, T, H, W;             /* T must be 8 (utils/helpers.py:14) */
+    int32_t bv, gv, n_frames, predict_maps, jhmdb;
+    float   lower_thresh, upper_thresh;   /* <0 = None */
+    float   bv_wt, gv_wt, wt_loc, wt_cons, wt_ramp;
+} pc_loss_desc;
+int64_t pc_loss_ws_floats(const pc_loss_desc* d);
+/* output, flip_op: [B][T][H][W] logits (flip_op still W-mirrored, as the model returns it);
+ * seg [B][T][H][W]; labeled[B] 0/1.  scalars[8] = {loc, cons, bce, dice, l2, lv1+lv2, lg, n_labeled};
+ * total adds wt_cls*spread on the host side.  mask_bv/mask_gv optional outputs (may be NULL). */
+int pc_consistency_loss(const pc_loss_desc* d, const float* output, const float* flip_op,
+                        const float* seg, const int32_t* labeled, float* scalars, float* d_output,
+                        float* d_flip_op, float* mask_bv, float* mask_gv, float* ws, pc_stream s);
+/* standalone masks behind utils.helpers.measure_pixelwise_var_v2 / measure_pixelwise_gradient */
+int pc_var_mask(const float* pred, const float* flip_pred, int B, int T, int H, int W, int n_frames,
+                int use_sig, float* mask, float* ws, pc_stream s);
+int pc_grad_mask(const float* pred, int B, int T, int H, int W, float lower, float upper,
+                 float* mask, float* ws, pc_stream s);
+/* SpreadLoss (utils/losses.py:14-37) on labeled rows: out[2] = {loss, absloss}; dx (+)= wt*dloss/dx */
+int pc_spread_loss(const float* x, const float* cls, const int32_t* labeled, int Bn, int C, float m,
+                   float wt, float* out, float* dx, pc_stream s);
+
+/* fused Adam over a flat buffer (optim.Adam(lr, weight_decay=0, eps=1e-6), main_ucf101.py:416);
+ * gscale folds the 1/world_size of the DP mean. */
+int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1,
+                 float b2, float eps, int step, float gscale, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
+ * Op-list runner: the host builds the step as a flat list of POD ops once (shape inference and
+ * arena planning in Python) and the library replays it with no per-op host round trip. */
+typedef struct pc_op {
+    int32_t  kind;                  /* PC_OP_* */
+    int32_t  i[48];
+    float    f[8];
+    uint64_t p[12];                 /* device pointers */
+    int64_t  l[4];
+} pc_op;
+enum {
+    PC_OP_CONV = 1, PC_OP_WGRAD, PC_OP_BN_FINALIZE, PC_OP_BN_APPLY, PC_OP_BN_EVAL_STAT, PC_OP_BN_BWD,
+    PC_OP_POOL_FWD, PC_OP_POOL_BWD, PC_OP_CHSCALE, PC_OP_ACT_BWD, PC_OP_TO_NDHWC, PC_OP_TO_NCDHW,
+    PC_OP_TRANSPOSE, PC_OP_FILL, PC_OP_AXPY, PC_OP_EM_FWD, PC_OP_EM_BWD, PC_OP_CMASK_FWD,
+    PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
+    PC_OP__COUNT
+};
+int pc_run_ops(const pc_op* ops, int n, pc_stream s);
+/* same, with a hipEvent pair recorded around every op of `kind` on stream s; returns elapsed
+ * ms summed over those ops in *ms and their count in *count (bench.py roofline leg). */
+int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, pc_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

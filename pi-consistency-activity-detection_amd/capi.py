@@ -1,0 +1,110 @@
+"""ctypes binding of libpicons.so (include/picons.h).  No CPU fallback: if the HIP library is
+missing or a call fails, this raises."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpicons.so")
+_lib = None
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho", "Wo", "Co", "ldo")] + \
+               [(n, i32 * 3) for n in ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")] + \
+               [(n, i32) for n in ("KT", "KH", "KW", "ldw", "act", "flags", "groups")]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds")] + \
+               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep")] + [("splitk", i32)]
+
+
+class PoolDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo")] + \
+               [(n, i32 * 3) for n in ("k", "s", "padf")]
+
+
+class LossDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("B", "T", "H", "W", "bv", "gv", "n_frames", "predict_maps", "jhmdb")] + \
+               [(n, f32) for n in ("lower_thresh", "upper_thresh", "bv_wt", "gv_wt", "wt_loc", "wt_cons", "wt_ramp")]
+
+
+# numpy mirror of struct pc_op (kind, i[48], f[8], p[12], l[4]) -- 4+192+32 = 228 -> padded to 232
+OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 8), ("_pad", np.int32),
+                     ("p", np.uint64, 12), ("l", np.int64, 4)], align=False)
+
+(OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
+ OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
+ OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM) = range(1, 25)
+
+ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART = 1, 2, 4, 8
+
+_SIGS = {
+    "pc_version": (i32, []),
+    "pc_last_error": (C.c_char_p, []),
+    "pc_conv_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
+    "pc_conv_bnpart_rows": (i32, [C.POINTER(ConvDesc)]),
+    "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
+    "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
+    "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
+    "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),
+    "pc_bn_bwd_ws_floats": (i64, [i64, i32, i32]),
+    "pc_bn_bwd": (i32, [vp, i32, vp, i32, vp, i32, i64, i32, i32, vp, i32, vp, vp, i32, vp, vp]),
+    "pc_maxpool_fwd": (i32, [C.POINTER(PoolDesc), vp, vp, vp, vp]),
+    "pc_maxpool_bwd": (i32, [C.POINTER(PoolDesc), vp, vp, vp, i32, vp]),
+    "pc_channel_scale": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
+    "pc_act_bwd_ws_floats": (i64, [i64, i32]),
+    "pc_act_bwd": (i32, [vp, i32, vp, i32, i32, i32, i64, vp, i32, vp, i32, vp, vp]),
+    "pc_ncdhw_to_ndhwc": (i32, [vp, i32, i32, i32, i64, i32, i32, i32, vp, vp]),
+    "pc_ndhwc_to_ncdhw": (i32, [vp, i32, i32, i32, i64, vp, vp]),
+    "pc_transpose_batched": (i32, [vp, i32, i32, i32, i64, i32, vp, i64, i32, i32, vp]),
+    "pc_fill": (i32, [vp, i64, f32, vp]),
+    "pc_axpy": (i32, [vp, vp, i64, f32, vp]),
+    "pc_em_ws_floats": (i64, [i32, i32, i32]),
+    "pc_em_routing_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
+    "pc_em_routing_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "pc_class_mask_fwd": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
+    "pc_class_mask_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
+    "pc_tapsum_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
+    "pc_tapsum_bwd": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "pc_loss_ws_floats": (i64, [C.POINTER(LossDesc)]),
+    "pc_consistency_loss": (i32, [C.POINTER(LossDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "pc_var_mask": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "pc_grad_mask": (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp]),
+    "pc_spread_loss": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]),
+    "pc_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
+    "pc_run_ops": (i32, [vp, i32, vp]),
+    "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),
+}
+EXPORTS = sorted(_SIGS)
+
+
+def lib():
+    """Load libpicons.so (once).  Raises if it has not been built: there is no fallback."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libpicons.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "or `make -C pi-consistency-activity-detection_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        assert C.sizeof(ConvDesc) == 45 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("libpicons error %d: %s" % (rc, lib().pc_last_error().decode()))
+
+
+def call(name, *args):
+    check(getattr(lib(), name)(*args))

@@ -1,0 +1,628 @@
+// Capsule head for gfx950: votes + 3-iteration EM routing (forward and hand-derived reverse
+// through all iterations), class-capsule masking, and the tap-sum stage of `smooth`.
+// Replaces /root/reference/models/capsules_ucf101.py:290-331 (ConvCaps.forward, K=(1,1)),
+// :108-211 (m_step / e_step / caps_em_routing), :438-484 (masking) and the ~150 small ATen
+// launches + two 157 MB `repeat` copies per pass they cost.
+//
+// One wavefront per spatial position.  Lane map: h = lane&15 (pose element p*4+q),
+// cg = lane>>4; the lane owns output capsules c = cg + 4*j (j < CJ).  Votes are never
+// materialised: v[i][c][p,q] = sum_k P_i[p][k] * W[i][c][k][q] is recomputed from the
+// position's poses and W^T held in LDS.  Reductions over h use 16-lane xor shuffles.
+#include "common.h"
+
+namespace {
+
+constexpr int NB = 32;          // input capsule types (capsules_ucf101.py:355)
+constexpr int MAXC = 24;        // output capsules (24 UCF101-24, 21 JHMDB-21)
+constexpr int CJ = MAXC / 4;
+constexpr float EPS = 1e-8f;    // capsules_ucf101.py:88
+constexpr float LAMBDA = 1e-6f; // capsules_ucf101.py:90
+constexpr float HALF_LN_2PI = 0.91893853320467274178f;
+
+#define WSYNC()                                               \
+    do {                                                      \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); \
+        __builtin_amdgcn_wave_barrier();                      \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
+    } while (0)
+
+__device__ __forceinline__ float sum16(float v) {   // over h (lane bits 0..3)
+    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float sum_cg(float v) {  // over cg (lane bits 4,5)
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return v;
+}
+
+// per-wave forward state (floats)
+struct FwdState {
+    float P[NB][16];
+    float a[NB];
+    float R[3][NB][MAXC];      // R[0] unused (constant 1/C)
+    float rn[NB][MAXC];        // scratch: normalised assignment of the current iteration
+    float invS[3][NB];
+    float rs[3][MAXC];
+    float mu[3][MAXC][16];
+    float s2[3][MAXC][16];
+    float aout[3][MAXC];
+    float D[4];                // stdv + eps per iteration
+};
+
+struct BwdState {
+    float dmu[3][MAXC][16];
+    float ds2[3][MAXC][16];
+    float dlnp[2][NB][MAXC];
+    float dco[NB][MAXC];
+    float dR[NB][MAXC];
+    float da_out[MAXC];
+    float drs[MAXC];
+    float da_in[NB];
+};
+
+// WT layout in LDS: [i][c][q][k]  (one ds_read_b128 gives W[i][c][0..3][q])
+__device__ __forceinline__ float vote(const float* WT, const f32x4 prow, int i, int c, int q, int C) {
+    const f32x4 w = *(const f32x4*)(WT + ((i * C + c) * 4 + q) * 4);
+    return prow[0] * w[0] + prow[1] * w[1] + prow[2] * w[2] + prow[3] * w[3];
+}
+
+// Forward EM for one position held in st->P / st->a.  Leaves every iteration's state in *st.
+__device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, const float* beta_a, int C, int lane) {
+    const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
+    for (int t = 0; t < 3; ++t) {
+        // ---- M-step (capsules_ucf101.py:127-152)
+        if (lane < NB) {
+            const float ai = st->a[lane];
+            float S = 0.f;
+            for (int c = 0; c < C; ++c) S += (t == 0 ? 1.0f / C : st->R[t][lane][c]) * ai;
+            st->invS[t][lane] = 1.0f / (S + EPS);
+        }
+        WSYNC();
+        for (int e = lane; e < NB * C; e += 64) {
+            const int i = e / C, c = e - i * C;
+            st->rn[i][c] = (t == 0 ? 1.0f / C : st->R[t][i][c]) * st->a[i] * st->invS[t][i];
+        }
+        WSYNC();
+        if (lane < C) {
+            float s = 0.f;
+            for (int i = 0; i < NB; ++i) s += st->rn[i][lane];
+            st->rs[t][lane] = s;
+        }
+        WSYNC();
+        float m[CJ], sg[CJ], irs[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) { m[j] = 0.f; sg[j] = 0.f; const int c = cg + 4 * j; irs[j] = c < C ? 1.0f / (st->rs[t][c] + EPS) : 0.f; }
+        for (int i = 0; i < NB; ++i) {
+            const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = cg + 4 * j;
+                if (c < C) m[j] += st->rn[i][c] * irs[j] * vote(WT, prow, i, c, q, C);
+            }
+        }
+        for (int i = 0; i < NB; ++i) {
+            const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = cg + 4 * j;
+                if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rn[i][c] * irs[j] * d * d; }
+            }
+        }
+        float cost[CJ], csum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = cg + 4 * j;
+            cost[j] = 0.f;
+            if (c < C) {
+                sg[j] += EPS;
+                st->mu[t][c][h] = m[j];
+                st->s2[t][c][h] = sg[j];
+                cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[t][c]);
+                csum += cost[j];
+            }
+        }
+        const float mean = sum_cg(csum) / C;
+        float dsum = 0.f;
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) if (cg + 4 * j < C) dsum += cost[j] - mean;
+        dsum = sum_cg(dsum);
+        const float D = sqrtf(dsum * dsum / C + EPS) + EPS;   // sum-then-square, :144
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = cg + 4 * j;
+            if (c < C && h == 0) st->aout[t][c] = 1.0f / (1.0f + expf(-LAMBDA * (beta_a[c] - (mean - cost[j]) / D)));
+        }
+        if (lane == 0) st->D[t] = D;
+        WSYNC();
+        if (t == 2) break;
+        // ---- E-step (capsules_ucf101.py:176-181)
+        float hl[CJ], is2[CJ], la[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) {
+            const int c = cg + 4 * j;
+            hl[j] = 0.f; is2[j] = 0.f; la[j] = 0.f;
+            if (c < C) { hl[j] = 0.5f * logf(sg[j]) + HALF_LN_2PI; is2[j] = 1.0f / (2.0f * sg[j]); la[j] = logf(EPS + st->aout[t][c]); }
+        }
+        for (int i = 0; i < NB; ++i) {
+            const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = cg + 4 * j;
+                if (c < C) {
+                    const float d = vote(WT, prow, i, c, q, C) - m[j];
+                    const float lp = sum16(-d * d * is2[j] - hl[j]);
+                    if (h == 0) st->R[t + 1][i][c] = lp + la[j];
+                }
+            }
+        }
+        WSYNC();
+        if (lane < NB) {   // softmax over c
+            float mx = -INFINITY;
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, st->R[t + 1][lane][c]);
+            float s = 0.f;
+            for (int c = 0; c < C; ++c) { const float e = expf(st->R[t + 1][lane][c] - mx); st->R[t + 1][lane][c] = e; s += e; }
+            const float inv = 1.0f / s;
+            for (int c = 0; c < C; ++c) st->R[t + 1][lane][c] *= inv;
+        }
+        WSYNC();
+    }
+}
+
+__device__ __forceinline__ void load_WT(float* WT, const float* W, int C, int tid, int nthr) {
+    // W [i][c][k][q] -> WT [i][c][q][k]
+    for (int e = tid; e < NB * C * 16; e += nthr) {
+        const int k = (e >> 2) & 3, q = e & 3;
+        WT[(e & ~15) + q * 4 + k] = W[e];
+    }
+}
+
+__device__ __forceinline__ void load_pos(FwdState* st, const float* x, int64_t pos, int lane) {
+    const float* xp = x + pos * (NB * 17);
+    for (int e = lane; e < NB * 16 / 4; e += 64) ((f32x4*)&st->P[0][0])[e] = ((const f32x4*)xp)[e];
+    if (lane < NB) st->a[lane] = xp[NB * 16 + lane];
+}
+
+constexpr int FWD_WAVES = 4;
+
+__global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 const float* __restrict__ beta_u, const float* __restrict__ beta_a,
+                                                                 int npos, int C, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* WT = smem;
+    FwdState* sts = (FwdState*)(smem + NB * MAXC * 16);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    load_WT(WT, W, C, threadIdx.x, blockDim.x);
+    __syncthreads();
+    FwdState* st = sts + wave;
+    for (int64_t pos = (int64_t)blockIdx.x * FWD_WAVES + wave; pos < npos; pos += (int64_t)gridDim.x * FWD_WAVES) {
+        WSYNC();
+        load_pos(st, x, pos, lane);
+        WSYNC();
+        em_forward(st, WT, beta_u, beta_a, C, lane);
+        float* o = out + pos * (C * 17);
+        for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[2][0][0])[e];
+        if (lane < C) o[C * 16 + lane] = st->aout[2][lane];
+    }
+}
+
+// Backward: one wave per block; forward recomputed into LDS, then reversed.
+__global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ beta_u, const float* __restrict__ beta_a,
+                                                    const float* __restrict__ dout, int npos, int C, float* __restrict__ dx,
+                                                    float* __restrict__ part) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* WT = smem;                              // [NB][C][4(q)][4(k)]
+    float* dWacc = smem + NB * MAXC * 16;          // [i][c][k][q]
+    float* dbu = dWacc + NB * MAXC * 16;           // [C][16]
+    float* dba = dbu + MAXC * 16;                  // [C]
+    FwdState* st = (FwdState*)(dba + 32);
+    BwdState* bs = (BwdState*)(st + 1);
+    const int lane = threadIdx.x;
+    const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
+    load_WT(WT, W, C, lane, 64);
+    for (int e = lane; e < NB * MAXC * 16 + MAXC * 16 + 32; e += 64) dWacc[e] = 0.f;
+    WSYNC();
+    for (int64_t pos = blockIdx.x; pos < npos; pos += gridDim.x) {
+        WSYNC();
+        load_pos(st, x, pos, lane);
+        WSYNC();
+        em_forward(st, WT, beta_u, beta_a, C, lane);
+        // ---- seeds
+        const float* dop = dout + pos * (C * 17);
+        for (int e = lane; e < 3 * MAXC * 16; e += 64) { (&bs->dmu[0][0][0])[e] = 0.f; (&bs->ds2[0][0][0])[e] = 0.f; }
+        WSYNC();
+        for (int e = lane; e < C * 16; e += 64) (&bs->dmu[2][0][0])[e] = dop[e];
+        if (lane < C) bs->da_out[lane] = dop[C * 16 + lane];
+        if (lane < NB) bs->da_in[lane] = 0.f;
+        WSYNC();
+        for (int t = 2; t >= 0; --t) {
+            // ---- step A: a_out / cost back to rs, beta, sigma^2  (capsules_ucf101.py:138-152)
+            const float D = st->D[t];
+            float du[CJ], dusum = 0.f;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = cg + 4 * j;
+                du[j] = 0.f;
+                if (c < C) { const float ao = st->aout[t][c]; du[j] = bs->da_out[c] * ao * (1.f - ao); dusum += du[j]; }
+            }
+            dusum = sum_cg(dusum);            // every h-lane of a cg holds the same du, so this is sum over c
+            const float dmean = -LAMBDA / D * dusum;
+#pragma unroll
+            for (int j = 0; j < CJ; ++j) {
+                const int c = cg + 4 * j;
+                if (c < C) {
+                    const float dcost = LAMBDA / D * du[j] + dmean / C;
+                    const float s2v = st->s2[t][c][h], rsv = st->rs[t][c];
+                    const float G = sum16(beta_u[c * 16 + h] + 0.5f * logf(s2v));
+                    dbu[c * 16 + h] += dcost * rsv;
+                    const float ds = bs->ds2[t][c][h] + dcost * rsv * 0.5f / s2v;
+                    bs->ds2[t][c][h] = ds;
+                    // d sigma^2 / d mu through sum_i co (v-mu)^2 :  -2 ds * mu * eps/(rs+eps)
+                    bs->dmu[t][c][h] += -2.f * ds * st->mu[t][c][h] * (EPS / (rsv + EPS));
+                    if (h == 0) { bs->drs[c] = dcost * G; dba[c] += LAMBDA * du[j]; }
+                }
+            }
+            WSYNC();
+            // recompute rn for this iteration
+            for (int e = lane; e < NB * C; e += 64) {
+                const int i = e / C, c = e - i * C;
+                st->rn[i][c] = (t == 0 ? 1.0f / C : st->R[t][i][c]) * st->a[i] * st->invS[t][i];
+            }
+            WSYNC();
+            // ---- step B: dco[i][c] = sum_h dmu*v + ds2*(v-mu)^2
+            {
+                float dm[CJ], dsv[CJ], muv[CJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = cg + 4 * j;
+                    dm[j] = dsv[j] = muv[j] = 0.f;
+                    if (c < C) { dm[j] = bs->dmu[t][c][h]; dsv[j] = bs->ds2[t][c][h]; muv[j] = st->mu[t][c][h]; }
+                }
+                for (int i = 0; i < NB; ++i) {
+                    const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) {
+                        const int c = cg + 4 * j;
+                        if (c < C) {
+                            const float v = vote(WT, prow, i, c, q, C), d = v - muv[j];
+                            const float s = sum16(dm[j] * v + dsv[j] * d * d);
+                            if (h == 0) bs->dco[i][c] = s;
+                        }
+                    }
+                }
+            }
+            WSYNC();
+            // ---- step C: co -> rn -> ra -> (R_t, a_in)
+            if (lane < C) {
+                const float irs = 1.0f / (st->rs[t][lane] + EPS);
+                float T = 0.f;
+                for (int i = 0; i < NB; ++i) T += bs->dco[i][lane] * st->rn[i][lane] * irs * irs;
+                bs->drs[lane] -= T;
+            }
+            WSYNC();
+            for (int e = lane; e < NB * C; e += 64) {     // dco now holds drn
+                const int i = e / C, c = e - i * C;
+                bs->dco[i][c] = bs->dco[i][c] / (st->rs[t][c] + EPS) + bs->drs[c];
+            }
+            WSYNC();
+            if (lane < NB) {
+                const float iS = st->invS[t][lane], ai = st->a[lane];
+                float dot = 0.f;
+                for (int c = 0; c < C; ++c) dot += bs->dco[lane][c] * st->rn[lane][c];
+                const float dS = -dot * iS;
+                float dai = 0.f;
+                for (int c = 0; c < C; ++c) {
+                    const float dra = bs->dco[lane][c] * iS + dS;
+                    const float Rt = t == 0 ? 1.0f / C : st->R[t][lane][c];
+                    dai += dra * Rt;
+                    bs->dR[lane][c] = dra * ai;
+                }
+                bs->da_in[lane] += dai;
+            }
+            WSYNC();
+            if (t == 0) break;
+            // ---- step D: E-step (t-1) backward from dR_t  (capsules_ucf101.py:176-181)
+            if (lane < NB) {
+                float dot = 0.f;
+                for (int c = 0; c < C; ++c) dot += st->R[t][lane][c] * bs->dR[lane][c];
+                for (int c = 0; c < C; ++c) bs->dlnp[t - 1][lane][c] = st->R[t][lane][c] * (bs->dR[lane][c] - dot);
+            }
+            WSYNC();
+            if (lane < C) {
+                float s = 0.f;
+                for (int i = 0; i < NB; ++i) s += bs->dlnp[t - 1][i][lane];
+                bs->da_out[lane] = s / (EPS + st->aout[t - 1][lane]);
+            }
+            {
+                float am[CJ], as2[CJ], muv[CJ], is2[CJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = cg + 4 * j;
+                    am[j] = as2[j] = muv[j] = is2[j] = 0.f;
+                    if (c < C) { muv[j] = st->mu[t - 1][c][h]; is2[j] = 1.0f / st->s2[t - 1][c][h]; }
+                }
+                for (int i = 0; i < NB; ++i) {
+                    const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+#pragma unroll
+                    for (int j = 0; j < CJ; ++j) {
+                        const int c = cg + 4 * j;
+                        if (c < C) {
+                            const float d = vote(WT, prow, i, c, q, C) - muv[j];
+                            const float g = bs->dlnp[t - 1][i][c];
+                            am[j] += g * d * is2[j];
+                            as2[j] += g * (0.5f * d * d * is2[j] * is2[j] - 0.5f * is2[j]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = cg + 4 * j;
+                    if (c < C) { bs->dmu[t - 1][c][h] = am[j]; bs->ds2[t - 1][c][h] = as2[j]; }
+                }
+            }
+            WSYNC();
+        }
+        // ---- final loop: total dv -> dP (to dx) and dW (LDS accumulator)
+        {
+            float dm[3][CJ], dsv[3][CJ], muv[3][CJ], is2[2][CJ], irs[3][CJ];
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = cg + 4 * j;
+                    dm[t][j] = dsv[t][j] = muv[t][j] = irs[t][j] = 0.f;
+                    if (t < 2) is2[t][j] = 0.f;
+                    if (c < C) {
+                        dm[t][j] = bs->dmu[t][c][h]; dsv[t][j] = bs->ds2[t][c][h]; muv[t][j] = st->mu[t][c][h];
+                        irs[t][j] = 1.0f / (st->rs[t][c] + EPS);
+                        if (t < 2) is2[t][j] = 1.0f / st->s2[t][c][h];
+                    }
+                }
+            float* dxp = dx + pos * (NB * 17);
+            for (int i = 0; i < NB; ++i) {
+                const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
+                const float ai = st->a[i];
+                f32x4 dP = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) {
+                    const int c = cg + 4 * j;
+                    if (c >= C) continue;   // uniform within a 16-lane group; shuffles below stay inside the group or are zero-padded
+                    const f32x4 w = *(const f32x4*)(WT + ((i * C + c) * 4 + q) * 4);
+                    const float v = prow[0] * w[0] + prow[1] * w[1] + prow[2] * w[2] + prow[3] * w[3];
+                    float dv = 0.f;
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const float Rt = t == 0 ? 1.0f / C : st->R[t][i][c];
+                        const float co = Rt * ai * st->invS[t][i] * irs[t][j];
+                        dv += co * (dm[t][j] + 2.f * dsv[t][j] * (v - muv[t][j]));
+                        if (t < 2) dv -= bs->dlnp[t][i][c] * (v - muv[t][j]) * is2[t][j];
+                    }
+                    dP += dv * w;
+                    // dW[i][c][k][q] = sum_p P[p][k] * dv[p,q]  (reduce over p = lane bits 2,3)
+                    f32x4 tk = dv * prow;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) { tk[k] += __shfl_xor(tk[k], 4, 64); tk[k] += __shfl_xor(tk[k], 8, 64); }
+                    const float mine = p == 0 ? tk[0] : (p == 1 ? tk[1] : (p == 2 ? tk[2] : tk[3]));
+                    dWacc[((i * C + c) * 4 + p) * 4 + q] += mine;
+                }
+                // dP[p][k]: reduce over q (lane bits 0,1) and cg (bits 4,5)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float s = dP[k];
+                    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+                    dP[k] = s;
+                }
+                if (q == 0 && cg == 0) *(f32x4*)(dxp + i * 16 + p * 4) = dP;
+            }
+            if (lane < NB) dxp[NB * 16 + lane] = bs->da_in[lane];
+        }
+    }
+    WSYNC();
+    float* pp = part + (size_t)blockIdx.x * (NB * MAXC * 16 + MAXC * 16 + 32);
+    for (int e = lane; e < NB * MAXC * 16 + MAXC * 16 + 32; e += 64) pp[e] = dWacc[e];
+}
+
+// part [nblk][NB*MAXC*16 + MAXC*16 + 32] -> dW [NB][C][4][4], dbeta_u [C][16], dbeta_a [C]  (+=)
+__global__ __launch_bounds__(256) void em_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* dW, float* dbu, float* dba) {
+    const int stride = NB * MAXC * 16 + MAXC * 16 + 32;
+    const int nW = NB * C * 16, nU = C * 16;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= nW + nU + C) return;
+    int src; float* dst;
+    if (e < nW) { src = e; dst = dW + e; }
+    else if (e < nW + nU) { src = NB * MAXC * 16 + (e - nW); dst = dbu + (e - nW); }
+    else { src = NB * MAXC * 16 + MAXC * 16 + (e - nW - nU); dst = dba + (e - nW - nU); }
+    double s = 0.0;
+    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * stride + src];
+    *dst += (float)s;
+}
+
+// ------------------------------------------------------------------------------ class mask
+__global__ __launch_bounds__(256) void cmask_pred_kernel(const float* __restrict__ caps, int npos, int C, const float* __restrict__ cls,
+                                                         const int* __restrict__ labeled, int mode, float* __restrict__ pred, float* __restrict__ mask) {
+    __shared__ float sh[256];
+    __shared__ float pr[MAXC];
+    const int b = blockIdx.x;
+    const float* cb = caps + (size_t)b * npos * C * 17 + C * 16;
+    for (int c = 0; c < C; ++c) {
+        float s = 0.f;
+        for (int i = threadIdx.x; i < npos; i += 256) s += cb[(size_t)i * C * 17 + c];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o]; __syncthreads(); }
+        if (threadIdx.x == 0) { pr[c] = sh[0] / npos; pred[b * C + c] = pr[c]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int am = 0;
+        for (int c = 1; c < C; ++c) if (pr[c] > pr[am]) am = c;
+        const bool lab = mode != 2 && labeled[b] != 0;
+        const int gt = (int)cls[b];
+        for (int c = 0; c < C; ++c) {
+            float m;
+            if (lab) m = c == gt ? 1.f : 0.f;
+            else if (mode == 0) m = 1.f;
+            else m = c == am ? 1.f : 0.f;
+            mask[b * C + c] = m;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cmask_apply_kernel(const float* __restrict__ caps, const float* __restrict__ mask, int npos, int C,
+                                                          int64_t total, float* __restrict__ masked) {
+    const int PC = C * 16;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / PC; const int e = (int)(idx - row * PC);
+        const int b = (int)(row / npos);
+        masked[idx] = caps[row * (C * 17) + e] * mask[b * C + (e >> 4)];
+    }
+}
+
+__global__ __launch_bounds__(256) void cmask_bwd_kernel(const float* __restrict__ dmasked, const float* __restrict__ dpred, const float* __restrict__ mask,
+                                                        int npos, int C, int64_t total, float* __restrict__ dcaps) {
+    const int W17 = C * 17, PC = C * 16;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / W17; const int e = (int)(idx - row * W17);
+        const int b = (int)(row / npos);
+        float v;
+        if (e < PC) v = dmasked[row * PC + e] * mask[b * C + (e >> 4)];
+        else v = dpred ? dpred[b * C + (e - PC)] / npos : 0.f;
+        dcaps[idx] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------ tap sum (smooth stage 2)
+// proj [N][T][H][W][32] (27 used); ConvTranspose3d k3 p1 s1: out[o] = b + sum_k proj[o + 1 - k][k]
+__global__ __launch_bounds__(256) void tapsum_fwd_kernel(const float* __restrict__ proj, int N, int T, int H, int W, const float* __restrict__ bias,
+                                                         float* __restrict__ out) {
+    const int64_t total = (int64_t)N * T * H * W;
+    const float b = bias ? bias[0] : 0.f;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T); const int n = (int)(r / T);
+        float s = b;
+        int tap = 0;
+        for (int a = 0; a < 3; ++a) {
+            const int ti = t + 1 - a;
+            for (int bb = 0; bb < 3; ++bb) {
+                const int hi = h + 1 - bb;
+                for (int c = 0; c < 3; ++c, ++tap) {
+                    const int wi = w + 1 - c;
+                    if ((unsigned)ti < (unsigned)T && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                        s += proj[((size_t)((n * T + ti) * H + hi) * W + wi) * 32 + tap];
+                }
+            }
+        }
+        out[idx] = s;
+    }
+}
+
+// dproj[i][k] = dout[i - 1 + k]
+__global__ __launch_bounds__(256) void tapsum_bwd_kernel(const float* __restrict__ dout, int N, int T, int H, int W, float* __restrict__ dproj) {
+    const int64_t total = (int64_t)N * T * H * W * 8;   // float4 groups of the 32 channels
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        int64_t r = idx >> 3; const int g4 = (int)(idx & 7);
+        const int64_t pos = r;
+        const int w = (int)(r % W); r /= W;
+        const int h = (int)(r % H); r /= H;
+        const int t = (int)(r % T); const int n = (int)(r / T);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int tap = g4 * 4 + e;
+            float v = 0.f;
+            if (tap < 27) {
+                const int a = tap / 9, bb = (tap / 3) % 3, c = tap % 3;
+                const int to = t - 1 + a, ho = h - 1 + bb, wo = w - 1 + c;
+                if ((unsigned)to < (unsigned)T && (unsigned)ho < (unsigned)H && (unsigned)wo < (unsigned)W)
+                    v = dout[(size_t)((n * T + to) * H + ho) * W + wo];
+            }
+            o[e] = v;
+        }
+        *(f32x4*)(dproj + pos * 32 + g4 * 4) = o;
+    }
+}
+
+inline int em_bwd_blocks(int npos) { return npos < 512 ? npos : 512; }
+constexpr size_t EM_PART = NB * MAXC * 16 + MAXC * 16 + 32;
+
+}  // namespace
+
+extern "C" int64_t pc_em_ws_floats(int npos, int B, int C) {
+    (void)B; (void)C;
+    return (int64_t)em_bwd_blocks(npos) * (int64_t)EM_PART + 64;
+}
+
+extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* beta_u, const float* beta_a, int npos, int B, int C,
+                                 float* out, pc_stream s) {
+    PC_CHECK_ARG(x && W && beta_u && beta_a && out, "pc_em_routing_fwd: null");
+    PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_fwd: B must be 32 and C <= 24 (B=%d C=%d)", B, C);
+    PC_CHECK_ARG((uintptr_t)x % 16 == 0, "pc_em_routing_fwd: x alignment");
+    const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdState) * FWD_WAVES;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)em_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    int grid = cdiv(npos, FWD_WAVES);
+    if (grid > 512) grid = 512;
+    hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out);
+    PC_CHECK_LAUNCH("em_fwd");
+    return PC_OK;
+}
+
+extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* beta_u, const float* beta_a, const float* dout, int npos,
+                                 int B, int C, float* dx, float* dW, float* dbeta_u, float* dbeta_a, float* ws, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(x && W && beta_u && beta_a && dout && dx && dW && dbeta_u && dbeta_a && ws, "pc_em_routing_bwd: null");
+    PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_bwd: B must be 32 and C <= 24");
+    const size_t lds = (2 * (size_t)NB * MAXC * 16 + MAXC * 16 + 32) * 4 + sizeof(FwdState) + sizeof(BwdState);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)em_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    const int nblk = em_bwd_blocks(npos);
+    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
+    PC_CHECK_LAUNCH("em_bwd");
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, 256)), dim3(256), 0, s, ws, nblk, C, dW, dbeta_u, dbeta_a);
+    PC_CHECK_LAUNCH("em_reduce");
+    return PC_OK;
+}
+
+extern "C" int pc_class_mask_fwd(const float* caps, int Bn, int npos_per_b, int C, const float* cls, const int32_t* labeled, int mode,
+                                 float* actor_pred, float* mask, float* masked, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(caps && actor_pred && mask && masked && C <= MAXC, "pc_class_mask_fwd: bad args");
+    PC_CHECK_ARG(mode == 2 || (cls && labeled), "pc_class_mask_fwd: cls/labeled required in train mode");
+    hipLaunchKernelGGL(cmask_pred_kernel, dim3(Bn), dim3(256), 0, s, caps, npos_per_b, C, cls, labeled, mode, actor_pred, mask);
+    const int64_t total = (int64_t)Bn * npos_per_b * C * 16;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(cmask_apply_kernel, dim3(grid), dim3(256), 0, s, caps, mask, npos_per_b, C, total, masked);
+    PC_CHECK_LAUNCH("class_mask_fwd");
+    return PC_OK;
+}
+
+extern "C" int pc_class_mask_bwd(const float* dmasked, const float* dactor_pred, const float* mask, int Bn, int npos_per_b, int C,
+                                 float* dcaps, pc_stream s) {
+    PC_CHECK_ARG(dmasked && mask && dcaps, "pc_class_mask_bwd: null");
+    const int64_t total = (int64_t)Bn * npos_per_b * C * 17;
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(cmask_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dmasked, dactor_pred, mask, npos_per_b, C, total, dcaps);
+    PC_CHECK_LAUNCH("class_mask_bwd");
+    return PC_OK;
+}
+
+extern "C" int pc_tapsum_fwd(const float* proj, int N, int T, int H, int W, const float* bias, float* out, pc_stream s) {
+    PC_CHECK_ARG(proj && out, "pc_tapsum_fwd: null");
+    const int64_t total = (int64_t)N * T * H * W;
+    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, proj, N, T, H, W, bias, out);
+    PC_CHECK_LAUNCH("tapsum_fwd");
+    return PC_OK;
+}
+
+extern "C" int pc_tapsum_bwd(const float* dout, int N, int T, int H, int W, float* dproj, pc_stream s) {
+    PC_CHECK_ARG(dout && dproj, "pc_tapsum_bwd: null");
+    const int64_t total = (int64_t)N * T * H * W * 8;
+    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(tapsum_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dout, N, T, H, W, dproj);
+    PC_CHECK_LAUNCH("tapsum_bwd");
+    return PC_OK;
+}

@@ -1,0 +1,443 @@
+// Gather-GEMM convolution family for gfx950: fp32 MFMA (v_mfma_f32_32x32x2_f32), LDS-tiled,
+// NDHWC activations, [Co][taps][Ci] weights.  One kernel form covers Conv3d/Conv2d forward
+// (TF-SAME padding folded into the gather), conv dgrad, ConvTranspose forward as sub-pixel
+// parity classes and ConvTranspose dgrad; a second form computes weight gradients.
+// Replaces the ATen/cuDNN convolution call sites listed in SURVEY.md §2a (K1, K6, K9-K12).
+#include "common.h"
+
+namespace {
+
+struct ConvK {
+    const float* in; const float* w; const float* bias; const float* cscale; float* out; float* bnpart;
+    int N, Ti, Hi, Wi, Ci, ldi;
+    int Tq, Hq, Wq, To, Ho, Wo, Co, ldo;
+    int ostr[3], ooff[3], istr[3], ntap[3], ioff0[3], istep[3], wk0[3], wkstep[3];
+    int KH, KW, wtaps, ldw;
+    int K, M, Mg, groups, mtiles_g, ntiles;
+    int act, flags;
+};
+
+constexpr int BK = 32;       // K chunk (floats)
+constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][LDK]
+    float* Bs = smem + 2 * BM * LDK;           // [2][BN][LDK]
+    int* rinfo = (int*)(Bs + 2 * BN * LDK);    // [BM][4] n,t0,h0,w0
+    int* rout = rinfo + BM * 4;                // [BM] output position index or -1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
+    const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
+    const int n0 = nt * BN;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int lm = lt * BM + r;
+        int4 info = make_int4(-1, 0, 0, 0);
+        int op = -1;
+        if (lm < p.Mg) {
+            int m = g * p.Mg + lm;
+            const int wq = m % p.Wq; m /= p.Wq;
+            const int hq = m % p.Hq; m /= p.Hq;
+            const int tq = m % p.Tq; const int n = m / p.Tq;
+            info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1],
+                             wq * p.istr[2] + p.ioff0[2]);
+            op = ((n * p.To + tq * p.ostr[0] + p.ooff[0]) * p.Ho + hq * p.ostr[1] + p.ooff[1]) * p.Wo +
+                 wq * p.ostr[2] + p.ooff[2];
+        }
+        ((int4*)rinfo)[r] = info;
+        rout[r] = op;
+    }
+    __syncthreads();
+
+    const int lrow = tid >> 3, lcol = (tid & 7) * 4;
+    int4 ri[AR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) ri[j] = ((int4*)rinfo)[lrow + 32 * j];
+
+    f32x4 areg[AR], breg[BR];
+    const int tapHW = p.ntap[1] * p.ntap[2];
+
+    auto gload = [&](int c) {
+        const int kk = c * BK + lcol;
+        const bool kval = kk < p.K;
+        const int tap = kk / p.Ci, ci = kk - tap * p.Ci;
+        const int a_ = tap / tapHW, rem = tap - a_ * tapHW;
+        const int b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
+        const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
+        const int wtap = ((p.wk0[0] + a_ * p.wkstep[0]) * p.KH + p.wk0[1] + b_ * p.wkstep[1]) * p.KW +
+                         p.wk0[2] + c_ * p.wkstep[2];
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const int t = ri[j].y + dt, h = ri[j].z + dh, w = ri[j].w + dw;
+            const bool v = kval && ri[j].x >= 0 && (unsigned)t < (unsigned)p.Ti &&
+                           (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v) {
+                const size_t pos = (size_t)(((ri[j].x * p.Ti + t) * p.Hi + h) * p.Wi + w);
+                val = *(const f32x4*)(p.in + pos * p.ldi + ci);
+            }
+            areg[j] = val;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const int co = n0 + lrow + 32 * j;
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (kval && co < p.Co) val = *(const f32x4*)(p.w + ((size_t)co * p.wtaps + wtap) * p.ldw + ci);
+            breg[j] = val;
+        }
+    };
+    auto lstore = [&](int buf) {
+        float* a = As + buf * BM * LDK;
+        float* b = Bs + buf * BN * LDK;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) *(f32x4*)(a + (lrow + 32 * j) * LDK + lcol) = areg[j];
+#pragma unroll
+        for (int j = 0; j < BR; ++j) *(f32x4*)(b + (lrow + 32 * j) * LDK + lcol) = breg[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (p.K + BK - 1) / BK;
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
+    const int kof = (lane >> 5) * 4;
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) gload(c + 1);
+        const float* a = As + buf * BM * LDK + arow * LDK + kof;
+        const float* b = Bs + buf * BN * LDK + brow * LDK + kof;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + i * 32 * LDK + ks * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + j * 32 * LDK + ks * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < nchunks) lstore(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D map row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
+    const bool has_bias = p.flags & PC_F_BIAS, has_cs = p.flags & PC_F_CSCALE, accum = p.flags & PC_F_ACCUM;
+    if (p.flags & PC_F_BNPART) {
+        float* part = p.bnpart + ((size_t)(g * p.mtiles_g + lt) * WM + wm) * 2 * p.Co;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; s2 += v * v; }
+            s += __shfl_xor(s, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int op = rout[row];
+            if (op < 0) continue;
+            const int nb = rinfo[row * 4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+                if (col >= p.Co) continue;
+                float v = acc[i][j][r];
+                if (has_bias) v += p.bias[col];
+                if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
+                else if (p.act == PC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                if (has_cs) v *= p.cscale[(size_t)nb * p.Co + col];
+                float* o = p.out + (size_t)op * p.ldo + col;
+                if (accum) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const ConvK& k, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * (BM + BN) * LDK + BM * 5) * sizeof(float);
+    if (!attr_set) {
+        hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    ConvK p = k;
+    p.mtiles_g = cdiv(p.Mg, BM);
+    p.ntiles = cdiv(p.Co, BN);
+    const int grid = p.groups * p.mtiles_g * p.ntiles;
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, s, p);
+    PC_CHECK_LAUNCH("conv_gemm_kernel");
+    return PC_OK;
+}
+
+// tile choice: minimise padded work, prefer larger tiles when the grid still fills the chip
+struct TileCfg { int bm, bn, wm; };
+inline TileCfg choose_tile(int Mg, int groups, int Co) {
+    const TileCfg cand[] = {{128, 128, 2}, {128, 64, 2}, {64, 64, 2}, {128, 32, 4}};
+    double best = 1e30; TileCfg bc = cand[0];
+    for (const TileCfg& c : cand) {
+        const double mt = (double)groups * cdiv(Mg, c.bm), ntl = cdiv(Co, c.bn);
+        const double blocks = mt * ntl;
+        const double work = blocks * c.bm * c.bn;                 // padded MACs per unit K
+        const double eff = (c.bm * c.bn) / (double)(c.bm + c.bn); // operand reuse
+        // waves of blocks over 512 slots (2 blocks/CU); partial last wave costs a full one
+        const double slots = 512.0, wavesq = ceil(blocks / slots);
+        const double fill = blocks / (wavesq * slots);
+        const double cost = work / (fill > 0.35 ? 1.0 : fill / 0.35) * (1.0 + 8.0 / eff);
+        if (cost < best) { best = cost; bc = c; }
+    }
+    return bc;
+}
+
+}  // namespace
+
+extern "C" int pc_conv_bnpart_rows(const pc_conv_desc* d) {
+    const int groups = d->groups > 0 ? d->groups : 1;
+    const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    const TileCfg c = choose_tile((int)Mg, groups, d->Co);
+    return groups * cdiv(Mg, c.bm) * c.wm;
+}
+
+static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, const float* w, const float* bias,
+                  const float* cscale, float* out, float* bnpart, hipStream_t s) {
+    PC_CHECK_ARG(d && in && w && out, "pc_conv_fwd: null pointer");
+    PC_CHECK_ARG(d->Ci % 4 == 0 && d->ldi % 4 == 0 && d->ldw % 4 == 0, "pc_conv_fwd: Ci/ldi/ldw must be multiples of 4 (Ci=%d ldi=%d ldw=%d)", d->Ci, d->ldi, d->ldw);
+    PC_CHECK_ARG(groups >= 1 && d->N % groups == 0, "pc_conv_fwd: N %% groups");
+    PC_CHECK_ARG(!(d->flags & PC_F_BIAS) || bias, "pc_conv_fwd: bias flag without pointer");
+    PC_CHECK_ARG(!(d->flags & PC_F_CSCALE) || cscale, "pc_conv_fwd: cscale flag without pointer");
+    PC_CHECK_ARG(!(d->flags & PC_F_BNPART) || bnpart, "pc_conv_fwd: bnpart flag without pointer");
+    PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)w % 16 == 0), "pc_conv_fwd: in/w must be 16-byte aligned");
+    ConvK k;
+    k.in = in; k.w = w; k.bias = bias; k.cscale = cscale; k.out = out; k.bnpart = bnpart;
+    k.N = d->N; k.Ti = d->Ti; k.Hi = d->Hi; k.Wi = d->Wi; k.Ci = d->Ci; k.ldi = d->ldi;
+    k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.To = d->To; k.Ho = d->Ho; k.Wo = d->Wo; k.Co = d->Co; k.ldo = d->ldo;
+    for (int i = 0; i < 3; ++i) {
+        k.ostr[i] = d->ostr[i]; k.ooff[i] = d->ooff[i]; k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i];
+        k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; k.wkstep[i] = d->wkstep[i];
+        PC_CHECK_ARG(d->ntap[i] >= 1, "pc_conv_fwd: ntap < 1");
+    }
+    k.KH = d->KH; k.KW = d->KW; k.wtaps = d->KT * d->KH * d->KW; k.ldw = d->ldw;
+    k.K = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Ci;
+    const int64_t M = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+    PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
+    k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
+    k.act = d->act; k.flags = d->flags;
+    const TileCfg c = choose_tile(k.Mg, groups, d->Co);
+    if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128, 2, 2>(k, s);
+    if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64, 2, 2>(k, s);
+    if (c.bm == 64 && c.bn == 64) return launch_conv<64, 64, 2, 2>(k, s);
+    return launch_conv<128, 32, 4, 1>(k, s);
+}
+
+extern "C" int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const float* bias,
+                           const float* cscale, float* out, float* bnpart, pc_stream s) {
+    return pc_conv_fwd_g(d, d && d->groups > 0 ? d->groups : 1, in, w, bias, cscale, out, bnpart, (hipStream_t)s);
+}
+
+// =============================================================================================
+// Weight gradient: G[m][n] += sum_pos D[pos][m] * S[gather(pos, tap(n))][cs(n)], n = tap*Cs + cs.
+// K (positions) is split over blockIdx.z; fp32 atomics combine the slices.
+namespace {
+
+struct WgK {
+    const float* D; const float* S; float* g;
+    int N, Tq, Hq, Wq, Cd, ldd, Ts, Hs, Ws, Cs, lds;
+    int istr[3], ntap[3], ioff0[3], istep[3];
+    int P, Ntot, chunks_per_split, nchunks;
+};
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
+    constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
+    static_assert(TM >= 1 && TN >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BK][BM];
+    __shared__ __attribute__((aligned(16))) float Ss[2][BK][BN];
+    __shared__ int4 ptab[3][BK];                     // per chunk: n, t0, h0, w0 of its 32 positions
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    if (c_begin >= c_end) return;
+
+    // column decode for the S tile (constant over the K loop)
+    constexpr int SC4 = BN / 4, DC4 = BM / 4;          // float4 columns per row
+    constexpr int SRP = 256 / SC4, DRP = 256 / DC4;    // rows covered per pass
+    const int scol = (tid % SC4) * 4, srow0 = tid / SC4;
+    const int dcol = (tid % DC4) * 4, drow0 = tid / DC4;
+    const int ncol = n0 + scol;
+    const bool nval = ncol < p.Ntot;
+    const int tap = nval ? ncol / p.Cs : 0, cs = ncol - tap * p.Cs;
+    const int tapHW = p.ntap[1] * p.ntap[2];
+    const int a_ = tap / tapHW, rem = tap - a_ * tapHW, b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
+    const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
+    const bool mval = (m0 + dcol) < p.Cd;
+
+    auto ptab_fill = [&](int c) {
+        if (tid < BK) {
+            const int pos = c * BK + tid;
+            int4 info = make_int4(-1, 0, 0, 0);
+            if (c < c_end && pos < p.P) {
+                int m = pos;
+                const int wq = m % p.Wq; m /= p.Wq;
+                const int hq = m % p.Hq; m /= p.Hq;
+                const int tq = m % p.Tq; const int n = m / p.Tq;
+                info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1],
+                                 wq * p.istr[2] + p.ioff0[2]);
+            }
+            ptab[c % 3][tid] = info;
+        }
+    };
+    constexpr int DN = BK / DRP, SN = BK / SRP;        // loads per thread
+    f32x4 dreg[DN], sreg[SN];
+    auto gload = [&](int c) {
+#pragma unroll
+        for (int j = 0; j < DN; ++j) {
+            const int r = drow0 + DRP * j;
+            const int pos = c * BK + r;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (mval && pos < p.P) v = *(const f32x4*)(p.D + (size_t)pos * p.ldd + m0 + dcol);
+            dreg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < SN; ++j) {
+            const int r = srow0 + SRP * j;
+            const int4 info = ptab[c % 3][r];
+            const int t = info.y + dt, h = info.z + dh, w = info.w + dw;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
+                (unsigned)w < (unsigned)p.Ws) {
+                const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
+                v = *(const f32x4*)(p.S + ps * p.lds + cs);
+            }
+            sreg[j] = v;
+        }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < DN; ++j) *(f32x4*)&Ds[buf][drow0 + DRP * j][dcol] = dreg[j];
+#pragma unroll
+        for (int j = 0; j < SN; ++j) *(f32x4*)&Ss[buf][srow0 + SRP * j][scol] = sreg[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    ptab_fill(c_begin);
+    ptab_fill(c_begin + 1);
+    __syncthreads();
+    gload(c_begin);
+    lstore(0);
+    __syncthreads();
+    const int ml = wm * (BM / 2) + (lane & 31), nl = wn * (BN / 2) + (lane & 31), kh = lane >> 5;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        ptab_fill(c + 2);
+        if (c + 1 < c_end) gload(c + 1);
+#pragma unroll
+        for (int ks = 0; ks < BK / 2; ++ks) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][ks * 2 + kh][ml + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][ks * 2 + kh][nl + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < c_end) lstore(buf ^ 1);
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.Cd) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                if (n < p.Ntot) atomicAdd(p.g + (size_t)m * p.Ntot + n, acc[i][j][r]);
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(d && D && S && g, "pc_conv_wgrad: null pointer");
+    PC_CHECK_ARG(d->Cd % 4 == 0 && d->Cs % 4 == 0 && d->ldd % 4 == 0 && d->lds % 4 == 0,
+                 "pc_conv_wgrad: channel counts / strides must be multiples of 4 (Cd=%d Cs=%d)", d->Cd, d->Cs);
+    PC_CHECK_ARG(((uintptr_t)D % 16 == 0) && ((uintptr_t)S % 16 == 0), "pc_conv_wgrad: D/S must be 16-byte aligned");
+    WgK k;
+    k.D = D; k.S = S; k.g = g;
+    k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
+    k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
+    for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; }
+    const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+    PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad: position count out of range");
+    k.P = (int)P;
+    k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+    k.nchunks = cdiv(P, BK);
+    const bool small_m = d->Cd <= 64;
+    const int bm = small_m ? 64 : 128, bn = 128;
+    const int mt = cdiv(d->Cd, bm), ntl = cdiv(k.Ntot, bn);
+    int splitk = d->splitk;
+    if (splitk <= 0) {
+        // aim at ~4 blocks per CU overall, at least 8 chunks (256 positions) per slice
+        const int64_t tiles = (int64_t)mt * ntl;
+        splitk = (int)((1024 + tiles - 1) / tiles);
+        const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
+        if (splitk > maxsplit) splitk = maxsplit;
+        if (splitk < 1) splitk = 1;
+    }
+    if (splitk > 65535) splitk = 65535;
+    k.chunks_per_split = cdiv(k.nchunks, splitk);
+    splitk = cdiv(k.nchunks, k.chunks_per_split);
+    PC_CHECK_ARG(ntl <= 65535, "pc_conv_wgrad: too many column tiles");
+    dim3 grid(mt, ntl, splitk);
+    if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, k);
+    PC_CHECK_LAUNCH("wgrad_kernel");
+    return PC_OK;
+}

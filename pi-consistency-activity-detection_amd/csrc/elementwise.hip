@@ -1,0 +1,550 @@
+// HBM-bound members of the train step for gfx950: BatchNorm3d(train)+ReLU fwd/bwd with
+// two-pass batch groups, MaxPool3d SAME fwd/bwd, Dropout3d channel scale, activation/bias
+// backward, layout changes, batched transposes for weight re-layout, fill/axpy, fused Adam.
+// All loads/stores are float4 along the channel (innermost NDHWC) dimension.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------ BN forward
+// part [groups][npg][2][C]; stat [groups][4][C] = mean, invstd, scale, shift.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int npg, int groups,
+                                                          int C, double count, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float eps, float mom,
+                                                          float* rmean, float* rvar, float* __restrict__ stat) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float rm = 0.f, rv = 0.f;
+    const bool upd = (rmean != nullptr) && c < C;
+    if (upd) { rm = rmean[c]; rv = rvar[c]; }
+    for (int g = 0; g < groups; ++g) {
+        double s = 0.0, s2 = 0.0;
+        if (c < C)
+            for (int i = rl; i < npg; i += 4) {
+                const float* q = part + ((size_t)(g * npg + i) * 2) * C + c;
+                s += (double)q[0];
+                s2 += (double)q[C];
+            }
+        sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            s = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+            s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+            const double mean = s / count;
+            double var = s2 / count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+            const float sc = gamma[c] * invstd;
+            float* st = stat + (size_t)g * 4 * C;
+            st[c] = (float)mean; st[C + c] = invstd; st[2 * C + c] = sc; st[3 * C + c] = beta[c] - (float)mean * sc;
+            if (upd) {
+                const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+                rm = (1.f - mom) * rm + mom * (float)mean;
+                rv = (1.f - mom) * rv + mom * (float)unb;
+            }
+        }
+        __syncthreads();
+    }
+    if (upd && rl == 0) { rmean[c] = rm; rvar[c] = rv; }
+}
+
+__global__ __launch_bounds__(256) void bn_eval_stat_kernel(const float* gamma, const float* beta, const float* rm,
+                                                           const float* rv, float eps, int C, float* stat) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps), sc = gamma[c] * invstd;
+    stat[c] = rm[c]; stat[C + c] = invstd; stat[2 * C + c] = sc; stat[3 * C + c] = beta[c] - rm[c] * sc;
+}
+
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ z, int ldz, const float* __restrict__ stat,
+                                                       int C4, int64_t total4, int64_t rows_per_group, float* __restrict__ y,
+                                                       int ldy, int relu) {
+    const int C = C4 * 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / C4;
+        const int c = (int)(idx - row * C4) * 4;
+        const float* st = stat + (size_t)(row / rows_per_group) * 4 * C;
+        const f32x4 v = *(const f32x4*)(z + row * ldz + c);
+        const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh = *(const f32x4*)(st + 3 * C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e] * sc[e] + sh[e]; o[e] = relu ? fmaxf(t, 0.f) : t; }
+        *(f32x4*)(y + row * ldy + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------ column reductions
+// Generic per-channel reduction of two quantities over a block of rows.  MODE 0: BN backward
+// (sum dzh, sum dzh*xhat); MODE 1: activation backward (sum dz, unused).
+struct RedP {
+    const float* a; int lda; const float* b; int ldb; const float* stat; int C4; int64_t rows, rows_per_group;
+    int64_t rows_per_block; int act; float* part;   // part [nblk][2][C]
+};
+
+template <int MODE>
+__global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
+    __shared__ float sh[256 * 8];
+    const int C4 = p.C4, C = C4 * 4;
+    const int rpi = 256 / C4;                       // rows per iteration
+    const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4;
+    const bool active = rl < rpi;
+    const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
+    const int64_t r1 = min(p.rows, r0 + p.rows_per_block);
+    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (active) {
+        const int c = c4 * 4;
+        for (int64_t r = r0 + rl; r < r1; r += rpi) {
+            const f32x4 dy = *(const f32x4*)(p.a + r * p.lda + c);
+            const f32x4 zz = *(const f32x4*)(p.b + r * p.ldb + c);
+            if (MODE == 0) {
+                const float* st = p.stat + (size_t)(r / p.rows_per_group) * 4 * C;
+                const f32x4 mean = *(const f32x4*)(st + c), inv = *(const f32x4*)(st + C + c);
+                const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh_ = *(const f32x4*)(st + 3 * C + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float yv = zz[e] * sc[e] + sh_[e];
+                    const float d = (p.act == PC_ACT_RELU && !(yv > 0.f)) ? 0.f : dy[e];
+                    s[e] += d;
+                    s[4 + e] += d * (zz[e] - mean[e]) * inv[e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float d = dy[e];
+                    if (p.act == PC_ACT_RELU) d = zz[e] > 0.f ? d : 0.f;
+                    else if (p.act == PC_ACT_SIGMOID) d = d * zz[e] * (1.f - zz[e]);
+                    s[e] += d;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < C4) {
+        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int q = 0; q < rpi; ++q)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += sh[(q * C4 + threadIdx.x) * 8 + e];
+        float* o = p.part + (size_t)blockIdx.x * 2 * C + threadIdx.x * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { o[e] = t[e]; o[C + e] = t[4 + e]; }
+    }
+}
+
+// partials [groups][npg][2][C] -> coef [groups][2][C] = (sum_dzh/count, sum_dzh_xhat/count);
+// dgamma/dbeta (+)= sums over all groups.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
+                                                              double count, float* coef, float* dgamma, float* dbeta,
+                                                              int accum) {
+    __shared__ double sh[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < groups; ++g) {
+        double s = 0.0, s2 = 0.0;
+        if (c < C)
+            for (int i = rl; i < npg; i += 4) {
+                const float* q = part + ((size_t)(g * npg + i) * 2) * C + c;
+                s += (double)q[0];
+                s2 += (double)q[C];
+            }
+        sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
+        __syncthreads();
+        if (rl == 0 && c < C) {
+            s = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
+            s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
+            coef[(size_t)g * 2 * C + c] = (float)(s / count);
+            coef[(size_t)g * 2 * C + C + c] = (float)(s2 / count);
+            tb += s; tg += s2;
+        }
+        __syncthreads();
+    }
+    if (rl == 0 && c < C) {
+        if (dbeta) dbeta[c] = (accum ? dbeta[c] : 0.f) + (float)tb;
+        if (dgamma) dgamma[c] = (accum ? dgamma[c] : 0.f) + (float)tg;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ z,
+                                                           int ldz, const float* __restrict__ stat, const float* __restrict__ coef,
+                                                           int C4, int64_t total4, int64_t rows_per_group, int relu,
+                                                           float* __restrict__ dz, int lddz) {
+    const int C = C4 * 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / C4;
+        const int c = (int)(idx - row * C4) * 4;
+        const int g = (int)(row / rows_per_group);
+        const float* st = stat + (size_t)g * 4 * C;
+        const float* cf = coef + (size_t)g * 2 * C;
+        const f32x4 d = *(const f32x4*)(dy + row * lddy + c), zz = *(const f32x4*)(z + row * ldz + c);
+        const f32x4 mean = *(const f32x4*)(st + c), inv = *(const f32x4*)(st + C + c);
+        const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh_ = *(const f32x4*)(st + 3 * C + c);
+        const f32x4 c1 = *(const f32x4*)(cf + c), c2 = *(const f32x4*)(cf + C + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float yv = zz[e] * sc[e] + sh_[e];
+            const float dd = (relu && !(yv > 0.f)) ? 0.f : d[e];
+            o[e] = sc[e] * (dd - c1[e] - (zz[e] - mean[e]) * inv[e] * c2[e]);
+        }
+        *(f32x4*)(dz + row * lddz + c) = o;
+    }
+}
+
+// partial [nblk][2][C] -> dbias (+)=
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
+    __shared__ double sh[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s = 0.0;
+    if (c < C)
+        for (int i = rl; i < nblk; i += 4) s += (double)part[(size_t)i * 2 * C + c];
+    sh[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < C) out[c] = (accum ? out[c] : 0.f) + (float)(sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+}
+
+__global__ __launch_bounds__(256) void act_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
+                                                            int act, int C4, int64_t total4, float* __restrict__ dz, int lddz) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / C4;
+        const int c = (int)(idx - row * C4) * 4;
+        const f32x4 d = *(const f32x4*)(dy + row * lddy + c), yy = *(const f32x4*)(y + row * ldy + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = d[e];
+            if (act == PC_ACT_RELU) v = yy[e] > 0.f ? v : 0.f;
+            else if (act == PC_ACT_SIGMOID) v = v * yy[e] * (1.f - yy[e]);
+            o[e] = v;
+        }
+        *(f32x4*)(dz + row * lddz + c) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------ max pool
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const pc_pool_desc d, const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ am, int64_t total4) {
+    const int C4 = d.C / 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        int64_t pos = idx / C4;
+        const int c = (int)(idx - pos * C4) * 4;
+        const int64_t opos = pos;
+        const int wo = (int)(pos % d.Wo); pos /= d.Wo;
+        const int ho = (int)(pos % d.Ho); pos /= d.Ho;
+        const int to = (int)(pos % d.To); const int n = (int)(pos / d.To);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {255, 255, 255, 255};
+        int tap = 0;
+        for (int a = 0; a < d.k[0]; ++a) {
+            const int t = to * d.s[0] - d.padf[0] + a;
+            for (int b = 0; b < d.k[1]; ++b) {
+                const int h = ho * d.s[1] - d.padf[1] + b;
+                for (int cc = 0; cc < d.k[2]; ++cc, ++tap) {
+                    const int w = wo * d.s[2] - d.padf[2] + cc;
+                    const bool inb = (unsigned)t < (unsigned)d.Ti && (unsigned)h < (unsigned)d.Hi && (unsigned)w < (unsigned)d.Wi;
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f};   // F.pad zero (pytorch_i3d.py:44)
+                    if (inb) v = *(const f32x4*)(x + ((size_t)((n * d.Ti + t) * d.Hi + h) * d.Wi + w) * d.ldi + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[e] > best[e]) { best[e] = v[e]; bi[e] = inb ? tap : 255; }
+                }
+            }
+        }
+        *(f32x4*)(y + opos * d.ldo + c) = best;
+        *(uchar4*)(am + opos * d.C + c) = make_uchar4(bi[0], bi[1], bi[2], bi[3]);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const pc_pool_desc d, const float* __restrict__ dy, const uint8_t* __restrict__ am,
+                                                          float* __restrict__ dx, int accum, int64_t total4) {
+    const int C4 = d.C / 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        int64_t pos = idx / C4;
+        const int c = (int)(idx - pos * C4) * 4;
+        const int64_t ipos = pos;
+        const int w = (int)(pos % d.Wi); pos /= d.Wi;
+        const int h = (int)(pos % d.Hi); pos /= d.Hi;
+        const int t = (int)(pos % d.Ti); const int n = (int)(pos / d.Ti);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        int tap = 0;
+        for (int a = 0; a < d.k[0]; ++a) {
+            const int tn = t + d.padf[0] - a;
+            for (int b = 0; b < d.k[1]; ++b) {
+                const int hn = h + d.padf[1] - b;
+                for (int cc = 0; cc < d.k[2]; ++cc, ++tap) {
+                    const int wn = w + d.padf[2] - cc;
+                    if (tn < 0 || hn < 0 || wn < 0 || tn % d.s[0] || hn % d.s[1] || wn % d.s[2]) continue;
+                    const int to = tn / d.s[0], ho = hn / d.s[1], wo = wn / d.s[2];
+                    if (to >= d.To || ho >= d.Ho || wo >= d.Wo) continue;
+                    const size_t op = (size_t)((n * d.To + to) * d.Ho + ho) * d.Wo + wo;
+                    const uchar4 ix = *(const uchar4*)(am + op * d.C + c);
+                    const f32x4 v = *(const f32x4*)(dy + op * d.ldo + c);
+                    if (ix.x == tap) g[0] += v[0];
+                    if (ix.y == tap) g[1] += v[1];
+                    if (ix.z == tap) g[2] += v[2];
+                    if (ix.w == tap) g[3] += v[3];
+                }
+            }
+        }
+        float* o = dx + ipos * d.ldi + c;
+        if (accum) { const f32x4 old = *(const f32x4*)o; g += old; }
+        *(f32x4*)o = g;
+    }
+}
+
+// ------------------------------------------------------------------------------ misc elementwise
+__global__ __launch_bounds__(256) void chscale_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ sc, int64_t pos_per_n,
+                                                      int C4, int64_t total4, float* __restrict__ y, int ldy, int accum) {
+    const int C = C4 * 4;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        const int64_t row = idx / C4;
+        const int c = (int)(idx - row * C4) * 4;
+        const int64_t n = row / pos_per_n;
+        const f32x4 v = *(const f32x4*)(x + row * ldx + c), s = *(const f32x4*)(sc + n * C + c);
+        f32x4 o = v * s;
+        float* q = y + row * ldy + c;
+        if (accum) o += *(const f32x4*)q;
+        *(f32x4*)q = o;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void to_ndhwc_kernel(const T* __restrict__ src, int N, int C, int64_t thw, int W, int Cpad, int flipw,
+                                                       float* __restrict__ dst) {
+    const int64_t total = (int64_t)N * thw;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t n = idx / thw, pos = idx - n * thw;
+        int64_t sp = pos;
+        if (flipw) { const int w = (int)(pos % W); sp = pos - w + (W - 1 - w); }
+        for (int c = 0; c < Cpad; ++c)
+            dst[idx * Cpad + c] = c < C ? (float)src[(n * C + c) * thw + sp] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void to_ncdhw_kernel(const float* __restrict__ src, int ld, int N, int C, int64_t thw, float* __restrict__ dst) {
+    const int64_t total = (int64_t)N * C * thw;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t pos = idx % thw; const int64_t nc = idx / thw;
+        const int c = (int)(nc % C); const int64_t n = nc / C;
+        dst[idx] = src[(n * thw + pos) * ld + c];
+    }
+}
+
+// dst[b][c][r] (+)= src[b][r][c]   (32x32 LDS tiles; used for every weight / weight-grad re-layout)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, int R, int Cc, int64_t sbs, int sld,
+                                                        float* __restrict__ dst, int64_t dbs, int dld, int accum) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(size_t)b * sbs + (size_t)r * sld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < Cc && r < R) {
+            float* o = dst + (size_t)b * dbs + (size_t)c * dld + r;
+            *o = (accum ? *o : 0.f) + tile[tx][i];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, int64_t n, float a) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] += a * x[i];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                                                   int64_t n, float lr_bc1, float b1, float b2, float eps, float inv_sqrt_bc2, float gscale) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.f - b1) * gi;
+        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] -= lr_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
+    }
+}
+
+inline int grid_for(int64_t n, int per_thread = 1) {
+    int64_t b = (n + 256ll * per_thread - 1) / (256ll * per_thread);
+    if (b > 256 * 16) b = 256 * 16;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+inline int64_t red_rows_per_block(int64_t rows) {
+    int64_t r = (rows + 2047) / 2048;
+    if (r < 32) r = 32;
+    return r;
+}
+
+}  // namespace
+
+// ================================================================================ C ABI
+extern "C" int pc_bn_finalize(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
+                              const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                              float* running_var, float* stat, pc_stream s) {
+    PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+                       (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
+    PC_CHECK_LAUNCH("bn_finalize");
+    return PC_OK;
+}
+
+extern "C" int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                               float eps, int C, float* stat, pc_stream s) {
+    PC_CHECK_ARG(gamma && beta && running_mean && running_var && stat, "pc_bn_eval_stat: null");
+    hipLaunchKernelGGL(bn_eval_stat_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)s, gamma, beta, running_mean, running_var, eps, C, stat);
+    PC_CHECK_LAUNCH("bn_eval_stat");
+    return PC_OK;
+}
+
+extern "C" int pc_bn_apply(const float* z, int ldz, const float* stat, int C, int64_t rows, int groups, float* y, int ldy,
+                           int relu, pc_stream s) {
+    PC_CHECK_ARG(z && stat && y && C % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && groups >= 1 && rows % groups == 0, "pc_bn_apply: bad args (C=%d)", C);
+    const int64_t total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, (hipStream_t)s, z, ldz, stat, C / 4, total4, rows / groups, y, ldy, relu);
+    PC_CHECK_LAUNCH("bn_apply");
+    return PC_OK;
+}
+
+extern "C" int64_t pc_bn_bwd_ws_floats(int64_t rows, int C, int groups) {
+    const int64_t rpg = rows / groups;
+    const int64_t npg = (rpg + red_rows_per_block(rpg) - 1) / red_rows_per_block(rpg);
+    return (npg * groups * 2 + groups * 2) * (int64_t)C + 64;
+}
+
+extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, const float* stat, int C, int64_t rows, int groups,
+                         int relu, float* dz, int lddz, float* dgamma, float* dbeta, int accum, float* ws, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(dy && z && stat && dz && ws && C % 4 == 0 && C <= 1024 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 &&
+                 groups >= 1 && rows % groups == 0, "pc_bn_bwd: bad args (C=%d)", C);
+    const int64_t rpg = rows / groups, rpb = red_rows_per_block(rpg);
+    const int npg = (int)((rpg + rpb - 1) / rpb);
+    float* part = ws;
+    float* coef = ws + (size_t)npg * groups * 2 * C;
+    for (int g = 0; g < groups; ++g) {   // one launch per group keeps block row ranges inside the group
+        RedP p;
+        p.a = dy + (size_t)g * rpg * lddy; p.lda = lddy; p.b = z + (size_t)g * rpg * ldz; p.ldb = ldz;
+        p.stat = stat + (size_t)g * 4 * C; p.C4 = C / 4; p.rows = rpg; p.rows_per_group = rpg; p.rows_per_block = rpb;
+        p.act = relu ? PC_ACT_RELU : PC_ACT_NONE; p.part = part + (size_t)g * npg * 2 * C;
+        hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg), dim3(256), 0, s, p);
+    }
+    PC_CHECK_LAUNCH("bn_bwd reduce");
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
+    const int64_t total4 = rows * (C / 4);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, z, ldz, stat, coef, C / 4, total4, rpg, relu, dz, lddz);
+    PC_CHECK_LAUNCH("bn_bwd apply");
+    return PC_OK;
+}
+
+extern "C" int pc_maxpool_fwd(const pc_pool_desc* d, const float* x, float* y, uint8_t* argmax, pc_stream s) {
+    PC_CHECK_ARG(d && x && y && argmax && d->C % 4 == 0 && d->ldi % 4 == 0 && d->ldo % 4 == 0, "pc_maxpool_fwd: bad args");
+    PC_CHECK_ARG(d->k[0] * d->k[1] * d->k[2] < 255, "pc_maxpool_fwd: window too large");
+    const int64_t total4 = (int64_t)d->N * d->To * d->Ho * d->Wo * (d->C / 4);
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, x, y, argmax, total4);
+    PC_CHECK_LAUNCH("maxpool_fwd");
+    return PC_OK;
+}
+
+extern "C" int pc_maxpool_bwd(const pc_pool_desc* d, const float* dy, const uint8_t* argmax, float* dx, int accum, pc_stream s) {
+    PC_CHECK_ARG(d && dy && dx && argmax && d->C % 4 == 0 && d->ldi % 4 == 0 && d->ldo % 4 == 0, "pc_maxpool_bwd: bad args");
+    const int64_t total4 = (int64_t)d->N * d->Ti * d->Hi * d->Wi * (d->C / 4);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, dy, argmax, dx, accum, total4);
+    PC_CHECK_LAUNCH("maxpool_bwd");
+    return PC_OK;
+}
+
+extern "C" int pc_channel_scale(const float* x, int ldx, const float* scale, int N, int64_t pos_per_n, int C, float* y, int ldy,
+                                int accum, pc_stream s) {
+    PC_CHECK_ARG(x && scale && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "pc_channel_scale: bad args");
+    const int64_t total4 = (int64_t)N * pos_per_n * (C / 4);
+    hipLaunchKernelGGL(chscale_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, (hipStream_t)s, x, ldx, scale, pos_per_n, C / 4, total4, y, ldy, accum);
+    PC_CHECK_LAUNCH("channel_scale");
+    return PC_OK;
+}
+
+extern "C" int64_t pc_act_bwd_ws_floats(int64_t rows, int C) {
+    const int64_t rpb = red_rows_per_block(rows);
+    return ((rows + rpb - 1) / rpb) * 2 * (int64_t)C + 64;
+}
+
+extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, int act, int C, int64_t rows, float* dz, int lddz,
+                          float* dbias, int accum, float* ws, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(dy && y && C % 4 == 0 && C <= 1024 && lddy % 4 == 0 && ldy % 4 == 0, "pc_act_bwd: bad args (C=%d)", C);
+    if (dbias) {
+        PC_CHECK_ARG(ws, "pc_act_bwd: ws required for dbias");
+        const int64_t rpb = red_rows_per_block(rows);
+        const int nblk = (int)((rows + rpb - 1) / rpb);
+        RedP p;
+        p.a = dy; p.lda = lddy; p.b = y; p.ldb = ldy; p.stat = nullptr; p.C4 = C / 4; p.rows = rows; p.rows_per_group = rows;
+        p.rows_per_block = rpb; p.act = act; p.part = ws;
+        hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 0, s, p);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, ws, nblk, C, dbias, accum);
+    }
+    if (dz && (act != PC_ACT_NONE || dz != dy)) {
+        PC_CHECK_ARG(lddz % 4 == 0, "pc_act_bwd: lddz");
+        const int64_t total4 = rows * (C / 4);
+        hipLaunchKernelGGL(act_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, y, ldy, act, C / 4, total4, dz, lddz);
+    }
+    PC_CHECK_LAUNCH("act_bwd");
+    return PC_OK;
+}
+
+extern "C" int pc_ncdhw_to_ndhwc(const void* src, int src_is_f64, int N, int C, int64_t thw, int W, int Cpad, int flipw, float* dst, pc_stream s) {
+    PC_CHECK_ARG(src && dst && Cpad >= C && W > 0 && thw % W == 0, "pc_ncdhw_to_ndhwc: bad args");
+    const int64_t total = (int64_t)N * thw;
+    if (src_is_f64) hipLaunchKernelGGL(to_ndhwc_kernel<double>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const double*)src, N, C, thw, W, Cpad, flipw, dst);
+    else hipLaunchKernelGGL(to_ndhwc_kernel<float>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const float*)src, N, C, thw, W, Cpad, flipw, dst);
+    PC_CHECK_LAUNCH("to_ndhwc");
+    return PC_OK;
+}
+
+extern "C" int pc_ndhwc_to_ncdhw(const float* src, int ld, int N, int C, int64_t thw, float* dst, pc_stream s) {
+    PC_CHECK_ARG(src && dst, "pc_ndhwc_to_ncdhw: null");
+    hipLaunchKernelGGL(to_ncdhw_kernel, dim3(grid_for((int64_t)N * C * thw)), dim3(256), 0, (hipStream_t)s, src, ld, N, C, thw, dst);
+    PC_CHECK_LAUNCH("to_ncdhw");
+    return PC_OK;
+}
+
+extern "C" int pc_transpose_batched(const float* src, int batch, int R, int Cc, int64_t src_batch_stride, int src_ld, float* dst,
+                                    int64_t dst_batch_stride, int dst_ld, int accum, pc_stream s) {
+    PC_CHECK_ARG(src && dst && batch >= 1 && batch <= 65535 && R >= 1 && Cc >= 1, "pc_transpose_batched: bad args");
+    PC_CHECK_ARG(cdiv(R, 32) <= 65535, "pc_transpose_batched: too many row tiles");
+    hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), batch), dim3(256), 0, (hipStream_t)s, src, R, Cc, src_batch_stride,
+                       src_ld, dst, dst_batch_stride, dst_ld, accum);
+    PC_CHECK_LAUNCH("transpose");
+    return PC_OK;
+}
+
+extern "C" int pc_fill(float* p, int64_t n, float v, pc_stream s) {
+    PC_CHECK_ARG(p || n == 0, "pc_fill: null");
+    if (n == 0) return PC_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, p, n, v);
+    PC_CHECK_LAUNCH("fill");
+    return PC_OK;
+}
+
+extern "C" int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s) {
+    PC_CHECK_ARG((y && x) || n == 0, "pc_axpy: null");
+    if (n == 0) return PC_OK;
+    hipLaunchKernelGGL(axpy_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, y, x, n, a);
+    PC_CHECK_LAUNCH("axpy");
+    return PC_OK;
+}
+
+extern "C" int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
+                            float gscale, pc_stream s) {
+    PC_CHECK_ARG(p && g && m && v && step >= 1, "pc_adam_step: bad args");
+    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
+                       (float)(1.0 / sqrt(bc2)), gscale);
+    PC_CHECK_LAUNCH("adam");
+    return PC_OK;
+}

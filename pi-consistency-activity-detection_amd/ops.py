@@ -1,0 +1,219 @@
+"""Thin torch-tensor wrappers over the C-ABI (one per entry point).  PyTorch is used for device
+memory and streams only; every wrapper launches HIP kernels from libpicons.so on torch's current
+stream and raises if the tensor is not on a GPU - there is no CPU path."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi, desc as D
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("picons ops need CUDA/HIP tensors (no CPU fallback)")
+    return C.c_void_p(t.data_ptr())
+
+
+def _fill_struct(st, d):
+    for name, ctype in st._fields_:
+        v = d[name]
+        if isinstance(v, (list, tuple)):
+            setattr(st, name, (C.c_int32 * 3)(*[int(x) for x in v]))
+        else:
+            setattr(st, name, ctype(v))
+    return st
+
+
+def conv_desc(d):
+    return _fill_struct(capi.ConvDesc(), d)
+
+
+def conv_bnpart_rows(d):
+    return capi.lib().pc_conv_bnpart_rows(C.byref(conv_desc(d)))
+
+
+def conv_fwd(d, x, w, out, bias=None, cscale=None, bnpart=None):
+    capi.call("pc_conv_fwd", C.byref(conv_desc(d)), ptr(x), ptr(w), ptr(bias), ptr(cscale), ptr(out), ptr(bnpart), stream())
+    return out
+
+
+def conv_wgrad(d, Dt, St, g):
+    capi.call("pc_conv_wgrad", C.byref(_fill_struct(capi.WgradDesc(), d)), ptr(Dt), ptr(St), ptr(g), stream())
+    return g
+
+
+def bn_finalize(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean=None, rvar=None):
+    stat = torch.empty(groups, 4, C_, device=part.device, dtype=torch.float32)
+    capi.call("pc_bn_finalize", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+              ptr(stat), stream())
+    return stat
+
+
+def bn_apply(z, ldz, stat, C_, rows, groups, y, ldy, relu=True):
+    capi.call("pc_bn_apply", ptr(z), ldz, ptr(stat), C_, int(rows), groups, ptr(y), ldy, int(relu), stream())
+    return y
+
+
+def bn_eval_stat(gamma, beta, rm, rv, eps):
+    stat = torch.empty(1, 4, gamma.numel(), device=gamma.device, dtype=torch.float32)
+    capi.call("pc_bn_eval_stat", ptr(gamma), ptr(beta), ptr(rm), ptr(rv), eps, gamma.numel(), ptr(stat), stream())
+    return stat
+
+
+def bn_bwd(dy, lddy, z, ldz, stat, C_, rows, groups, relu, dz, lddz, dgamma, dbeta, accum=False):
+    ws = torch.empty(capi.lib().pc_bn_bwd_ws_floats(int(rows), C_, groups), device=dy.device, dtype=torch.float32)
+    capi.call("pc_bn_bwd", ptr(dy), lddy, ptr(z), ldz, ptr(stat), C_, int(rows), groups, int(relu), ptr(dz), lddz, ptr(dgamma), ptr(dbeta),
+              int(accum), ptr(ws), stream())
+    return dz
+
+
+def maxpool_fwd(d, x, y, argmax):
+    capi.call("pc_maxpool_fwd", C.byref(_fill_struct(capi.PoolDesc(), d)), ptr(x), ptr(y), ptr(argmax), stream())
+
+
+def maxpool_bwd(d, dy, argmax, dx, accum=False):
+    capi.call("pc_maxpool_bwd", C.byref(_fill_struct(capi.PoolDesc(), d)), ptr(dy), ptr(argmax), ptr(dx), int(accum), stream())
+
+
+def channel_scale(x, ldx, scale, N, pos_per_n, C_, y, ldy, accum=False):
+    capi.call("pc_channel_scale", ptr(x), ldx, ptr(scale), N, int(pos_per_n), C_, ptr(y), ldy, int(accum), stream())
+
+
+def act_bwd(dy, lddy, y, ldy, act, C_, rows, dz, lddz, dbias=None, accum=False):
+    ws = torch.empty(capi.lib().pc_act_bwd_ws_floats(int(rows), C_), device=dy.device, dtype=torch.float32)
+    capi.call("pc_act_bwd", ptr(dy), lddy, ptr(y), ldy, act, C_, int(rows), ptr(dz), lddz, ptr(dbias), int(accum), ptr(ws), stream())
+
+
+def to_ndhwc(src, Cpad=None, flipw=False):
+    """src (N,C,T,H,W) fp32/fp64 contiguous -> (N,T,H,W,Cpad) fp32."""
+    N, Cc, T, H, W = src.shape
+    Cpad = Cpad or Cc
+    dst = torch.empty(N, T, H, W, Cpad, device=src.device, dtype=torch.float32)
+    capi.call("pc_ncdhw_to_ndhwc", ptr(src.contiguous()), int(src.dtype == torch.float64), N, Cc, T * H * W, W, Cpad, int(flipw), ptr(dst), stream())
+    return dst
+
+
+def to_ncdhw(src, C_=None):
+    N, T, H, W, ld = src.shape
+    C_ = C_ or ld
+    dst = torch.empty(N, C_, T, H, W, device=src.device, dtype=torch.float32)
+    capi.call("pc_ndhwc_to_ncdhw", ptr(src), ld, N, C_, T * H * W, ptr(dst), stream())
+    return dst
+
+
+def transpose_batched(src, batch, R, Cc, sbs, sld, dst, dbs, dld, accum=False):
+    capi.call("pc_transpose_batched", ptr(src), batch, R, Cc, int(sbs), sld, ptr(dst), int(dbs), dld, int(accum), stream())
+
+
+def em_fwd(x, W, bu, ba, npos, B, C_):
+    out = torch.empty(npos, C_ * 17, device=x.device, dtype=torch.float32)
+    capi.call("pc_em_routing_fwd", ptr(x), ptr(W), ptr(bu), ptr(ba), npos, B, C_, ptr(out), stream())
+    return out
+
+
+def em_bwd(x, W, bu, ba, dout, npos, B, C_, dW, dbu, dba):
+    dx = torch.empty_like(x)
+    ws = torch.empty(capi.lib().pc_em_ws_floats(npos, B, C_), device=x.device, dtype=torch.float32)
+    capi.call("pc_em_routing_bwd", ptr(x), ptr(W), ptr(bu), ptr(ba), ptr(dout), npos, B, C_, ptr(dx), ptr(dW), ptr(dbu), ptr(dba), ptr(ws), stream())
+    return dx
+
+
+def class_mask_fwd(caps, Bn, npos, C_, cls, labeled, mode):
+    dev = caps.device
+    pred = torch.empty(Bn, C_, device=dev); mask = torch.empty(Bn, C_, device=dev)
+    masked = torch.empty(Bn, npos, C_ * 16, device=dev)
+    capi.call("pc_class_mask_fwd", ptr(caps), Bn, npos, C_, ptr(cls), ptr(labeled), mode, ptr(pred), ptr(mask), ptr(masked), stream())
+    return pred, mask, masked
+
+
+def class_mask_bwd(dmasked, dpred, mask, Bn, npos, C_):
+    dcaps = torch.empty(Bn, npos, C_ * 17, device=dmasked.device)
+    capi.call("pc_class_mask_bwd", ptr(dmasked), ptr(dpred), ptr(mask), Bn, npos, C_, ptr(dcaps), stream())
+    return dcaps
+
+
+def tapsum_fwd(proj, bias):
+    N, T, H, W, _ = proj.shape
+    out = torch.empty(N, T, H, W, device=proj.device)
+    capi.call("pc_tapsum_fwd", ptr(proj), N, T, H, W, ptr(bias), ptr(out), stream())
+    return out
+
+
+def tapsum_bwd(dout):
+    N, T, H, W = dout.shape
+    dproj = torch.empty(N, T, H, W, 32, device=dout.device)
+    capi.call("pc_tapsum_bwd", ptr(dout), N, T, H, W, ptr(dproj), stream())
+    return dproj
+
+
+def loss_desc(B, T, H, W, bv=False, gv=False, n_frames=3, predict_maps=False, jhmdb=False, lower=None, upper=None,
+              bv_wt=0.5, gv_wt=0.5, wt_loc=1.0, wt_cons=1.0, wt_ramp=0.0):
+    d = capi.LossDesc()
+    d.B, d.T, d.H, d.W = B, T, H, W
+    d.bv, d.gv, d.n_frames, d.predict_maps, d.jhmdb = int(bv), int(gv), n_frames, int(predict_maps), int(jhmdb)
+    d.lower_thresh = -1.0 if lower is None else lower
+    d.upper_thresh = -1.0 if upper is None else upper
+    d.bv_wt, d.gv_wt, d.wt_loc, d.wt_cons, d.wt_ramp = bv_wt, gv_wt, wt_loc, wt_cons, wt_ramp
+    return d
+
+
+def consistency_loss(d, output, flip_op, seg, labeled, want_masks=False):
+    """output, flip_op, seg: (B,1,8,H,W) fp32 contiguous; labeled int32 (B,).  Returns
+    (scalars[8], d_output, d_flip_op, mask_bv, mask_gv)."""
+    dev = output.device
+    scal = torch.zeros(8, device=dev)
+    dO = torch.empty_like(output); dF = torch.empty_like(flip_op)
+    mb = torch.zeros_like(output) if want_masks else None
+    mg = torch.zeros_like(output) if want_masks else None
+    ws = torch.empty(capi.lib().pc_loss_ws_floats(C.byref(d)), device=dev, dtype=torch.float32)
+    capi.call("pc_consistency_loss", C.byref(d), ptr(output), ptr(flip_op), ptr(seg), ptr(labeled), ptr(scal), ptr(dO), ptr(dF),
+              ptr(mb), ptr(mg), ptr(ws), stream())
+    return scal, dO, dF, mb, mg
+
+
+def var_mask(pred, flip_pred, n_frames=5, use_sig=False):
+    B, _, T, H, W = pred.shape
+    d = loss_desc(B, T, H, W)
+    ws = torch.empty(capi.lib().pc_loss_ws_floats(C.byref(d)), device=pred.device, dtype=torch.float32)
+    m = torch.empty(B, 1, T, H, W, device=pred.device)
+    capi.call("pc_var_mask", ptr(pred.contiguous()), ptr(flip_pred.contiguous()), B, T, H, W, n_frames, int(use_sig), ptr(m), ptr(ws), stream())
+    return m
+
+
+def grad_mask(pred, lower=None, upper=None):
+    B, _, T, H, W = pred.shape
+    d = loss_desc(B, T, H, W)
+    ws = torch.empty(capi.lib().pc_loss_ws_floats(C.byref(d)), device=pred.device, dtype=torch.float32)
+    m = torch.empty(B, T, H, W, device=pred.device)
+    capi.call("pc_grad_mask", ptr(pred.contiguous()), B, T, H, W, -1.0 if lower is None else lower, -1.0 if upper is None else upper,
+              ptr(m), ptr(ws), stream())
+    return m
+
+
+def spread_loss(x, cls, labeled, m=0.2, wt=1.0, dx=None):
+    out = torch.empty(2, device=x.device)
+    capi.call("pc_spread_loss", ptr(x), ptr(cls), ptr(labeled), x.shape[0], x.shape[1], m, wt, ptr(out), ptr(dx), stream())
+    return out
+
+
+def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-6, gscale=1.0):
+    capi.call("pc_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, step, gscale, stream())
+
+
+def run_ops(ops_np, n=None):
+    """ops_np: numpy array of capi.OP_DTYPE (host memory); replayed by the library."""
+    n = len(ops_np) if n is None else n
+    capi.call("pc_run_ops", C.c_void_p(ops_np.ctypes.data), n, stream())
+
+
+def run_ops_timed(ops_np, kind):
+    ms = C.c_float(0); cnt = C.c_int32(0)
+    capi.call("pc_run_ops_timed", C.c_void_p(ops_np.ctypes.data), len(ops_np), kind, C.byref(ms), C.byref(cnt), stream())
+    return ms.value, cnt.value

@@ -1,0 +1,53 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/picons.h
+declares (no compute calls without a GPU); product ops refuse CPU tensors."""
+import os
+import re
+
+import pytest
+import torch
+
+import __graft_entry__ as ge
+from picons_amd import capi, desc, ops
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    if not os.path.exists(capi.LIB_PATH):
+        ge.build()
+    return capi.lib()
+
+
+def test_header_symbols_exported(built):
+    hdr = open(os.path.join(ROOT, "include", "picons.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = sorted(set(re.findall(r"\b(pc_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(built, n), "libpicons.so does not export %s" % n
+    assert sorted(n for n in names) == sorted(capi.EXPORTS), set(names) ^ set(capi.EXPORTS)
+    assert built.pc_version() >= 100
+
+
+def test_struct_layouts_match_header(built):
+    import ctypes as C
+    assert C.sizeof(capi.ConvDesc) == 45 * 4
+    assert C.sizeof(capi.WgradDesc) == 24 * 4
+    assert C.sizeof(capi.PoolDesc) == 19 * 4
+    assert C.sizeof(capi.LossDesc) == 16 * 4
+    assert capi.OP_DTYPE.itemsize == 360 and capi.OP_DTYPE.fields["p"][1] == 232
+    assert len(desc.flatten(desc.conv_fwd(1, (1, 2, 2), 4, 4, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)), desc.CONV_FIELDS)) == 45
+
+
+def test_no_cpu_fallback(built):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.conv_fwd(desc.conv_fwd(1, (1, 2, 2), 4, 4, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)),
+                     torch.zeros(1, 1, 2, 2, 4), torch.zeros(4, 1, 4), torch.zeros(1, 1, 2, 2, 4))
+
+
+def test_bad_descriptor_is_reported_without_gpu(built):
+    import ctypes as C
+    d = ops.conv_desc(desc.conv_fwd(1, (1, 2, 2), 3, 3, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)))
+    rc = built.pc_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, None)
+    assert rc == -1 and b"multiples of 4" in built.pc_last_error()

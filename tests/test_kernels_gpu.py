@@ -1,0 +1,397 @@
+"""GPU parity of every HIP kernel family (through the C-ABI) against the CPU oracle / plain torch
+fp32 on the same seeded inputs.  Tolerances: fp32 contraction noise only (1e-4 relative)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import caps as ocaps, i3d as oi3d, losses as olosses
+from picons_amd import capi, desc, ops, spec
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def cl(x):
+    """NCDHW cpu -> NDHWC cuda contiguous fp32"""
+    return x.detach().permute(0, 2, 3, 4, 1).contiguous().float().to(DEV)
+
+
+def uncl(x):
+    return x.detach().cpu().permute(0, 4, 1, 2, 3).contiguous()
+
+
+def close(a, b, rtol=2e-4, atol=None, what=""):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = b.abs().max().item() + 1e-30
+    atol = rtol * scale if atol is None else atol
+    err = (a - b).abs().max().item()
+    assert err <= atol, "%s: max err %.3e > %.3e (scale %.3e)" % (what, err, atol, scale)
+
+
+def w_oki(w, pad_to=None):
+    O, I = w.shape[:2]
+    taps = int(np.prod(w.shape[2:]))
+    t = w.detach().reshape(O, I, taps).permute(0, 2, 1).contiguous()
+    if pad_to and pad_to > I:
+        t = F.pad(t, (0, pad_to - I))
+    return t.contiguous().float().to(DEV)
+
+
+def w_iko(w):
+    O, I = w.shape[:2]
+    taps = int(np.prod(w.shape[2:]))
+    return w.detach().reshape(O, I, taps).permute(1, 2, 0).contiguous().float().to(DEV)
+
+
+CONV_CASES = [
+    (16, 24, (3, 3, 3), (2, 1, 1), (4, 12, 12), 2),
+    (4, 64, (7, 7, 7), (2, 2, 2), (8, 30, 30), 2),
+    (64, 16, (1, 1, 1), (1, 1, 1), (2, 9, 9), 3),
+    (32, 200, (3, 3, 3), (1, 1, 1), (2, 14, 14), 2),
+    (48, 136, (1, 3, 3), (1, 1, 1), (1, 20, 20), 4),
+]
+
+
+@pytest.mark.parametrize("Ci,Co,k,s,thw,N", CONV_CASES)
+def test_conv_same_fwd_dgrad_wgrad(Ci, Co, k, s, thw, N):
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Ci, *thw, generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, *k, generator=g) / np.sqrt(Ci * np.prod(k))).requires_grad_(True)
+    pads = [spec.same_pad(thw[i], k[i], s[i]) for i in range(3)]
+    xp = F.pad(x, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    y = F.conv3d(xp, w, None, s)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    othw = tuple(y.shape[2:]); pf = [p[0] for p in pads]
+    xg, dyg = cl(x), cl(dy)
+    out = torch.empty(N, *othw, Co, device=DEV)
+    ops.conv_fwd(desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, s, pf, othw), xg, w_oki(w), out)
+    close(uncl(out), y, what="fwd")
+    dx = torch.full((N, *thw, Ci), 7.0, device=DEV)
+    for dd in desc.transposed_classes(N, othw, Co, Co, thw, Ci, Ci, k, s, pf):
+        ops.conv_fwd(dd, dyg, w_iko(w), dx)
+    close(uncl(dx), x.grad, what="dgrad")
+    taps = int(np.prod(k))
+    gw = torch.zeros(Co, taps, Ci, device=DEV)
+    ops.conv_wgrad(desc.wgrad(N, othw, Co, Co, thw, Ci, Ci, k, s, pf), dyg, xg, gw)
+    close(gw.cpu(), w.grad.reshape(Co, Ci, taps).permute(0, 2, 1), what="wgrad")
+
+
+def test_conv_epilogue_bias_act_cscale_accum_slice():
+    g = torch.Generator().manual_seed(6)
+    N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)
+    x = torch.randn(N, Ci, *thw, generator=g); w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g); cs = (torch.rand(N, Co, generator=g) < 0.5).float() * 2
+    ref = torch.relu(F.conv3d(x, w, b, padding=1)) * cs.view(N, Co, 1, 1, 1)
+    wide = torch.full((N, *thw, 64), 3.0, device=DEV)          # write into channel slice [8, 48) of a 64-wide tensor
+    d = desc.conv_fwd(N, thw, Ci, Ci, Co, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), thw, act=capi.ACT_RELU,
+                      flags=capi.F_BIAS | capi.F_CSCALE)
+    ops.conv_fwd(d, cl(x), w_oki(w), wide[..., 8:], bias=b.to(DEV), cscale=cs.to(DEV))
+    close(uncl(wide[..., 8:48]), ref, what="epilogue")
+    assert (wide[..., :8] == 3.0).all() and (wide[..., 48:] == 3.0).all()
+    d["flags"] |= capi.F_ACCUM
+    ops.conv_fwd(d, cl(x), w_oki(w), wide[..., 8:], bias=b.to(DEV), cscale=cs.to(DEV))
+    close(uncl(wide[..., 8:48]), 2 * ref, what="accumulate")
+    d2 = desc.conv_fwd(N, thw, Ci, Ci, 32, 32, (3, 3, 3), (1, 1, 1), (1, 1, 1), thw, act=capi.ACT_SIGMOID, flags=capi.F_BIAS)
+    o2 = torch.empty(N, *thw, 32, device=DEV)
+    ops.conv_fwd(d2, cl(x), w_oki(w[:32]), o2, bias=b[:32].to(DEV))
+    close(uncl(o2), torch.sigmoid(F.conv3d(x, w[:32], b[:32], padding=1)), what="sigmoid")
+
+
+TCASES = [
+    (128, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (1, 7, 7), 2),
+    (16, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (2, 6, 5), 2),
+    (48, 64, (1, 9, 9), (1, 1, 1), (0, 0, 0), (0, 0, 0), (1, 6, 6), 2),
+    (128, 4, (3, 3, 3), (1, 1, 1), (1, 1, 1), (0, 0, 0), (3, 6, 6), 1),
+]
+
+
+@pytest.mark.parametrize("Ci,Co,k,s,pd,op,thw,N", TCASES)
+def test_conv_transpose(Ci, Co, k, s, pd, op, thw, N):
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, Ci, *thw, generator=g, requires_grad=True)
+    w = (torch.randn(Ci, Co, *k, generator=g) * 0.05).requires_grad_(True)
+    y = F.conv_transpose3d(x, w, None, s, pd, op)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    othw = tuple(y.shape[2:]); taps = int(np.prod(k))
+    wt_oki = w.detach().reshape(Ci, Co, taps).permute(1, 2, 0).contiguous().to(DEV)
+    wt_iko = w.detach().reshape(Ci, Co, taps).permute(0, 2, 1).contiguous().to(DEV)
+    out = torch.full((N, *othw, Co), -5.0, device=DEV)
+    for dd in desc.transposed_classes(N, thw, Ci, Ci, othw, Co, Co, k, s, pd):
+        ops.conv_fwd(dd, cl(x), wt_oki, out)
+    close(uncl(out), y, what="convT fwd")
+    dx = torch.empty(N, *thw, Ci, device=DEV)
+    ops.conv_fwd(desc.conv_fwd(N, othw, Co, Co, Ci, Ci, k, s, pd, thw), cl(dy), wt_iko, dx)
+    close(uncl(dx), x.grad, what="convT dgrad")
+    gw = torch.zeros(Ci, taps, Co, device=DEV)
+    ops.conv_wgrad(desc.wgrad(N, thw, Ci, Ci, othw, Co, Co, k, s, pd), cl(x), cl(dy), gw)
+    close(gw.cpu(), w.grad.reshape(Ci, Co, taps).permute(0, 2, 1), what="convT wgrad")
+
+
+@pytest.mark.parametrize("groups", [1, 2])
+def test_unit3d_bn_relu_fwd_bwd(groups):
+    """conv (BN partials in the epilogue) -> finalize -> apply, and the backward, vs oracle Unit3D
+    run once per group (the reference's two sequential forward passes)."""
+    g = torch.Generator().manual_seed(8)
+    N, Ci, Co, thw, k, s = 4, 16, 40, (4, 10, 10), (3, 3, 3), (2, 1, 1)
+    x = torch.randn(N, Ci, *thw, generator=g)
+    w = torch.randn(Co, Ci, *k, generator=g) * 0.1
+    gamma = torch.rand(Co, generator=g) + 0.5; beta = torch.randn(Co, generator=g) * 0.1
+    P = {"u.conv3d.weight": w.clone().requires_grad_(True), "u.bn.weight": gamma.clone().requires_grad_(True),
+         "u.bn.bias": beta.clone().requires_grad_(True), "u.bn.running_mean": torch.zeros(Co), "u.bn.running_var": torch.ones(Co)}
+    xs = x.clone().requires_grad_(True)
+    ys = [oi3d.unit3d(P, "u", xs[i * (N // groups):(i + 1) * (N // groups)], s, True) for i in range(groups)]
+    y = torch.cat(ys)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    othw = tuple(y.shape[2:]); pf = [spec.same_pad(thw[i], k[i], s[i])[0] for i in range(3)]
+    d = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, s, pf, othw, flags=capi.F_BNPART, groups=groups)
+    rows = N * int(np.prod(othw))
+    nrows = ops.conv_bnpart_rows(d)
+    part = torch.zeros(nrows, 2, Co, device=DEV)
+    z = torch.empty(N, *othw, Co, device=DEV)
+    ops.conv_fwd(d, cl(x), w_oki(w), z, bnpart=part)
+    rm = torch.zeros(Co, device=DEV); rv = torch.ones(Co, device=DEV)
+    stat = ops.bn_finalize(part, nrows // groups, groups, Co, rows // groups, gamma.to(DEV), beta.to(DEV), spec.BN_EPS, spec.BN_MOMENTUM, rm, rv)
+    yg = torch.empty_like(z)
+    ops.bn_apply(z, Co, stat, Co, rows, groups, yg, Co, True)
+    close(uncl(yg), y, what="bn+relu fwd")
+    close(rm.cpu(), P["u.bn.running_mean"], atol=1e-6, what="running_mean")
+    close(rv.cpu(), P["u.bn.running_var"], atol=1e-6, what="running_var")
+    dz = torch.empty_like(z); dgam = torch.zeros(Co, device=DEV); dbet = torch.zeros(Co, device=DEV)
+    ops.bn_bwd(cl(dy), Co, z, Co, stat, Co, rows, groups, True, dz, Co, dgam, dbet)
+    close(dgam.cpu(), P["u.bn.weight"].grad, what="dgamma")
+    close(dbet.cpu(), P["u.bn.bias"].grad, what="dbeta")
+    dx = torch.empty(N, *thw, Ci, device=DEV)
+    for dd in desc.transposed_classes(N, othw, Co, Co, thw, Ci, Ci, k, s, pf):
+        ops.conv_fwd(dd, dz, w_iko(w), dx)
+    close(uncl(dx), xs.grad, what="dx through bn")
+    ev = ops.bn_eval_stat(gamma.to(DEV), beta.to(DEV), rm, rv, spec.BN_EPS)
+    ye = torch.empty_like(z)
+    ops.bn_apply(z, Co, ev, Co, rows, 1, ye, Co, True)
+    ref_e = torch.relu(F.batch_norm(uncl(z), rm.cpu(), rv.cpu(), gamma, beta, False, 0.0, spec.BN_EPS))
+    close(uncl(ye), ref_e, what="bn eval")
+
+
+@pytest.mark.parametrize("tag", ["p133", "p333s2", "p333s1", "p133odd"])
+def test_maxpool_golden(golden_dir, tag):
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    x = torch.from_numpy(G[tag + "_x"]); k = [int(v) for v in G[tag + "_k"]]; s = [int(v) for v in G[tag + "_s"]]
+    N, C_, T, H, W = x.shape
+    othw = [spec.same_out((T, H, W)[i], k[i], s[i]) for i in range(3)]
+    padf = [spec.same_pad((T, H, W)[i], k[i], s[i])[0] for i in range(3)]
+    d = desc.pool(N, (T, H, W), C_, C_, othw, C_, k, s, padf)
+    y = torch.empty(N, *othw, C_, device=DEV); am = torch.empty(N, *othw, C_, device=DEV, dtype=torch.uint8)
+    ops.maxpool_fwd(d, cl(x), y, am)
+    close(uncl(y), torch.from_numpy(G[tag + "_y"]), atol=0, what="pool fwd")
+    dx = torch.empty(N, T, H, W, C_, device=DEV)
+    ops.maxpool_bwd(d, cl(torch.from_numpy(G[tag + "_dy"])), am, dx)
+    close(uncl(dx), torch.from_numpy(G[tag + "_dx"]), atol=1e-6, what="pool bwd")
+
+
+def test_elementwise_helpers():
+    g = torch.Generator().manual_seed(9)
+    x = torch.rand(2, 3, 8, 6, 10, generator=g, dtype=torch.float64)
+    a = ops.to_ndhwc(x.to(DEV), 4)
+    assert torch.equal(a[..., :3].cpu(), x.float().permute(0, 2, 3, 4, 1)) and (a[..., 3] == 0).all()
+    b = ops.to_ndhwc(x.to(DEV), 4, flipw=True)
+    assert torch.equal(b[..., :3].cpu(), x.float().flip(4).permute(0, 2, 3, 4, 1))
+    assert torch.equal(ops.to_ncdhw(a, 3).cpu(), x.float())
+    t = torch.randn(2, 5, 1, 4, 8, generator=g).to(DEV); sc = torch.rand(2, 8, generator=g).to(DEV)
+    y = torch.empty_like(t)
+    ops.channel_scale(t, 8, sc, 2, 5 * 4, 8, y, 8)
+    assert torch.allclose(y, t * sc.view(2, 1, 1, 1, 8))
+    src = torch.randn(3, 37, 50, generator=g).to(DEV); dst = torch.zeros(3, 50, 37, device=DEV)
+    ops.transpose_batched(src, 3, 37, 50, 37 * 50, 50, dst, 50 * 37, 37)
+    assert torch.equal(dst, src.transpose(1, 2))
+    ops.transpose_batched(src, 3, 37, 50, 37 * 50, 50, dst, 50 * 37, 37, accum=True)
+    assert torch.allclose(dst, 2 * src.transpose(1, 2))
+    # activation backward + bias grad
+    yv = torch.rand(70, 24, generator=g).to(DEV); dyv = torch.randn(70, 24, generator=g).to(DEV)
+    for act, f in ((capi.ACT_RELU, lambda v: (v > 0.5).float()), (capi.ACT_SIGMOID, lambda v: v * (1 - v)), (capi.ACT_NONE, lambda v: torch.ones_like(v))):
+        yy = (yv - 0.5).clamp(min=0) if act == capi.ACT_RELU else yv
+        dz = torch.empty_like(dyv); db = torch.zeros(24, device=DEV)
+        ops.act_bwd(dyv, 24, yy, 24, act, 24, 70, dz, 24, db)
+        ref = dyv * (f(yv) if act != capi.ACT_RELU else (yy > 0).float())
+        assert torch.allclose(dz, ref, atol=1e-6) and torch.allclose(db, ref.sum(0), atol=1e-4)
+    p = torch.randn(1000, generator=g).to(DEV); gr = torch.randn(1000, generator=g).to(DEV)
+    m = torch.zeros(1000, device=DEV); v = torch.zeros(1000, device=DEV)
+    pr = p.clone().cpu().requires_grad_(True); opt = torch.optim.Adam([pr], lr=1e-3, eps=1e-6)
+    for stp in (1, 2, 3):
+        pr.grad = gr.cpu().clone(); opt.step()
+        ops.adam_step(p, gr, m, v, 1e-3, stp)
+    assert torch.allclose(p.cpu(), pr.detach(), atol=1e-6)
+
+
+@pytest.mark.parametrize("C_,npos", [(24, 37), (21, 20)])
+def test_em_routing_fwd_bwd(C_, npos):
+    g = torch.Generator().manual_seed(10)
+    B = 32
+    x = torch.cat([torch.randn(npos, B * 16, generator=g), torch.rand(npos, B, generator=g)], 1).requires_grad_(True)
+    W = (torch.randn(1, B, C_, 4, 4, generator=g) * 0.5).requires_grad_(True)
+    bu = torch.randn(C_, 16, generator=g).requires_grad_(True); ba = torch.randn(C_, generator=g).requires_grad_(True)
+    v = ocaps.votes(x[:, :B * 16].reshape(npos, B, 16), W)
+    mu, a_out = ocaps.em_routing(v, x[:, B * 16:].reshape(npos, B, 1), bu, ba)
+    out = torch.cat([mu.reshape(npos, C_ * 16), a_out.reshape(npos, C_)], 1)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    xg = x.detach().to(DEV)
+    og = ops.em_fwd(xg, W.detach().to(DEV), bu.detach().to(DEV), ba.detach().to(DEV), npos, B, C_)
+    close(og[:, :C_ * 16], out[:, :C_ * 16], rtol=1e-4, what="mu")
+    close(og[:, C_ * 16:], out[:, C_ * 16:], atol=2e-6, what="a_out")
+    dW = torch.zeros(B, C_, 4, 4, device=DEV); dbu = torch.zeros(C_, 16, device=DEV); dba = torch.zeros(C_, device=DEV)
+    dx = ops.em_bwd(xg, W.detach().to(DEV), bu.detach().to(DEV), ba.detach().to(DEV), dout.to(DEV), npos, B, C_, dW, dbu, dba)
+    close(dx, x.grad, rtol=2e-3, what="dx")
+    close(dW.cpu(), W.grad[0], rtol=2e-3, what="dW")
+    close(dbu.cpu(), bu.grad, rtol=2e-3, what="dbeta_u")
+    close(dba.cpu(), ba.grad, rtol=2e-3, what="dbeta_a")
+
+
+def test_em_routing_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    pc = torch.from_numpy(G["capF_pc"]); b, h, w, _ = pc.shape
+    out = ops.em_fwd(pc.reshape(-1, 32 * 17).to(DEV), torch.from_numpy(G["capF_W"])[0].contiguous().to(DEV),
+                     torch.from_numpy(G["capF_beta_u"]).to(DEV), torch.from_numpy(G["capF_beta_a"]).to(DEV), b * h * w, 32, 24)
+    close(out.reshape(b, h, w, -1), torch.from_numpy(G["capF_out"]), atol=5e-5, what="conv caps vs reference")
+
+
+def test_class_mask_and_tapsum():
+    g = torch.Generator().manual_seed(11)
+    Bn, npos, C_ = 4, 25, 24
+    caps = torch.rand(Bn, npos, C_ * 17, generator=g)
+    cls = torch.tensor([3., 7., 0., 23.]); lab = torch.tensor([1, 0, 1, 0], dtype=torch.int32)
+    for mode in (0, 1, 2):
+        pred, mask, masked = ops.class_mask_fwd(caps.to(DEV), Bn, npos, C_, cls.to(DEV), lab.to(DEV), mode)
+        ap = caps[..., C_ * 16:].mean(1)
+        m = ocaps.class_mask(ap, cls.view(-1, 1), lab, 1 if mode == 0 else 99, 11, mode != 2)
+        close(pred, ap, atol=1e-6, what="actor_prediction")
+        assert torch.equal(mask.cpu(), m)
+        ref = (caps[..., :C_ * 16].view(Bn, npos, C_, 16) * m.view(Bn, 1, C_, 1)).reshape(Bn, npos, -1)
+        close(masked, ref, atol=0, what="masked poses")
+        dm = torch.randn(Bn, npos, C_ * 16, generator=g); dp = torch.randn(Bn, C_, generator=g)
+        dc = ops.class_mask_bwd(dm.to(DEV), dp.to(DEV), mask, Bn, npos, C_).cpu()
+        close(dc[..., :C_ * 16], (dm.view(Bn, npos, C_, 16) * m.view(Bn, 1, C_, 1)).reshape(Bn, npos, -1), atol=0)
+        close(dc[..., C_ * 16:], (dp / npos).view(Bn, 1, C_).expand(Bn, npos, C_), atol=1e-7)
+    # smooth = 27-tap projection (conv kernel, Co=27->32) + tap sum
+    N, T, H, W = 2, 4, 9, 10
+    x = torch.randn(N, 128, T, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(128, 1, 3, 3, 3, generator=g) * 0.05).requires_grad_(True); b = torch.randn(1, generator=g)
+    y = F.conv_transpose3d(x, w, b, padding=1)
+    dy = torch.randn(y.shape, generator=g); y.backward(dy)
+    wproj = torch.zeros(32, 1, 128); wproj[:27, 0] = w.detach().reshape(128, 27).t()
+    proj = torch.empty(N, T, H, W, 32, device=DEV)
+    ops.conv_fwd(desc.conv_fwd(N, (T, H, W), 128, 128, 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), (T, H, W)), cl(x), wproj.to(DEV), proj)
+    out = ops.tapsum_fwd(proj, b.to(DEV))
+    close(out.cpu(), y[:, 0], what="smooth fwd")
+    dproj = ops.tapsum_bwd(dy[:, 0].contiguous().to(DEV))
+    dxg = torch.empty(N, T, H, W, 128, device=DEV)
+    wT = torch.zeros(128, 1, 32); wT[:, 0, :27] = w.detach().reshape(128, 27)
+    ops.conv_fwd(desc.conv_fwd(N, (T, H, W), 32, 32, 128, 128, (1, 1, 1), (1, 1, 1), (0, 0, 0), (T, H, W)), dproj, wT.to(DEV), dxg)
+    close(uncl(dxg), x.grad, what="smooth dgrad")
+
+
+LOSS_CASES = [
+    dict(bv=True, n_frames=5, wt_ramp=0.3, wt_cons=0.1),
+    dict(bv=True, n_frames=3, predict_maps=True, wt_ramp=0.0074),
+    dict(gv=True, wt_cons=0.5),
+    dict(gv=True, lower=0.2, upper=0.85),
+    dict(bv=True, gv=True, n_frames=5, wt_ramp=0.6, bv_wt=0.3, gv_wt=0.7),
+    dict(),
+    dict(bv=True, gv=True, jhmdb=True, n_frames=3, wt_ramp=0.5),
+]
+
+
+@pytest.mark.parametrize("kw", LOSS_CASES)
+@pytest.mark.parametrize("hw", [24, 224])
+def test_consistency_loss(kw, hw):
+    from oracle.step import default_args
+    g = torch.Generator().manual_seed(12)
+    B = 4
+    O = (torch.randn(B, 1, 8, hw, hw, generator=g) * 2).requires_grad_(True)
+    Fl = (O.detach().flip(4) * 0.8 + torch.randn(B, 1, 8, hw, hw, generator=g)).requires_grad_(True)
+    seg = (torch.rand(B, 1, 8, hw, hw, generator=g) < 0.3).float()
+    lab = torch.tensor([1, 0, 1, 0], dtype=torch.int32)
+    a = default_args(bv=kw.get("bv", False), gv=kw.get("gv", False), n_frames=kw.get("n_frames", 3),
+                     predict_maps=kw.get("predict_maps", False), lower_thresh=kw.get("lower"), upper_thresh=kw.get("upper"),
+                     bv_wt=kw.get("bv_wt", 0.5), gv_wt=kw.get("gv_wt", 0.5))
+    ramp = kw.get("wt_ramp", 0.0); wt_cons = kw.get("wt_cons", 1.0); wt_loc = 0.7
+    idx = torch.where(lab == 1)[0]
+    loc = olosses.bce_logits(O[idx], seg[idx]) + olosses.dice_loss(O[idx], seg[idx])
+    fp = torch.flip(Fl, [4])
+    l2 = olosses.weighted_mse(fp, O, torch.ones_like(O))
+    c1 = c2 = None
+    if a.bv:
+        vc = olosses.var_mask(O, torch.flip(fp, [2]), a.n_frames, a.predict_maps).float()
+        va = olosses.var_mask(torch.flip(O, [2]), fp, a.n_frames, a.predict_maps).float()
+        c1 = ramp * (olosses.weighted_mse(fp, O, vc) + olosses.weighted_mse(fp, O, torch.flip(va, [2]))) + (1 - ramp) * l2
+    if a.gv:
+        c2 = olosses.weighted_mse(fp, O, olosses.grad_mask(O, a.lower_thresh, a.upper_thresh).float())
+    if kw.get("jhmdb"):
+        cons = c2 if a.gv else (c1 if a.bv else l2)
+    elif a.bv and a.gv:
+        cons = a.bv_wt * c1 + a.gv_wt * c2
+    else:
+        cons = c2 if a.gv else (c1 if a.bv else l2)
+    (wt_loc * loc + wt_cons * cons).backward()
+    d = ops.loss_desc(B, 8, hw, hw, bv=a.bv, gv=a.gv, n_frames=a.n_frames, predict_maps=a.predict_maps, jhmdb=kw.get("jhmdb", False),
+                      lower=a.lower_thresh, upper=a.upper_thresh, bv_wt=a.bv_wt, gv_wt=a.gv_wt, wt_loc=wt_loc, wt_cons=wt_cons, wt_ramp=ramp)
+    scal, dO, dF, mb, mg = ops.consistency_loss(d, O.detach().to(DEV), Fl.detach().to(DEV), seg.to(DEV), lab.to(DEV), want_masks=True)
+    scal = scal.cpu()
+    assert abs(scal[0].item() - loc.item()) <= 1e-4, ("loc", scal[0].item(), loc.item())        # north_star: loss scalars 1e-4
+    assert abs(scal[1].item() - cons.item()) <= 1e-4 * max(1.0, abs(cons.item())), ("cons", scal[1].item(), cons.item())
+    close(dO, O.grad, rtol=2e-4, what="d_output")
+    close(dF, Fl.grad, rtol=2e-4, what="d_flip_op")
+    if a.bv:
+        close(mb, vc, atol=2e-5, what="bv mask")
+    if a.gv:
+        close(mg[:, 0], olosses.grad_mask(O, a.lower_thresh, a.upper_thresh).float(), atol=2e-5, what="gv mask")
+
+
+def test_masks_standalone_golden(golden_dir):
+    """utils.helpers drop-ins vs the reference's own outputs (tests/golden/masks.npz)."""
+    M = np.load(os.path.join(golden_dir, "masks.npz"))
+    g = np.random.default_rng(23)
+    pred = g.normal(0, 2, (2, 1, 8, 224, 224)).astype(np.float32)
+    flip = (pred[:, :, ::-1] * 0.7 + g.normal(0, 1, pred.shape)).astype(np.float32)
+    P, Fp = torch.from_numpy(pred).to(DEV), torch.from_numpy(flip).to(DEV)
+    for nf in (3, 5):
+        for sig in (False, True):
+            tag = "var%d%s" % (nf, "s" if sig else "")
+            m = ops.var_mask(P, Fp, nf, sig).cpu().numpy()
+            assert np.abs(m[..., ::7, ::7] - M[tag + "_sample"]).max() <= 2e-5, tag
+            assert np.abs(m.astype(np.float64).sum(axis=(-1, -2)) - M[tag + "_sum"]).max() <= 0.05, tag
+    for tag, lo, up in (("grad", None, None), ("grad_thr", 0.2, 0.85)):
+        m = ops.grad_mask(P, lo, up).cpu().numpy()
+        assert np.abs(m[..., ::7, ::7] - M[tag + "_sample"]).max() <= 2e-5, tag
+
+
+def test_spread_loss_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    x = torch.from_numpy(G["spread_x"]).to(DEV); t = torch.from_numpy(G["spread_t"]).to(DEV)
+    lab = torch.ones(x.shape[0], dtype=torch.int32, device=DEV)
+    dx = torch.zeros_like(x)
+    out = ops.spread_loss(x, t.view(-1), lab, 0.2, 1.0, dx).cpu()
+    assert abs(out[0].item() - float(G["spread_loss"])) < 1e-6 and abs(out[1].item() - float(G["spread_abs"])) < 1e-5
+    close(dx, torch.from_numpy(G["spread_dx"]), atol=1e-7, what="spread dx")
+    # unlabeled rows are ignored
+    lab2 = lab.clone(); lab2[1] = 0
+    xr = torch.from_numpy(G["spread_x"]).requires_grad_(True); keep = [0, 2, 3, 4]
+    l, _ = olosses.spread_loss(xr[keep], torch.from_numpy(G["spread_t"])[keep]); l.backward()
+    dx2 = torch.zeros_like(x)
+    out2 = ops.spread_loss(x, t.view(-1), lab2, 0.2, 2.0, dx2).cpu()
+    assert abs(out2[0].item() - l.item()) < 1e-6
+    close(dx2, 2.0 * xr.grad, atol=1e-7)
+
+
+def test_errors_are_loud():
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd(desc.conv_fwd(1, (1, 4, 4), 3, 3, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 4)),
+                     torch.zeros(1, 1, 4, 4, 3, device=DEV), torch.zeros(8, 1, 3, device=DEV), torch.zeros(1, 1, 4, 4, 8, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.conv_fwd(desc.conv_fwd(1, (1, 4, 4), 4, 4, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 4)),
+                     torch.zeros(1, 1, 4, 4, 4), torch.zeros(8, 1, 4), torch.zeros(1, 1, 4, 4, 8))   # CPU tensors
