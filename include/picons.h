@@ -63,6 +63,7 @@ typedef struct pc_conv_desc {
     int32_t wk0[3], wkstep[3];
     int32_t KT, KH, KW, ldw;
     int32_t act, flags;
+    int32_t act_c0;                 /* activation applies to output channels >= act_c0 (merged pose|activation conv) */
     int32_t groups;                 /* >=1: rows are tiled per batch group (N/groups samples each) so BatchNorm
                                        partials never straddle the two forward passes of one step */
 } pc_conv_desc;

@@ -15,7 +15,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho", "Wo", "Co", "ldo")] + \
                [(n, i32 * 3) for n in ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")] + \
-               [(n, i32) for n in ("KT", "KH", "KW", "ldw", "act", "flags", "groups")]
+               [(n, i32) for n in ("KT", "KH", "KW", "ldw", "act", "flags", "act_c0", "groups")]
 
 
 class WgradDesc(C.Structure):
@@ -96,7 +96,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        assert C.sizeof(ConvDesc) == 45 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
+        assert C.sizeof(ConvDesc) == 46 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
         _lib = L
     return _lib
 

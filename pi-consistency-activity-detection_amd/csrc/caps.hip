@@ -108,7 +108,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rn[i][c] * irs[j] * d * d; }
             }
         }
-        float cost[CJ], csum = 0.f;
+        float cost[CJ]; double csum = 0.0;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int c = cg + 4 * j;
@@ -118,15 +118,21 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 st->mu[t][c][h] = m[j];
                 st->s2[t][c][h] = sg[j];
                 cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[t][c]);
-                csum += cost[j];
+                csum += (double)cost[j];
             }
         }
-        const float mean = sum_cg(csum) / C;
-        float dsum = 0.f;
+        // mean and the reference's sum-then-square "stdv" (:142-144).  S = sum_c(cost - mean) is zero in exact
+        // arithmetic; in the reference's fp32 it is rounding noise that moves D by a few percent (SURVEY finding 4).
+        // Evaluate it in double so this path sits at the noise-free value instead of adding noise of its own.
+        double cs_d = csum;
+        cs_d += __shfl_xor(cs_d, 16, 64); cs_d += __shfl_xor(cs_d, 32, 64);
+        const double mean_d = cs_d / C;
+        const float mean = (float)mean_d;
+        double ds_d = 0.0;
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) if (cg + 4 * j < C) dsum += cost[j] - mean;
-        dsum = sum_cg(dsum);
-        const float D = sqrtf(dsum * dsum / C + EPS) + EPS;   // sum-then-square, :144
+        for (int j = 0; j < CJ; ++j) if (cg + 4 * j < C) ds_d += (double)cost[j] - mean_d;
+        ds_d += __shfl_xor(ds_d, 16, 64); ds_d += __shfl_xor(ds_d, 32, 64);
+        const float D = sqrtf((float)(ds_d * ds_d / C) + EPS) + EPS;   // sum-then-square, :144
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int c = cg + 4 * j;

@@ -14,7 +14,7 @@ struct ConvK {
     int ostr[3], ooff[3], istr[3], ntap[3], ioff0[3], istep[3], wk0[3], wkstep[3];
     int KH, KW, wtaps, ldw;
     int K, M, Mg, groups, mtiles_g, ntiles;
-    int act, flags;
+    int act, flags, act_c0;
 };
 
 constexpr int BK = 32;       // K chunk (floats)
@@ -172,8 +172,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
                 if (col >= p.Co) continue;
                 float v = acc[i][j][r];
                 if (has_bias) v += p.bias[col];
-                if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
-                else if (p.act == PC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                if (col >= p.act_c0) {
+                    if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == PC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                }
                 if (has_cs) v *= p.cscale[(size_t)nb * p.Co + col];
                 float* o = p.out + (size_t)op * p.ldo + col;
                 if (accum) v += *o;
@@ -252,7 +254,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     const int64_t M = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
-    k.act = d->act; k.flags = d->flags;
+    k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0;
     const TileCfg c = choose_tile(k.Mg, groups, d->Co);
     if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128, 2, 2>(k, s);
     if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64, 2, 2>(k, s);

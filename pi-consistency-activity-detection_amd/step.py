@@ -1,0 +1,200 @@
+"""The fused semi-supervised train step on one MI355X: owns the device arena and the flat
+parameter / gradient / Adam buffers, stages a minibatch pair, and replays the op lists of plan.py
+through libpicons.so.  Mirrors /root/reference/main_ucf101.py train_model_interface :50-150 plus the
+zero_grad/backward/Adam loop :171-190, with both forward passes batched and every mask/loss on device.
+
+PyTorch is used for device memory, streams and (in dist.py) the RCCL collective only.
+"""
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import capi, ops, spec, synthetic
+from .plan import Plan
+
+
+def default_args(**kw):
+    """CLI defaults of main_ucf101.py:285-315 that reach the step."""
+    a = dict(bv=False, gv=False, n_frames=3, predict_maps=False, lower_thresh=None, upper_thresh=None,
+             bv_wt=0.5, gv_wt=0.5, wt_loc=1.0, wt_cls=1.0, wt_cons=1.0, thresh_epoch=11, lr=1e-3, epochs=1)
+    a.update(kw)
+    return SimpleNamespace(**a)
+
+
+def exp_rampup(rampup_length):
+    """utils/ramp_ups.py:15-24 (host scalar)."""
+    def f(epoch):
+        if epoch < rampup_length:
+            e = float(np.clip(epoch, 0.0, rampup_length))
+            ph = 1.0 - e / rampup_length
+            return float(np.exp(-5.0 * ph * ph))
+        return 1.0
+    return f
+
+
+class StepEngine:
+    def __init__(self, args, bs=8, hw=224, num_classes=24, device="cuda:0", jhmdb=False, state=None, seed=47):
+        if not torch.cuda.is_available():
+            raise RuntimeError("StepEngine needs a GPU: the hot path is HIP-only (no CPU fallback)")
+        capi.lib()
+        self.args = args
+        self.dev = torch.device(device)
+        torch.cuda.set_device(self.dev)
+        self.bs = bs
+        self.C = num_classes
+        self.hw = hw
+        self.jhmdb = jhmdb
+        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb)
+        p.build_forward()
+        p.build_loss(args)
+        p.build_backward()
+        p.build_adam()
+        self.plan = p
+        f32 = dict(device=self.dev, dtype=torch.float32)
+        self.arena = torch.empty(p.arena_bytes + 256, device=self.dev, dtype=torch.uint8)
+        self.P = torch.zeros(p.nparams, **f32)
+        self.G = torch.zeros(p.nparams, **f32)
+        self.M = torch.zeros(p.nparams, **f32)
+        self.V = torch.zeros(p.nparams, **f32)
+        self.R = torch.zeros(p.nrunning, **f32)
+        base_a = (self.arena.data_ptr() + 255) // 256 * 256
+        self._a0 = base_a - self.arena.data_ptr()
+        self.bases = dict(A=base_a, P=self.P.data_ptr(), G=self.G.data_ptr(), M=self.M.data_ptr(), V=self.V.data_ptr(), R=self.R.data_ptr())
+        self.ops = p.resolve(self.bases)
+        self.step_count = 0
+        self.load_state(state if state is not None else synthetic.init_state(seed, num_classes))
+
+    # ------------------------------------------------------------------ views
+    def aview(self, ref, nfloats, dtype=torch.float32):
+        o = self._a0 + ref[1]
+        return self.arena[o:o + 4 * nfloats].view(dtype)
+
+    def param(self, name):
+        shp = self.plan.pshape[name]
+        o = self.plan.poff[name]
+        return self.P[o:o + int(np.prod(shp))].view(shp)
+
+    def grad(self, name):
+        shp = self.plan.pshape[name]
+        o = self.plan.poff[name]
+        return self.G[o:o + int(np.prod(shp))].view(shp)
+
+    def load_state(self, state):
+        """state: reference-layout state_dict (numpy or torch values, SURVEY §5 key names)."""
+        for k in self.plan.pshape:
+            self.param(k).copy_(torch.as_tensor(np.asarray(state[k])).to(self.dev))
+        for k, o in self.plan.roff.items():
+            v = torch.as_tensor(np.asarray(state[k])).to(self.dev)
+            self.R[o:o + v.numel()].copy_(v)
+        self.nbt = {k: int(np.asarray(v)) for k, v in state.items() if k.endswith("num_batches_tracked")}
+
+    def state_dict(self):
+        sd = {}
+        for k in spec.state_dict_keys(self.C):
+            if k in self.plan.pshape:
+                sd[k] = self.param(k).detach().clone()
+            elif k in self.plan.roff:
+                o = self.plan.roff[k]
+                n = self.plan.pshape[k.rsplit(".bn.", 1)[0] + ".bn.weight"][0]
+                sd[k] = self.R[o:o + n].detach().clone()
+            else:
+                sd[k] = torch.tensor(self.nbt.get(k, 0), dtype=torch.long)
+        return sd
+
+    # ------------------------------------------------------------------ staging
+    def stage(self, label_mb, unlabel_mb, perm, drops):
+        """Concat labeled+unlabeled, apply the shuffle (main_ucf101.py:65-79) and copy to the arena.
+        drops: four (bs,C) scale arrays [d832 pass0, d128 pass0, d832 pass1, d128 pass1]."""
+        p = self.plan
+        T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a)
+        cat = lambda k: torch.cat([T(label_mb[k]), T(unlabel_mb[k])], dim=0)
+        perm = torch.as_tensor(np.asarray(perm)).long()
+        n = self.bs
+        per = 3 * spec.FRAMES * self.hw * self.hw
+        data = cat("data")[perm].to(self.dev, torch.float32, non_blocking=True)
+        aug = cat("aug_data")[perm].to(self.dev, torch.float32, non_blocking=True)
+        seg = cat("loc_msk")[perm].to(self.dev, torch.float32, non_blocking=True)
+        act = cat("action")[perm].reshape(-1).to(self.dev, torch.float32)
+        if self.jhmdb:        # main_jhmdb.py:68-70
+            lab = torch.cat([torch.ones(len(label_mb["action"])), torch.zeros(len(unlabel_mb["action"]))])
+        else:
+            lab = cat("label_vid")
+        lab = lab[perm].to(self.dev, torch.int32)
+        self.aview(p.in_data, n * per).copy_(data.reshape(-1))
+        self.aview(p.in_aug, n * per).copy_(aug.reshape(-1))
+        self.aview(p.in_seg, n * per // 3).copy_(seg.reshape(-1))
+        self.aview(p.in_cls, 2 * n).copy_(torch.cat([act, act]))
+        self.aview(p.in_labeled, 2 * n, torch.int32).copy_(torch.cat([lab, lab]))
+        d = [torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.dev) for x in drops]
+        self.aview(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH).copy_(torch.cat([d[0], d[2]]).reshape(-1))
+        self.aview(p.in_drop128, 2 * n * 128).copy_(torch.cat([d[1], d[3]]).reshape(-1))
+        self.labels_host = lab.cpu()
+        self.action_host = act.cpu()
+
+    # ------------------------------------------------------------------ execution
+    def forward_backward(self, epoch, wt_ramp):
+        p, o = self.plan, self.ops
+        o["fwd"][p.op_cmask]["i"][3] = 0 if epoch < self.args.thresh_epoch else 1
+        o["loss"][p.op_loss]["f"][6] = wt_ramp
+        ops.run_ops(o["prep"])
+        ops.run_ops(o["fwd"])
+        ops.run_ops(o["loss"])
+        ops.run_ops(o["bwd"])
+        ops.run_ops(o["unprep"])
+
+    def adam(self, lr, gscale=1.0):
+        self.step_count += 1
+        a = self.ops["adam"][0]
+        a["i"][0] = self.step_count
+        a["f"][0] = lr
+        a["f"][4] = gscale
+        ops.run_ops(self.ops["adam"])
+        for k in self.nbt:
+            self.nbt[k] += 2           # two forward passes per step
+
+    def read_scalars(self):
+        """One packed D2H for the step's loss scalars (replaces the reference's five .item() syncs)."""
+        s = self.aview(self.plan.scalars, 16).cpu()
+        sp = self.aview(self.plan.spread_out, 2).cpu()
+        loc, cons, cls = float(s[0]), float(s[1]), float(sp[0])
+        a = self.args
+        return dict(total=a.wt_loc * loc + a.wt_cls * cls + a.wt_cons * cons, loc=loc, cls=cls, cons=cons,
+                    bce=float(s[2]), dice=float(s[3]), l2=float(s[4]), lvar=float(s[5]), lgrad=float(s[6]))
+
+    def outputs(self):
+        """(output (bs,1,8,H,W), flip_op, predicted_action (bs,C)) of the last forward, shuffled order."""
+        p = self.plan
+        per = spec.FRAMES * self.hw * self.hw
+        out = self.aview(p.out.ref, 2 * self.bs * per).view(2 * self.bs, 1, spec.FRAMES, self.hw, self.hw)
+        pred = self.aview(p.pred, 2 * self.bs * self.C).view(2 * self.bs, self.C)
+        return out[:self.bs], out[self.bs:], pred[:self.bs]
+
+    def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, allreduce=None, gscale=1.0):
+        self.stage(label_mb, unlabel_mb, perm, drops)
+        self.forward_backward(epoch, wt_ramp)
+        if allreduce is not None:
+            allreduce(self.G)
+        self.adam(self.args.lr if lr is None else lr, gscale)
+        return self.read_scalars()
+
+
+def smoke_check(device="cuda:0", hw=224):
+    """One bs=2 train step on the GPU checked against the CPU oracle (used by __graft_entry__.smoke)."""
+    from oracle import step as ostep
+    args = default_args(bv=True, n_frames=5, wt_cons=0.1, lr=1e-4, epochs=100)
+    eng = StepEngine(args, bs=2, hw=hw, device=device)
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=0, hw=hw)
+    ramp = exp_rampup(100)(1)
+    got = eng.train_step(lab, unl, 1, ramp, perm, drops)
+    out, _flip, pred = eng.outputs()
+    P = ostep.as_torch_params(synthetic.init_state(47, 24))
+    oa = ostep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    ref = ostep.train_step(P, oa, lab, unl, 1, ramp, perm, drops)
+    dl = max(abs(got[k] - float(ref[k])) for k in ("total", "loc", "cls", "cons"))
+    dp = (pred.cpu() - ref["predicted_action"]).abs().max().item()
+    dm = (out.cpu() - ref["output"]).abs().max().item()
+    print("smoke: |dloss| %.2e  |dlogits| %.2e  |dmask| %.2e  total %.6f" % (dl, dp, dm, got["total"]))
+    assert dl <= 1e-4 and dp <= 1e-3 and dm <= 1e-3, "HIP step disagrees with the CPU oracle"
+    return got

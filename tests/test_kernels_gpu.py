@@ -228,36 +228,62 @@ def test_elementwise_helpers():
     assert torch.allclose(p.cpu(), pr.detach(), atol=1e-6)
 
 
-@pytest.mark.parametrize("C_,npos", [(24, 37), (21, 20)])
-def test_em_routing_fwd_bwd(C_, npos):
-    g = torch.Generator().manual_seed(10)
-    B = 32
-    x = torch.cat([torch.randn(npos, B * 16, generator=g), torch.rand(npos, B, generator=g)], 1).requires_grad_(True)
-    W = (torch.randn(1, B, C_, 4, 4, generator=g) * 0.5).requires_grad_(True)
-    bu = torch.randn(C_, 16, generator=g).requires_grad_(True); ba = torch.randn(C_, generator=g).requires_grad_(True)
+def _em_oracle(x, W, bu, ba, dout, npos, B, C_, dtype):
+    x = x.detach().to(dtype).requires_grad_(True); W = W.detach().to(dtype).requires_grad_(True)
+    bu = bu.detach().to(dtype).requires_grad_(True); ba = ba.detach().to(dtype).requires_grad_(True)
     v = ocaps.votes(x[:, :B * 16].reshape(npos, B, 16), W)
     mu, a_out = ocaps.em_routing(v, x[:, B * 16:].reshape(npos, B, 1), bu, ba)
     out = torch.cat([mu.reshape(npos, C_ * 16), a_out.reshape(npos, C_)], 1)
-    dout = torch.randn(out.shape, generator=g)
-    out.backward(dout)
-    xg = x.detach().to(DEV)
-    og = ops.em_fwd(xg, W.detach().to(DEV), bu.detach().to(DEV), ba.detach().to(DEV), npos, B, C_)
-    close(og[:, :C_ * 16], out[:, :C_ * 16], rtol=1e-4, what="mu")
-    close(og[:, C_ * 16:], out[:, C_ * 16:], atol=2e-6, what="a_out")
+    out.backward(dout.to(dtype))
+    return [t.detach().double() for t in (out[:, :C_ * 16], out[:, C_ * 16:], x.grad, W.grad[0], bu.grad, ba.grad)]
+
+
+@pytest.mark.parametrize("C_,npos,pscale", [(24, 37, 1.0), (21, 20, 1.0), (24, 64, 0.3)])
+def test_em_routing_fwd_bwd(C_, npos, pscale):
+    """EM routing is ill-conditioned in fp32 (SURVEY finding 4): judge the HIP kernel against an
+    fp64 run of the oracle, allowing a small multiple of the fp32 oracle's own distance to it."""
+    g = torch.Generator().manual_seed(10)
+    B = 32
+    x = torch.cat([torch.randn(npos, B * 16, generator=g) * pscale, torch.rand(npos, B, generator=g)], 1)
+    W = torch.randn(1, B, C_, 4, 4, generator=g) * 0.5
+    bu = torch.randn(C_, 16, generator=g); ba = torch.randn(C_, generator=g)
+    dout = torch.randn(npos, C_ * 17, generator=g)
+    ref64 = _em_oracle(x, W, bu, ba, dout, npos, B, C_, torch.float64)
+    ref32 = _em_oracle(x, W, bu, ba, dout, npos, B, C_, torch.float32)
+    xg = x.to(DEV); Wg = W[0].contiguous().to(DEV)
+    og = ops.em_fwd(xg, Wg, bu.to(DEV), ba.to(DEV), npos, B, C_)
     dW = torch.zeros(B, C_, 4, 4, device=DEV); dbu = torch.zeros(C_, 16, device=DEV); dba = torch.zeros(C_, device=DEV)
-    dx = ops.em_bwd(xg, W.detach().to(DEV), bu.detach().to(DEV), ba.detach().to(DEV), dout.to(DEV), npos, B, C_, dW, dbu, dba)
-    close(dx, x.grad, rtol=2e-3, what="dx")
-    close(dW.cpu(), W.grad[0], rtol=2e-3, what="dW")
-    close(dbu.cpu(), bu.grad, rtol=2e-3, what="dbeta_u")
-    close(dba.cpu(), ba.grad, rtol=2e-3, what="dbeta_a")
+    dx = ops.em_bwd(xg, Wg, bu.to(DEV), ba.to(DEV), dout.to(DEV), npos, B, C_, dW, dbu, dba)
+    got = [og[:, :C_ * 16], og[:, C_ * 16:], dx, dW, dbu, dba]
+    names = ["mu", "a_out", "dx", "dW", "dbeta_u", "dbeta_a"]
+    report = []
+    for n, gt, r32, r64 in zip(names, got, ref32, ref64):
+        scale = r64.abs().max().item() + 1e-30
+        e_gpu = (gt.detach().cpu().double() - r64).abs().max().item() / scale
+        e_cpu = (r32 - r64).abs().max().item() / scale
+        report.append((n, e_gpu, e_cpu))
+    bad = [(n, eg, ec) for n, eg, ec in report if eg > max(5 * ec, 2e-5)]
+    assert not bad, "rel err (gpu vs fp64, cpu-fp32 vs fp64): %s" % report
 
 
 def test_em_routing_golden(golden_dir):
+    """Reference ConvCaps output (fp32) on a full-size capsule layer.  The reference's a_out carries a few
+    1e-3 of its own rounding noise through the sum-then-square stdv (SURVEY finding 4), so the HIP result is
+    anchored on an fp64 run of the oracle: it must be no further from it than the reference itself is."""
     G = np.load(os.path.join(golden_dir, "stages.npz"))
     pc = torch.from_numpy(G["capF_pc"]); b, h, w, _ = pc.shape
     out = ops.em_fwd(pc.reshape(-1, 32 * 17).to(DEV), torch.from_numpy(G["capF_W"])[0].contiguous().to(DEV),
                      torch.from_numpy(G["capF_beta_u"]).to(DEV), torch.from_numpy(G["capF_beta_a"]).to(DEV), b * h * w, 32, 24)
-    close(out.reshape(b, h, w, -1), torch.from_numpy(G["capF_out"]), atol=5e-5, what="conv caps vs reference")
+    out = out.reshape(b, h, w, -1).cpu().double()
+    ref = torch.from_numpy(G["capF_out"]).double()
+    x64 = pc.double().reshape(-1, 32 * 17)
+    v = ocaps.votes(x64[:, :512].reshape(-1, 32, 16), torch.from_numpy(G["capF_W"]).double())
+    mu, a = ocaps.em_routing(v, x64[:, 512:].reshape(-1, 32, 1), torch.from_numpy(G["capF_beta_u"]).double(), torch.from_numpy(G["capF_beta_a"]).double())
+    o64 = torch.cat([mu.reshape(-1, 24 * 16), a.reshape(-1, 24)], 1).reshape(b, h, w, -1)
+    e_ref = (ref - o64).abs().max().item(); e_gpu = (out - o64).abs().max().item()
+    assert e_gpu <= max(1.5 * e_ref, 5e-5), (e_gpu, e_ref)
+    assert (out - ref).abs().max().item() <= 2.5 * max(e_ref, 5e-5)         # and within the reference's own noise band of it
+    close(out[..., :384], ref[..., :384], rtol=2e-4, what="poses vs reference")
 
 
 def test_class_mask_and_tapsum():

@@ -1,0 +1,110 @@
+"""GPU parity of the whole fused train step (plan replayed through libpicons.so):
+ - against the CPU oracle on identical synthetic clips / weights / shuffle / dropout draws at a
+   reduced frame size the oracle finishes in seconds, every parameter gradient included;
+ - against THE REFERENCE'S OWN outputs (tests/golden/step_*.npz) at the full 8x224x224 size.
+Bars (BASELINE.json north_star): logits and localisation masks 1e-3, loss scalars 1e-4 (fp32)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import step as ostep
+from picons_amd import spec, step as pstep, synthetic
+
+pytestmark = pytest.mark.gpu
+
+
+def run_pair(akw, hw, bs, epoch, ncls=24, jhmdb=False, stepid=0, lr=1e-4):
+    args = pstep.default_args(lr=lr, **akw)
+    eng = pstep.StepEngine(args, bs=bs, hw=hw, num_classes=ncls, jhmdb=jhmdb)
+    lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid, num_classes=ncls, hw=hw)
+    ramp = pstep.exp_rampup(100)(epoch)
+    eng.stage(lab, unl, perm, drops)
+    eng.forward_backward(epoch, ramp)
+    torch.cuda.synchronize()
+    P = ostep.as_torch_params(synthetic.init_state(47, ncls))
+    oa = ostep.default_args(dataset="jhmdb" if jhmdb else "ucf101", **akw)
+    ref = ostep.train_step(P, oa, lab, unl, epoch, ramp, perm, drops)
+    ref["total"].backward()
+    return eng, ref, P
+
+
+CASES = [
+    ("bv5", dict(bv=True, n_frames=5, wt_cons=0.1), 1, 24, False),
+    ("gv_pseudo", dict(gv=True, lower_thresh=0.2, upper_thresh=0.9, wt_cons=0.1), 12, 24, False),
+    ("bvgv3_sig", dict(bv=True, gv=True, n_frames=3, predict_maps=True), 3, 24, False),
+    ("jhmdb_bv", dict(bv=True, n_frames=5, wt_cons=0.1), 1, 21, True),
+    ("l2_only", dict(), 1, 24, False),
+]
+
+
+@pytest.mark.parametrize("tag,akw,epoch,ncls,jhmdb", CASES)
+def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
+    hw, bs = 112, 2
+    eng, ref, P = run_pair(akw, hw, bs, epoch, ncls, jhmdb)
+    got = eng.read_scalars()
+    out, flip, pred = eng.outputs()
+    for k in ("total", "loc", "cls", "cons"):
+        assert abs(got[k] - float(ref[k])) <= 1e-4, (k, got[k], float(ref[k]))
+    assert (pred.cpu() - ref["predicted_action"]).abs().max().item() <= 1e-3
+    assert (out.cpu() - ref["output"]).abs().max().item() <= 1e-3
+    assert (flip.cpu() - ref["flip_op"]).abs().max().item() <= 1e-3
+    # every parameter gradient, relative L2 per tensor
+    bad = []
+    for name in eng.plan.pshape:
+        g = eng.grad(name).cpu().double(); r = P[name].grad.double()
+        den = r.norm().item()
+        rel = (g - r).norm().item() / (den + 1e-12)
+        if rel > 2e-2 and (g - r).abs().max().item() > 1e-7:
+            bad.append((name, rel, den))
+    assert not bad, bad[:10]
+    # BN running statistics after the two passes
+    for pre, _ci, co, _k, _s in spec.trunk_units()[:6] + spec.trunk_units()[-3:]:
+        for nm in ("running_mean", "running_var"):
+            key = pre + ".bn." + nm
+            o = eng.plan.roff[key]
+            assert (eng.R[o:o + co].cpu() - P[key]).abs().max().item() <= 1e-5, key
+    # Adam update
+    before = {k: eng.param(k).clone() for k in ("conv_caps.beta_u", "smooth.weight", "conv1.Mixed_4f.b0.bn.weight")}
+    eng.adam(1e-4)
+    m, v = {}, {}
+    ostep.adam_step(P, m, v, 1, 1e-4)
+    for k in before:
+        assert (eng.param(k).cpu() - P[k].detach()).abs().max().item() <= 2e-6, k
+
+
+@pytest.mark.parametrize("tag", ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv"])
+def test_step_vs_reference_golden_full_size(golden_dir, tag):
+    S = np.load(os.path.join(golden_dir, tag + ".npz"))
+    ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
+    akw = dict(eval(str(S["args"])))
+    jh = akw.pop("dataset", "ucf101") == "jhmdb"
+    for k in ("wt_seg",):
+        akw.pop(k, None)
+    args = pstep.default_args(**akw)
+    eng = pstep.StepEngine(args, bs=2, hw=224, num_classes=ncls, jhmdb=jh)
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=stepid, num_classes=ncls)
+    eng.stage(lab, unl, perm, drops)
+    eng.forward_backward(epoch, float(S["ramp"]))
+    got = eng.read_scalars()
+    out, _flip, pred = eng.outputs()
+    for k in ("total", "loc", "cls", "cons"):
+        assert abs(got[k] - float(S[k])) <= 1e-4, (k, got[k], float(S[k]))
+    assert np.abs(pred.cpu().numpy() - S["predicted_action"]).max() <= 1e-3
+    assert np.abs(out[:, :, :, ::8, ::8].cpu().numpy() - S["output_sample"]).max() <= 1e-3
+    assert np.abs(out.sum(dim=(-1, -2)).cpu().numpy() - S["output_frame_sum"]).max() <= 1e-3 * 224 * 224
+    gn = dict(zip([str(x) for x in S["grad_names"]], S["grad_norms"]))
+    bad = [(n, float(eng.grad(n).norm()), r) for n, r in gn.items() if abs(float(eng.grad(n).norm()) - r) > 2e-2 * max(r, 1e-6) + 1e-7]
+    assert not bad, bad[:10]
+    for k in S.files:
+        if k.startswith("grad::"):
+            ref = S[k]
+            assert np.abs(eng.grad(k[6:]).cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-8, k
+        if k.startswith("buf::") and not k.endswith("num_batches_tracked"):
+            o = eng.plan.roff[k[5:]]
+            assert np.abs(eng.R[o:o + S[k].size].cpu().numpy() - S[k]).max() <= 1e-5, k
+
+
+def test_smoke_entry():
+    pstep.smoke_check(hw=112)
