@@ -1,0 +1,90 @@
+"""Data parallelism for the train step: one process per GPU, per-rank minibatches / BN statistics /
+dropout draws (the reference has no multi-GPU semantics; SURVEY §8e defines DP(world x bs) as the
+mean of `world` independent reference steps), gradients summed with bucketed RCCL all-reduce
+(torch.distributed backend "nccl" == RCCL over xGMI) on a side stream while the rest of the
+backward still runs, 1/world folded into the fused Adam (pc_adam_step gscale).
+
+The bucket schedule comes from Plan.grad_buckets(): contiguous ranges of the flat gradient buffer
+in the order backward finalises them.  The same class runs on CPU tensors with the gloo backend,
+which is how the N>1 path is tested without GPUs (tests/test_dist_cpu.py).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from torchrun-style env (RANK / WORLD_SIZE / MASTER_*).  Returns
+    (rank, world, local_rank).  No-op for world size 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+class GradReducer:
+    """Sums ranges of one flat gradient tensor across ranks, bucket by bucket.
+
+    launch(i) is called by the step engine right after the backward op that finalises bucket i was
+    enqueued; on GPU the collective is issued on a dedicated stream behind an event, so it overlaps
+    with the remaining backward kernels.  wait() joins before Adam."""
+
+    def __init__(self, flat_grad, buckets, group=None):
+        self.g = flat_grad
+        self.buckets = list(buckets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = flat_grad.is_cuda
+        self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        self.handles = []
+
+    def launch(self, i):
+        if self.world == 1:
+            return
+        _ready, a, b = self.buckets[i]
+        view = self.g[a:b]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm_stream):
+                self.comm_stream.wait_event(ev)
+                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for h in self.handles:
+            h.wait()
+        self.handles = []
+        if self.cuda and self.world > 1:
+            torch.cuda.current_stream().wait_stream(self.comm_stream)
+
+    @property
+    def gscale(self):
+        """Factor the optimiser applies to the summed gradient (mean over ranks)."""
+        return 1.0 / self.world
+
+
+def shard_indices(n_items, rank, world):
+    """DistributedSampler-style contiguous shard [rank*n/world, (rank+1)*n/world)."""
+    per = n_items // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+def barrier_max_ms(ms, device=None):
+    """MAX over ranks of a local timing (bench.py contract)."""
+    if not dist.is_initialized():
+        return ms
+    t = torch.tensor([ms], dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

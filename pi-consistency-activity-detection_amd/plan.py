@@ -74,6 +74,7 @@ class Plan:
             self.roff[pre + ".bn.running_var"] = o; o += co
         self.nrunning = o
         self.kg_ranges = []       # (ref, nfloats) of kernel-layout grad buffers to zero each step
+        self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
 
     # ------------------------------------------------------------------ memory
     def alloc(self, nfloats, name=""):
@@ -125,7 +126,7 @@ class Plan:
         Ipad = Ipad or I
         O = sum(O_list)
         key = names[0]
-        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc(O * taps * Ipad))
+        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc(O * taps * Ipad), unprep=[])
         if Ipad != I:
             self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst="prep")
         self.kg_ranges.append((w["kg"], O * taps * Ipad))
@@ -138,9 +139,8 @@ class Plan:
                       p=[src, off(w["fwd"], o0 * taps * Ipad)], lst="prep")
             if need_tr:
                 self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst="prep")
-            # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]
-            self.emit(capi.OP_TRANSPOSE, i=[Oi, taps, I, Ipad, taps, 0], l=[taps * Ipad, I * taps],
-                      p=[off(w["kg"], o0 * taps * Ipad), self.G(nm)], lst="unprep")
+            # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]  (flushed right after the wgrad, see flush_grad)
+            w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, 0], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
             o0 += Oi
         self.kw[key] = w
         return w
@@ -149,14 +149,25 @@ class Plan:
         """Reference IO(T)HW master -> fwd-type layout [O][taps][I] (ConvTranspose forward) and
         [I][taps][O] (its dgrad, a strided conv); grads come back as [I][taps][O]."""
         taps = k[0] * k[1] * k[2]
-        w = dict(O=O, I=I, taps=taps, fwd=self.alloc(O * taps * I), tr=self.alloc(I * taps * O), kg=self.alloc(I * taps * O))
+        w = dict(O=O, I=I, taps=taps, fwd=self.alloc(O * taps * I), tr=self.alloc(I * taps * O), kg=self.alloc(I * taps * O), unprep=[])
         self.kg_ranges.append((w["kg"], I * taps * O))
         src = self.P(name)
         self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst="prep")
         self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst="prep")
-        self.emit(capi.OP_TRANSPOSE, i=[I, taps, O, O, taps, 0], l=[taps * O, O * taps], p=[w["kg"], self.G(name)], lst="unprep")
+        w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, 0], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
         self.kw[name] = w
         return w
+
+    def flush_grad(self, w):
+        """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
+        wgrad so a gradient bucket is final (all-reduce can start) as early as possible."""
+        for nm, op in w["unprep"]:
+            self.lists[self.cur].append(op)
+            self.mark_final(nm)
+
+    def mark_final(self, *names):
+        for nm in names:
+            self.final_at[nm] = len(self.lists["bwd"])
 
     # ------------------------------------------------------------------ layers
     def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None):
@@ -197,12 +208,12 @@ class Plan:
                       p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
+            self.flush_grad(w)
+            self.mark_final(pre + ".bn.weight", pre + ".bn.bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
-                first = True
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
                     self.conv_op(dd, dz.ref, w["tr"], dx.ref)
-                    first = False
         self.tape.append(bwd)
         return y
 
@@ -257,6 +268,8 @@ class Plan:
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
+            self.flush_grad(w)
+            self.mark_final(name + ".bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
@@ -290,6 +303,8 @@ class Plan:
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad), D.WGRAD_FIELDS),
                       p=[x.ref, dz.ref, w["kg"]])
+            self.flush_grad(w)
+            self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
             dd = D.conv_fwd(x.N, othw, cout, dz.ld, Ci, dx.ld, k, stride, pad, x.thw, flags=capi.F_ACCUM if acc else 0, ldw=cout)
             self.conv_op(dd, dz.ref, w["tr"], dx.ref)
@@ -386,6 +401,8 @@ class Plan:
                       p=[dcaps.ref, caps_in.ref, None, self.G("primary_caps.pose.bias"), ws2])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
                       p=[dcaps.ref, xd.ref, wpc["kg"]])
+            self.flush_grad(wpc)
+            self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
             dx, acc = self.grad_for_write(xd)
             for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
                                            flags=capi.F_ACCUM if acc else 0, ldw=caps_in.C):
@@ -414,7 +431,6 @@ class Plan:
         # smooth.weight (128,1,3,3,3) = [ch][27]  -> wproj [27 of 32][128]; wprojT [128][27 of 32]
         self.emit(capi.OP_TRANSPOSE, i=[1, 128, 27, 27, 128, 0], l=[0, 0], p=[self.P("smooth.weight"), wproj], lst="prep")
         self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 32, 0], l=[0, 0], p=[wproj, wprojT], lst="prep")
-        self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, 0], l=[0, 0], p=[kgproj, self.G("smooth.weight")], lst="unprep")
         proj = self.tensor(N, u4.thw, 32, "proj")
         self.conv_op(D.conv_fwd(N, u4.thw, 128, u4.ld, 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), u4.thw), u4.ref, wproj, proj.ref)
         out = self.tensor(N, u4.thw, 1, "out")
@@ -431,6 +447,8 @@ class Plan:
             self.emit(capi.OP_AXPY, p=[self.G("smooth.bias"), off(tmp32, 13)], l=[1], f=[1.0])   # centre tap: sum of dout
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, u4.thw, 32, 32, u4.thw, 128, u4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
                       p=[dproj.ref, u4.ref, kgproj])
+            self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, 0], l=[0, 0], p=[kgproj, self.G("smooth.weight")])
+            self.mark_final("smooth.weight", "smooth.bias")
             du4, acc = self.grad_for_write(u4)
             self.conv_op(D.conv_fwd(N, u4.thw, 32, 32, 128, du4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0), u4.thw, ldw=32), dproj.ref, wprojT, du4.ref)
         self.tape.append(bwd_smooth)
@@ -467,6 +485,26 @@ class Plan:
         for fn in reversed(self.tape):
             fn()
 
+    def grad_buckets(self, target_floats=12_000_000):
+        """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the
+        order their gradients become final during backward, each with the bwd-op index after which it may
+        be reduced.  -> [(ready_after_bwd_ops, start_float, end_float)] sorted by readiness."""
+        missing = [k for k in self.pshape if k not in self.final_at]
+        if missing:
+            raise RuntimeError("no backward op finalises %s" % missing[:4])
+        names = list(self.pshape)
+        buckets, cur_end, cur_ready, cur_size = [], self.nparams, 0, 0
+        for nm in reversed(names):              # backward finalises parameters roughly in reverse flat order
+            cur_ready = max(cur_ready, self.final_at[nm])
+            cur_size = cur_end - self.poff[nm]
+            if cur_size >= target_floats:
+                buckets.append((cur_ready, self.poff[nm], cur_end))
+                cur_end, cur_ready = self.poff[nm], 0
+        if cur_end > 0:
+            buckets.append((max(cur_ready, max(self.final_at.values()) if cur_ready == 0 else cur_ready), 0, cur_end))
+        buckets.sort(key=lambda b: b[0])
+        return buckets
+
     def build_adam(self):
         self.op_adam = 0
         self.emit(capi.OP_ADAM, i=[1], f=[1e-4, 0.9, 0.999, 1e-6, 1.0], l=[self.nparams], p=[("P", 0), ("G", 0), ("M", 0), ("V", 0)], lst="adam")
@@ -487,12 +525,14 @@ class Plan:
             out[name] = arr
         return out
 
-    def flops(self):
-        """Algorithmic FLOPs of the conv / wgrad ops per list (2*M*N*K)."""
+    def flops(self, only_kind=None):
+        """Algorithmic FLOPs (2*M*N*K, real channel counts) of the conv / wgrad ops per list."""
         tot = {}
         for name, lst in self.lists.items():
             s = 0
             for kind, i, f, p, l in lst:
+                if only_kind is not None and kind != only_kind:
+                    continue
                 if kind == capi.OP_CONV:
                     N, Ci, Tq, Hq, Wq, Co = i[0], i[4], i[6], i[7], i[8], i[12]
                     nt = i[23] * i[24] * i[25]

@@ -64,6 +64,7 @@ class StepEngine:
         self.bases = dict(A=base_a, P=self.P.data_ptr(), G=self.G.data_ptr(), M=self.M.data_ptr(), V=self.V.data_ptr(), R=self.R.data_ptr())
         self.ops = p.resolve(self.bases)
         self.step_count = 0
+        self.kind_ms, self.kind_count = 0.0, 0
         self.load_state(state if state is not None else synthetic.init_state(seed, num_classes))
 
     # ------------------------------------------------------------------ views
@@ -134,15 +135,36 @@ class StepEngine:
         self.action_host = act.cpu()
 
     # ------------------------------------------------------------------ execution
-    def forward_backward(self, epoch, wt_ramp):
+    def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
+        """prep -> forward (both passes batched) -> losses -> backward.  With a dist.GradReducer the
+        backward list is replayed in segments and each gradient bucket's all-reduce is launched as soon
+        as the ops that finalise it are enqueued.  timed_kind: accumulate hipEvent time of that op kind
+        (bench.py roofline leg) into self.kind_ms / self.kind_count."""
         p, o = self.plan, self.ops
         o["fwd"][p.op_cmask]["i"][3] = 0 if epoch < self.args.thresh_epoch else 1
         o["loss"][p.op_loss]["f"][6] = wt_ramp
-        ops.run_ops(o["prep"])
-        ops.run_ops(o["fwd"])
-        ops.run_ops(o["loss"])
-        ops.run_ops(o["bwd"])
-        ops.run_ops(o["unprep"])
+
+        def run(arr):
+            if timed_kind is None or len(arr) == 0:
+                ops.run_ops(arr)
+            else:
+                ms, cnt = ops.run_ops_timed(arr, timed_kind)
+                self.kind_ms += ms
+                self.kind_count += cnt
+        run(o["prep"])
+        run(o["fwd"])
+        run(o["loss"])
+        if reducer is None or reducer.world == 1:
+            run(o["bwd"])
+        else:
+            done = 0
+            for i, (ready, _a, _b) in enumerate(reducer.buckets):
+                if ready > done:
+                    run(o["bwd"][done:ready])
+                    done = ready
+                reducer.launch(i)
+            if done < len(o["bwd"]):
+                run(o["bwd"][done:])
 
     def adam(self, lr, gscale=1.0):
         self.step_count += 1
@@ -171,13 +193,24 @@ class StepEngine:
         pred = self.aview(p.pred, 2 * self.bs * self.C).view(2 * self.bs, self.C)
         return out[:self.bs], out[self.bs:], pred[:self.bs]
 
-    def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, allreduce=None, gscale=1.0):
-        self.stage(label_mb, unlabel_mb, perm, drops)
-        self.forward_backward(epoch, wt_ramp)
-        if allreduce is not None:
-            allreduce(self.G)
+    def make_reducer(self, group=None, target_floats=3_000_000):
+        from . import dist as pdist
+        return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats), group)
+
+    def run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None):
+        """One full step on the minibatch already staged in HBM: fwd x2 + losses + bwd (+ all-reduce) +
+        Adam + the packed loss read-back."""
+        self.forward_backward(epoch, wt_ramp, reducer, timed_kind)
+        gscale = 1.0
+        if reducer is not None:
+            reducer.wait()
+            gscale = reducer.gscale
         self.adam(self.args.lr if lr is None else lr, gscale)
         return self.read_scalars()
+
+    def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, reducer=None):
+        self.stage(label_mb, unlabel_mb, perm, drops)
+        return self.run_staged(epoch, wt_ramp, lr, reducer)
 
 
 def smoke_check(device="cuda:0", hw=224):

@@ -1,0 +1,87 @@
+"""CPU (gloo, world_size 2): the bucketed gradient all-reduce schedule used for data parallelism sums
+exactly the ranges Plan.grad_buckets() hands it, in readiness order, and covers the flat buffer
+once; DP(world x bs) == mean of per-rank gradients."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from picons_amd import dist as pdist, step as pstep
+from picons_amd.plan import Plan
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _build_plan(bs=2, hw=112):
+    args = pstep.default_args(bv=True, n_frames=5)
+    p = Plan(24, hw, n=bs, groups=2)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    return p
+
+
+def test_bucket_schedule_covers_flat_buffer_once():
+    p = _build_plan()
+    b = p.grad_buckets(3_000_000)
+    assert len(b) >= 3
+    assert [x[0] for x in b] == sorted(x[0] for x in b)                   # readiness order
+    spans = sorted((a, e) for _r, a, e in b)
+    assert spans[0][0] == 0 and spans[-1][1] == p.nparams
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    assert b[-1][0] == len(p.lists["bwd"])                               # the last bucket needs the whole backward
+    # decoder + capsule head parameters are final long before the trunk's (they sit at the end of the flat buffer)
+    first = b[0]
+    assert first[2] == p.nparams and first[0] < len(p.lists["bwd"]) // 2
+    # every parameter is finalised by some backward op
+    assert set(p.final_at) == set(p.pshape)
+
+
+def _worker(rank, world, port, nparams, buckets, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    r, w, _ = pdist.init_from_env("gloo")
+    assert (r, w) == (rank, world)
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(nparams, generator=g)
+    mine = flat.clone()
+    red = pdist.GradReducer(flat, buckets)
+    done = 0
+    for i, (ready, a, b) in enumerate(buckets):          # same driving loop as StepEngine.forward_backward
+        assert ready >= done
+        done = ready
+        red.launch(i)
+    red.wait()
+    others = [torch.randn(nparams, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    expect = sum(others)
+    ok = torch.allclose(flat, expect, atol=1e-6) and abs(red.gscale - 1.0 / world) < 1e-12
+    # mean of per-rank gradients == what Adam sees after gscale
+    ok = ok and torch.allclose(flat * red.gscale, torch.stack(others).mean(0), atol=1e-6)
+    ms = pdist.barrier_max_ms(10.0 * (rank + 1))
+    ok = ok and ms == 10.0 * world
+    q.put((rank, bool(ok), float((mine - others[rank]).abs().max())))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_gloo_world2():
+    p = _build_plan()
+    buckets = p.grad_buckets(3_000_000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, p.nparams, buckets, q)) for r in range(2)]
+    for pr in procs:
+        pr.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for pr in procs:
+        pr.join(60)
+    assert all(ok for _r, ok, _d in res), res
+
+
+def test_shard_indices():
+    assert pdist.shard_indices(8, 1, 4) == [2, 3]
+    assert sorted(sum((pdist.shard_indices(16, r, 8) for r in range(8)), [])) == list(range(16))

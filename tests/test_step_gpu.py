@@ -27,7 +27,12 @@ def run_pair(akw, hw, bs, epoch, ncls=24, jhmdb=False, stepid=0, lr=1e-4):
     oa = ostep.default_args(dataset="jhmdb" if jhmdb else "ucf101", **akw)
     ref = ostep.train_step(P, oa, lab, unl, epoch, ramp, perm, drops)
     ref["total"].backward()
-    return eng, ref, P
+    # fp64 run of the same oracle: the anchor for gradients (the fp32 reference differs from ITSELF by ~1 % on
+    # gradients across thread counts, SURVEY finding 4, so fp32-vs-fp32 bars tighter than that are meaningless)
+    P64 = ostep.as_torch_params(synthetic.init_state(47, ncls), dtype=torch.float64)
+    ref64 = ostep.train_step(P64, oa, lab, unl, epoch, ramp, perm, drops, dtype=torch.float64)
+    ref64["total"].backward()
+    return eng, ref, P, P64
 
 
 CASES = [
@@ -42,7 +47,7 @@ CASES = [
 @pytest.mark.parametrize("tag,akw,epoch,ncls,jhmdb", CASES)
 def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
     hw, bs = 112, 2
-    eng, ref, P = run_pair(akw, hw, bs, epoch, ncls, jhmdb)
+    eng, ref, P, P64 = run_pair(akw, hw, bs, epoch, ncls, jhmdb)
     got = eng.read_scalars()
     out, flip, pred = eng.outputs()
     for k in ("total", "loc", "cls", "cons"):
@@ -50,15 +55,27 @@ def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
     assert (pred.cpu() - ref["predicted_action"]).abs().max().item() <= 1e-3
     assert (out.cpu() - ref["output"]).abs().max().item() <= 1e-3
     assert (flip.cpu() - ref["flip_op"]).abs().max().item() <= 1e-3
-    # every parameter gradient, relative L2 per tensor
-    bad = []
+    # every parameter gradient: relative L2 per tensor against the fp64 oracle, judged next to the fp32
+    # oracle's own distance from it
+    bad, rows = [], []
+    num_g = num_c = den_all = 0.0
     for name in eng.plan.pshape:
-        g = eng.grad(name).cpu().double(); r = P[name].grad.double()
-        den = r.norm().item()
-        rel = (g - r).norm().item() / (den + 1e-12)
-        if rel > 2e-2 and (g - r).abs().max().item() > 1e-7:
-            bad.append((name, rel, den))
+        g = eng.grad(name).cpu().double(); r32 = P[name].grad.double(); r64 = P64[name].grad
+        den = r64.norm().item() + 1e-12
+        rel_g = (g - r64).norm().item() / den
+        rel_c = (r32 - r64).norm().item() / den
+        rows.append((name, rel_g, rel_c, den))
+        num_g += (g - r64).norm().item() ** 2; num_c += (r32 - r64).norm().item() ** 2; den_all += den ** 2
+        if rel_g > max(4 * rel_c, 5e-3) and (g - r64).abs().max().item() > 1e-7:
+            bad.append((name, rel_g, rel_c, den))
+    tot_g, tot_c = (num_g / den_all) ** 0.5, (num_c / den_all) ** 0.5
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/step_grad_err_%s.txt" % tag, "w") as f:
+        f.write("whole-gradient rel-L2 vs fp64 oracle: hip %.3e   fp32-oracle %.3e\n" % (tot_g, tot_c))
+        for r in sorted(rows, key=lambda r: -r[1])[:40]:
+            f.write("%-44s hip %.3e  cpu32 %.3e  |g| %.3e\n" % r)
     assert not bad, bad[:10]
+    assert tot_g <= max(3 * tot_c, 2e-3), (tot_g, tot_c)
     # BN running statistics after the two passes
     for pre, _ci, co, _k, _s in spec.trunk_units()[:6] + spec.trunk_units()[-3:]:
         for nm in ("running_mean", "running_var"):
