@@ -32,7 +32,9 @@ def cpu_baseline(seconds_budget=30.0):
     from oracle import step as ostep
     from picons_amd import synthetic
     from picons_amd.step import exp_rampup
-    cores = os.cpu_count() or 1
+    # a bounded thread count: with all 256 host threads of the GPU box torch's CPU convolutions oversubscribe
+    # (the same step took 448 s there); 16 threads finish it in tens of seconds
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     P = ostep.as_torch_params(synthetic.init_state(47, 24))
     a = ostep.default_args(bv=True, n_frames=5, wt_cons=0.1)

@@ -35,11 +35,11 @@ __device__ __forceinline__ float sum_cg(float v) {  // over cg (lane bits 4,5)
     return v;
 }
 
-// per-wave forward state (floats)
+// forward state of one position (floats)
 struct FwdState {
     float P[NB][16];
     float a[NB];
-    float R[3][NB][MAXC];      // R[0] unused (constant 1/C)
+    float R[2][NB][MAXC];      // assignments entering iterations 1 and 2 (iteration 0 uses the constant 1/C)
     float rn[NB][MAXC];        // scratch: normalised assignment of the current iteration
     float invS[3][NB];
     float rs[3][MAXC];
@@ -53,8 +53,7 @@ struct BwdState {
     float dmu[3][MAXC][16];
     float ds2[3][MAXC][16];
     float dlnp[2][NB][MAXC];
-    float dco[NB][MAXC];
-    float dR[NB][MAXC];
+    float dco[NB][MAXC];       // dco -> drn -> dR in place
     float da_out[MAXC];
     float drs[MAXC];
     float da_in[NB];
@@ -66,33 +65,61 @@ __device__ __forceinline__ float vote(const float* WT, const f32x4 prow, int i, 
     return prow[0] * w[0] + prow[1] * w[1] + prow[2] * w[2] + prow[3] * w[3];
 }
 
-// Forward EM for one position held in st->P / st->a.  Leaves every iteration's state in *st.
-__device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, const float* beta_a, int C, int lane) {
+// NW cooperating waves work on ONE position: wave wv owns input capsules [wv*NB/NW, (wv+1)*NB/NW); sums over i
+// are combined through `red` ([NW][MAXC*16] floats per quantity).  NW == 1: a single wave, no block barrier.
+template <int NW>
+__device__ __forceinline__ void SYNC() {
+    if (NW == 1) WSYNC(); else __syncthreads();
+}
+__device__ __forceinline__ float Rt(const FwdState* st, int t, int i, int c, int C) { return t == 0 ? 1.0f / C : st->R[t - 1][i][c]; }
+
+template <int NW>
+__device__ __forceinline__ void xwave_sum(float (&v)[CJ], float* red, int wv, int lane) {
+    if (NW == 1) return;
+    const int h = lane & 15, cg = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) red[wv * (MAXC * 16) + (cg + 4 * j) * 16 + h] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CJ; ++j) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += red[w * (MAXC * 16) + (cg + 4 * j) * 16 + h];
+        v[j] = s;
+    }
+    __syncthreads();
+}
+
+// Forward EM for the position held in st->P / st->a.  Leaves every iteration's state in *st.
+template <int NW>
+__device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, const float* beta_a, int C, int tid, float* red) {
+    const int lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
+    const int i0 = wv * (NB / NW), i1 = i0 + NB / NW;
     for (int t = 0; t < 3; ++t) {
         // ---- M-step (capsules_ucf101.py:127-152)
-        if (lane < NB) {
-            const float ai = st->a[lane];
+        if (tid < NB) {
+            const float ai = st->a[tid];
             float S = 0.f;
-            for (int c = 0; c < C; ++c) S += (t == 0 ? 1.0f / C : st->R[t][lane][c]) * ai;
-            st->invS[t][lane] = 1.0f / (S + EPS);
+            for (int c = 0; c < C; ++c) S += Rt(st, t, tid, c, C) * ai;
+            st->invS[t][tid] = 1.0f / (S + EPS);
         }
-        WSYNC();
-        for (int e = lane; e < NB * C; e += 64) {
+        SYNC<NW>();
+        for (int e = tid; e < NB * C; e += 64 * NW) {
             const int i = e / C, c = e - i * C;
-            st->rn[i][c] = (t == 0 ? 1.0f / C : st->R[t][i][c]) * st->a[i] * st->invS[t][i];
+            st->rn[i][c] = Rt(st, t, i, c, C) * st->a[i] * st->invS[t][i];
         }
-        WSYNC();
-        if (lane < C) {
+        SYNC<NW>();
+        if (tid < C) {
             float s = 0.f;
-            for (int i = 0; i < NB; ++i) s += st->rn[i][lane];
-            st->rs[t][lane] = s;
+            for (int i = 0; i < NB; ++i) s += st->rn[i][tid];
+            st->rs[t][tid] = s;
         }
-        WSYNC();
+        SYNC<NW>();
         float m[CJ], sg[CJ], irs[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) { m[j] = 0.f; sg[j] = 0.f; const int c = cg + 4 * j; irs[j] = c < C ? 1.0f / (st->rs[t][c] + EPS) : 0.f; }
-        for (int i = 0; i < NB; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
@@ -100,7 +127,8 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 if (c < C) m[j] += st->rn[i][c] * irs[j] * vote(WT, prow, i, c, q, C);
             }
         }
-        for (int i = 0; i < NB; ++i) {
+        xwave_sum<NW>(m, red, wv, lane);
+        for (int i = i0; i < i1; ++i) {
             const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
@@ -108,6 +136,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rn[i][c] * irs[j] * d * d; }
             }
         }
+        xwave_sum<NW>(sg, red, wv, lane);
         float cost[CJ]; double csum = 0.0;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
@@ -115,8 +144,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             cost[j] = 0.f;
             if (c < C) {
                 sg[j] += EPS;
-                st->mu[t][c][h] = m[j];
-                st->s2[t][c][h] = sg[j];
+                if (wv == 0) { st->mu[t][c][h] = m[j]; st->s2[t][c][h] = sg[j]; }
                 cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[t][c]);
                 csum += (double)cost[j];
             }
@@ -133,13 +161,18 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
         for (int j = 0; j < CJ; ++j) if (cg + 4 * j < C) ds_d += (double)cost[j] - mean_d;
         ds_d += __shfl_xor(ds_d, 16, 64); ds_d += __shfl_xor(ds_d, 32, 64);
         const float D = sqrtf((float)(ds_d * ds_d / C) + EPS) + EPS;   // sum-then-square, :144
+        float ao[CJ];
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
             const int c = cg + 4 * j;
-            if (c < C && h == 0) st->aout[t][c] = 1.0f / (1.0f + expf(-LAMBDA * (beta_a[c] - (mean - cost[j]) / D)));
+            ao[j] = 0.f;
+            if (c < C) {
+                ao[j] = 1.0f / (1.0f + expf(-LAMBDA * (beta_a[c] - (mean - cost[j]) / D)));
+                if (h == 0 && wv == 0) st->aout[t][c] = ao[j];
+            }
         }
-        if (lane == 0) st->D[t] = D;
-        WSYNC();
+        if (tid == 0) st->D[t] = D;
+        SYNC<NW>();
         if (t == 2) break;
         // ---- E-step (capsules_ucf101.py:176-181)
         float hl[CJ], is2[CJ], la[CJ];
@@ -147,9 +180,9 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
         for (int j = 0; j < CJ; ++j) {
             const int c = cg + 4 * j;
             hl[j] = 0.f; is2[j] = 0.f; la[j] = 0.f;
-            if (c < C) { hl[j] = 0.5f * logf(sg[j]) + HALF_LN_2PI; is2[j] = 1.0f / (2.0f * sg[j]); la[j] = logf(EPS + st->aout[t][c]); }
+            if (c < C) { hl[j] = 0.5f * logf(sg[j]) + HALF_LN_2PI; is2[j] = 1.0f / (2.0f * sg[j]); la[j] = logf(EPS + ao[j]); }
         }
-        for (int i = 0; i < NB; ++i) {
+        for (int i = i0; i < i1; ++i) {
             const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
@@ -157,20 +190,20 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 if (c < C) {
                     const float d = vote(WT, prow, i, c, q, C) - m[j];
                     const float lp = sum16(-d * d * is2[j] - hl[j]);
-                    if (h == 0) st->R[t + 1][i][c] = lp + la[j];
+                    if (h == 0) st->R[t][i][c] = lp + la[j];
                 }
             }
         }
-        WSYNC();
-        if (lane < NB) {   // softmax over c
+        SYNC<NW>();
+        if (tid < NB) {   // softmax over c
             float mx = -INFINITY;
-            for (int c = 0; c < C; ++c) mx = fmaxf(mx, st->R[t + 1][lane][c]);
+            for (int c = 0; c < C; ++c) mx = fmaxf(mx, st->R[t][tid][c]);
             float s = 0.f;
-            for (int c = 0; c < C; ++c) { const float e = expf(st->R[t + 1][lane][c] - mx); st->R[t + 1][lane][c] = e; s += e; }
+            for (int c = 0; c < C; ++c) { const float e = expf(st->R[t][tid][c] - mx); st->R[t][tid][c] = e; s += e; }
             const float inv = 1.0f / s;
-            for (int c = 0; c < C; ++c) st->R[t + 1][lane][c] *= inv;
+            for (int c = 0; c < C; ++c) st->R[t][tid][c] *= inv;
         }
-        WSYNC();
+        SYNC<NW>();
     }
 }
 
@@ -182,10 +215,10 @@ __device__ __forceinline__ void load_WT(float* WT, const float* W, int C, int ti
     }
 }
 
-__device__ __forceinline__ void load_pos(FwdState* st, const float* x, int64_t pos, int lane) {
+__device__ __forceinline__ void load_pos(FwdState* st, const float* x, int64_t pos, int tid, int nthr) {
     const float* xp = x + pos * (NB * 17);
-    for (int e = lane; e < NB * 16 / 4; e += 64) ((f32x4*)&st->P[0][0])[e] = ((const f32x4*)xp)[e];
-    if (lane < NB) st->a[lane] = xp[NB * 16 + lane];
+    for (int e = tid; e < NB * 16 / 4; e += nthr) ((f32x4*)&st->P[0][0])[e] = ((const f32x4*)xp)[e];
+    if (tid < NB) st->a[tid] = xp[NB * 16 + tid];
 }
 
 constexpr int FWD_WAVES = 4;
@@ -202,20 +235,23 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __r
     FwdState* st = sts + wave;
     for (int64_t pos = (int64_t)blockIdx.x * FWD_WAVES + wave; pos < npos; pos += (int64_t)gridDim.x * FWD_WAVES) {
         WSYNC();
-        load_pos(st, x, pos, lane);
+        load_pos(st, x, pos, lane, 64);
         WSYNC();
-        em_forward(st, WT, beta_u, beta_a, C, lane);
+        em_forward<1>(st, WT, beta_u, beta_a, C, lane, nullptr);
         float* o = out + pos * (C * 17);
         for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[2][0][0])[e];
         if (lane < C) o[C * 16 + lane] = st->aout[2][lane];
     }
 }
 
-// Backward: one wave per block; forward recomputed into LDS, then reversed.
-__global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
-                                                    const float* __restrict__ beta_u, const float* __restrict__ beta_a,
-                                                    const float* __restrict__ dout, int npos, int C, float* __restrict__ dx,
-                                                    float* __restrict__ part) {
+// Backward: BWD_WAVES waves per block cooperate on one position at a time; forward recomputed into LDS, then reversed.
+constexpr int BWD_WAVES = 4;
+constexpr int BW = BWD_WAVES;
+
+__global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+                                                                 const float* __restrict__ beta_u, const float* __restrict__ beta_a,
+                                                                 const float* __restrict__ dout, int npos, int C, float* __restrict__ dx,
+                                                                 float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* WT = smem;                              // [NB][C][4(q)][4(k)]
     float* dWacc = smem + NB * MAXC * 16;          // [i][c][k][q]
@@ -223,26 +259,31 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
     float* dba = dbu + MAXC * 16;                  // [C]
     FwdState* st = (FwdState*)(dba + 32);
     BwdState* bs = (BwdState*)(st + 1);
-    const int lane = threadIdx.x;
+    float* red = (float*)(bs + 1);                 // [2][BW][MAXC*16]
+    float* red2 = red + BW * MAXC * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
-    load_WT(WT, W, C, lane, 64);
-    for (int e = lane; e < NB * MAXC * 16 + MAXC * 16 + 32; e += 64) dWacc[e] = 0.f;
-    WSYNC();
+    const int i0 = wv * (NB / BW), i1 = i0 + NB / BW;
+    constexpr int NT = 64 * BW;
+    load_WT(WT, W, C, tid, NT);
+    for (int e = tid; e < NB * MAXC * 16 + MAXC * 16 + 32; e += NT) dWacc[e] = 0.f;
+    __syncthreads();
     for (int64_t pos = blockIdx.x; pos < npos; pos += gridDim.x) {
-        WSYNC();
-        load_pos(st, x, pos, lane);
-        WSYNC();
-        em_forward(st, WT, beta_u, beta_a, C, lane);
+        __syncthreads();
+        load_pos(st, x, pos, tid, NT);
+        __syncthreads();
+        em_forward<BW>(st, WT, beta_u, beta_a, C, tid, red);
         // ---- seeds
         const float* dop = dout + pos * (C * 17);
-        for (int e = lane; e < 3 * MAXC * 16; e += 64) { (&bs->dmu[0][0][0])[e] = 0.f; (&bs->ds2[0][0][0])[e] = 0.f; }
-        WSYNC();
-        for (int e = lane; e < C * 16; e += 64) (&bs->dmu[2][0][0])[e] = dop[e];
-        if (lane < C) bs->da_out[lane] = dop[C * 16 + lane];
-        if (lane < NB) bs->da_in[lane] = 0.f;
-        WSYNC();
+        for (int e = tid; e < 3 * MAXC * 16; e += NT) { (&bs->dmu[0][0][0])[e] = 0.f; (&bs->ds2[0][0][0])[e] = 0.f; }
+        __syncthreads();
+        for (int e = tid; e < C * 16; e += NT) (&bs->dmu[2][0][0])[e] = dop[e];
+        if (tid < C) bs->da_out[tid] = dop[C * 16 + tid];
+        if (tid < NB) bs->da_in[tid] = 0.f;
+        __syncthreads();
         for (int t = 2; t >= 0; --t) {
-            // ---- step A: a_out / cost back to rs, beta, sigma^2  (capsules_ucf101.py:138-152)
+            // ---- step A: a_out / cost back to rs, beta, sigma^2  (capsules_ucf101.py:138-152); every wave computes
+            // the same values, wave 0 stores them
             const float D = st->D[t];
             float du[CJ], dusum = 0.f;
 #pragma unroll
@@ -251,93 +292,96 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
                 du[j] = 0.f;
                 if (c < C) { const float ao = st->aout[t][c]; du[j] = bs->da_out[c] * ao * (1.f - ao); dusum += du[j]; }
             }
-            dusum = sum_cg(dusum);            // every h-lane of a cg holds the same du, so this is sum over c
+            dusum = sum_cg(dusum);            // every h-lane of a cg holds the same du, so this is the sum over c
             const float dmean = -LAMBDA / D * dusum;
+            float ds_new[CJ], dmu_add[CJ], drs_new[CJ];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const int c = cg + 4 * j;
+                ds_new[j] = dmu_add[j] = drs_new[j] = 0.f;
                 if (c < C) {
                     const float dcost = LAMBDA / D * du[j] + dmean / C;
                     const float s2v = st->s2[t][c][h], rsv = st->rs[t][c];
                     const float G = sum16(beta_u[c * 16 + h] + 0.5f * logf(s2v));
-                    dbu[c * 16 + h] += dcost * rsv;
                     const float ds = bs->ds2[t][c][h] + dcost * rsv * 0.5f / s2v;
-                    bs->ds2[t][c][h] = ds;
+                    ds_new[j] = ds;
                     // d sigma^2 / d mu through sum_i co (v-mu)^2 :  -2 ds * mu * eps/(rs+eps)
-                    bs->dmu[t][c][h] += -2.f * ds * st->mu[t][c][h] * (EPS / (rsv + EPS));
-                    if (h == 0) { bs->drs[c] = dcost * G; dba[c] += LAMBDA * du[j]; }
+                    dmu_add[j] = bs->dmu[t][c][h] - 2.f * ds * st->mu[t][c][h] * (EPS / (rsv + EPS));
+                    drs_new[j] = dcost * G;
+                    if (wv == 0) { dbu[c * 16 + h] += dcost * rsv; if (h == 0) dba[c] += LAMBDA * du[j]; }
                 }
             }
-            WSYNC();
-            // recompute rn for this iteration
-            for (int e = lane; e < NB * C; e += 64) {
-                const int i = e / C, c = e - i * C;
-                st->rn[i][c] = (t == 0 ? 1.0f / C : st->R[t][i][c]) * st->a[i] * st->invS[t][i];
-            }
-            WSYNC();
-            // ---- step B: dco[i][c] = sum_h dmu*v + ds2*(v-mu)^2
-            {
-                float dm[CJ], dsv[CJ], muv[CJ];
+            __syncthreads();                  // all reads of ds2/dmu/da_out done before wave 0 overwrites them
+            if (wv == 0) {
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
                     const int c = cg + 4 * j;
-                    dm[j] = dsv[j] = muv[j] = 0.f;
-                    if (c < C) { dm[j] = bs->dmu[t][c][h]; dsv[j] = bs->ds2[t][c][h]; muv[j] = st->mu[t][c][h]; }
+                    if (c < C) { bs->ds2[t][c][h] = ds_new[j]; bs->dmu[t][c][h] = dmu_add[j]; if (h == 0) bs->drs[c] = drs_new[j]; }
                 }
-                for (int i = 0; i < NB; ++i) {
+            }
+            // recompute rn for this iteration
+            for (int e = tid; e < NB * C; e += NT) {
+                const int i = e / C, c = e - i * C;
+                st->rn[i][c] = Rt(st, t, i, c, C) * st->a[i] * st->invS[t][i];
+            }
+            __syncthreads();
+            // ---- step B: dco[i][c] = sum_h dmu*v + ds2*(v-mu)^2
+            {
+                float muv[CJ];
+#pragma unroll
+                for (int j = 0; j < CJ; ++j) { const int c = cg + 4 * j; muv[j] = c < C ? st->mu[t][c][h] : 0.f; }
+                for (int i = i0; i < i1; ++i) {
                     const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
                     for (int j = 0; j < CJ; ++j) {
                         const int c = cg + 4 * j;
                         if (c < C) {
                             const float v = vote(WT, prow, i, c, q, C), d = v - muv[j];
-                            const float s = sum16(dm[j] * v + dsv[j] * d * d);
+                            const float s = sum16(dmu_add[j] * v + ds_new[j] * d * d);
                             if (h == 0) bs->dco[i][c] = s;
                         }
                     }
                 }
             }
-            WSYNC();
+            __syncthreads();
             // ---- step C: co -> rn -> ra -> (R_t, a_in)
-            if (lane < C) {
-                const float irs = 1.0f / (st->rs[t][lane] + EPS);
+            if (tid < C) {
+                const float irs = 1.0f / (st->rs[t][tid] + EPS);
                 float T = 0.f;
-                for (int i = 0; i < NB; ++i) T += bs->dco[i][lane] * st->rn[i][lane] * irs * irs;
-                bs->drs[lane] -= T;
+                for (int i = 0; i < NB; ++i) T += bs->dco[i][tid] * st->rn[i][tid] * irs * irs;
+                bs->drs[tid] -= T;
             }
-            WSYNC();
-            for (int e = lane; e < NB * C; e += 64) {     // dco now holds drn
+            __syncthreads();
+            for (int e = tid; e < NB * C; e += NT) {     // dco now holds drn
                 const int i = e / C, c = e - i * C;
                 bs->dco[i][c] = bs->dco[i][c] / (st->rs[t][c] + EPS) + bs->drs[c];
             }
-            WSYNC();
-            if (lane < NB) {
-                const float iS = st->invS[t][lane], ai = st->a[lane];
+            __syncthreads();
+            if (tid < NB) {                               // ... and then dR_t (in place)
+                const float iS = st->invS[t][tid], ai = st->a[tid];
                 float dot = 0.f;
-                for (int c = 0; c < C; ++c) dot += bs->dco[lane][c] * st->rn[lane][c];
+                for (int c = 0; c < C; ++c) dot += bs->dco[tid][c] * st->rn[tid][c];
                 const float dS = -dot * iS;
                 float dai = 0.f;
                 for (int c = 0; c < C; ++c) {
-                    const float dra = bs->dco[lane][c] * iS + dS;
-                    const float Rt = t == 0 ? 1.0f / C : st->R[t][lane][c];
-                    dai += dra * Rt;
-                    bs->dR[lane][c] = dra * ai;
+                    const float dra = bs->dco[tid][c] * iS + dS;
+                    dai += dra * Rt(st, t, tid, c, C);
+                    bs->dco[tid][c] = dra * ai;
                 }
-                bs->da_in[lane] += dai;
+                bs->da_in[tid] += dai;
+                if (t > 0) {
+                    // ---- step D(i): E-step (t-1) backward from dR_t  (capsules_ucf101.py:176-181)
+                    float dot2 = 0.f;
+                    for (int c = 0; c < C; ++c) dot2 += st->R[t - 1][tid][c] * bs->dco[tid][c];
+                    for (int c = 0; c < C; ++c) bs->dlnp[t - 1][tid][c] = st->R[t - 1][tid][c] * (bs->dco[tid][c] - dot2);
+                }
             }
-            WSYNC();
+            __syncthreads();
             if (t == 0) break;
-            // ---- step D: E-step (t-1) backward from dR_t  (capsules_ucf101.py:176-181)
-            if (lane < NB) {
-                float dot = 0.f;
-                for (int c = 0; c < C; ++c) dot += st->R[t][lane][c] * bs->dR[lane][c];
-                for (int c = 0; c < C; ++c) bs->dlnp[t - 1][lane][c] = st->R[t][lane][c] * (bs->dR[lane][c] - dot);
-            }
-            WSYNC();
-            if (lane < C) {
+            if (tid < C) {
                 float s = 0.f;
-                for (int i = 0; i < NB; ++i) s += bs->dlnp[t - 1][i][lane];
-                bs->da_out[lane] = s / (EPS + st->aout[t - 1][lane]);
+                for (int i = 0; i < NB; ++i) s += bs->dlnp[t - 1][i][tid];
+                bs->da_out[tid] = s / (EPS + st->aout[t - 1][tid]);
             }
             {
                 float am[CJ], as2[CJ], muv[CJ], is2[CJ];
@@ -347,7 +391,7 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
                     am[j] = as2[j] = muv[j] = is2[j] = 0.f;
                     if (c < C) { muv[j] = st->mu[t - 1][c][h]; is2[j] = 1.0f / st->s2[t - 1][c][h]; }
                 }
-                for (int i = 0; i < NB; ++i) {
+                for (int i = i0; i < i1; ++i) {
                     const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
                     for (int j = 0; j < CJ; ++j) {
@@ -360,15 +404,19 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
                         }
                     }
                 }
+                xwave_sum<BW>(am, red, wv, lane);
+                xwave_sum<BW>(as2, red2, wv, lane);
+                if (wv == 0) {
 #pragma unroll
-                for (int j = 0; j < CJ; ++j) {
-                    const int c = cg + 4 * j;
-                    if (c < C) { bs->dmu[t - 1][c][h] = am[j]; bs->ds2[t - 1][c][h] = as2[j]; }
+                    for (int j = 0; j < CJ; ++j) {
+                        const int c = cg + 4 * j;
+                        if (c < C) { bs->dmu[t - 1][c][h] = am[j]; bs->ds2[t - 1][c][h] = as2[j]; }
+                    }
                 }
             }
-            WSYNC();
+            __syncthreads();
         }
-        // ---- final loop: total dv -> dP (to dx) and dW (LDS accumulator)
+        // ---- final loop: total dv -> dP (to dx) and dW (LDS accumulator; wave wv owns its own i rows)
         {
             float dm[3][CJ], dsv[3][CJ], muv[3][CJ], is2[2][CJ], irs[3][CJ];
 #pragma unroll
@@ -385,21 +433,20 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
                     }
                 }
             float* dxp = dx + pos * (NB * 17);
-            for (int i = 0; i < NB; ++i) {
+            for (int i = i0; i < i1; ++i) {
                 const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
                 const float ai = st->a[i];
                 f32x4 dP = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < CJ; ++j) {
                     const int c = cg + 4 * j;
-                    if (c >= C) continue;   // uniform within a 16-lane group; shuffles below stay inside the group or are zero-padded
+                    if (c >= C) continue;   // uniform within a 16-lane group; the shuffles below stay inside the group
                     const f32x4 w = *(const f32x4*)(WT + ((i * C + c) * 4 + q) * 4);
                     const float v = prow[0] * w[0] + prow[1] * w[1] + prow[2] * w[2] + prow[3] * w[3];
                     float dv = 0.f;
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
-                        const float Rt = t == 0 ? 1.0f / C : st->R[t][i][c];
-                        const float co = Rt * ai * st->invS[t][i] * irs[t][j];
+                        const float co = Rt(st, t, i, c, C) * ai * st->invS[t][i] * irs[t][j];
                         dv += co * (dm[t][j] + 2.f * dsv[t][j] * (v - muv[t][j]));
                         if (t < 2) dv -= bs->dlnp[t][i][c] * (v - muv[t][j]) * is2[t][j];
                     }
@@ -420,12 +467,12 @@ __global__ __launch_bounds__(64) void em_bwd_kernel(const float* __restrict__ x,
                 }
                 if (q == 0 && cg == 0) *(f32x4*)(dxp + i * 16 + p * 4) = dP;
             }
-            if (lane < NB) dxp[NB * 16 + lane] = bs->da_in[lane];
+            if (tid < NB) dxp[NB * 16 + tid] = bs->da_in[tid];
         }
     }
-    WSYNC();
+    __syncthreads();
     float* pp = part + (size_t)blockIdx.x * (NB * MAXC * 16 + MAXC * 16 + 32);
-    for (int e = lane; e < NB * MAXC * 16 + MAXC * 16 + 32; e += 64) pp[e] = dWacc[e];
+    for (int e = tid; e < NB * MAXC * 16 + MAXC * 16 + 32; e += NT) pp[e] = dWacc[e];
 }
 
 // part [nblk][NB*MAXC*16 + MAXC*16 + 32] -> dW [NB][C][4][4], dbeta_u [C][16], dbeta_a [C]  (+=)
@@ -499,30 +546,44 @@ __global__ __launch_bounds__(256) void cmask_bwd_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------ tap sum (smooth stage 2)
 // proj [N][T][H][W][32] (27 used); ConvTranspose3d k3 p1 s1: out[o] = b + sum_k proj[o + 1 - k][k]
+// Block = 8(h) x 32(w) outputs of one frame.  For each temporal tap a the 10 x 34 halo of positions is staged in
+// LDS with only the 12 floats that hold taps 9a..9a+8 (coalesced float4 loads), then every thread sums its 9 taps.
+constexpr int TS_H = 8, TS_W = 32, TS_LD = 13;
 __global__ __launch_bounds__(256) void tapsum_fwd_kernel(const float* __restrict__ proj, int N, int T, int H, int W, const float* __restrict__ bias,
                                                          float* __restrict__ out) {
-    const int64_t total = (int64_t)N * T * H * W;
-    const float b = bias ? bias[0] : 0.f;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        int64_t r = idx;
-        const int w = (int)(r % W); r /= W;
-        const int h = (int)(r % H); r /= H;
-        const int t = (int)(r % T); const int n = (int)(r / T);
-        float s = b;
-        int tap = 0;
-        for (int a = 0; a < 3; ++a) {
-            const int ti = t + 1 - a;
-            for (int bb = 0; bb < 3; ++bb) {
-                const int hi = h + 1 - bb;
-                for (int c = 0; c < 3; ++c, ++tap) {
-                    const int wi = w + 1 - c;
-                    if ((unsigned)ti < (unsigned)T && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-                        s += proj[((size_t)((n * T + ti) * H + hi) * W + wi) * 32 + tap];
-                }
-            }
+    __shared__ float slab[(TS_H + 2) * (TS_W + 2) * TS_LD];
+    const int wt = (W + TS_W - 1) / TS_W, ht = (H + TS_H - 1) / TS_H;
+    int bid = blockIdx.x;
+    const int w0 = (bid % wt) * TS_W; bid /= wt;
+    const int h0 = (bid % ht) * TS_H; bid /= ht;
+    const int t = bid % T; const int n = bid / T;
+    const int hl = threadIdx.x / TS_W, wl = threadIdx.x % TS_W;
+    float s = bias ? bias[0] : 0.f;
+    for (int a = 0; a < 3; ++a) {
+        const int ti = t + 1 - a;
+        if ((unsigned)ti >= (unsigned)T) continue;            // block-uniform
+        const int f0 = (9 * a) / 4;                           // first float4 of the 3 that cover taps 9a..9a+8
+        __syncthreads();
+        for (int e = threadIdx.x; e < (TS_H + 2) * (TS_W + 2) * 3; e += 256) {
+            const int pos = e / 3, f = e - pos * 3;
+            const int r = pos / (TS_W + 2), c = pos - r * (TS_W + 2);
+            const int hi = h0 - 1 + r, wi = w0 - 1 + c;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if ((unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                v = *(const f32x4*)(proj + ((size_t)((n * T + ti) * H + hi) * W + wi) * 32 + (f0 + f) * 4);
+            float* d = slab + pos * TS_LD + f * 4;
+            d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
         }
-        out[idx] = s;
+        __syncthreads();
+        const int k0 = 9 * a - 4 * f0;
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                s += slab[((hl + 2 - b) * (TS_W + 2) + (wl + 2 - c)) * TS_LD + k0 + 3 * b + c];
     }
+    const int h = h0 + hl, w = w0 + wl;
+    if (h < H && w < W) out[(size_t)((n * T + t) * H + h) * W + w] = s;
 }
 
 // dproj[i][k] = dout[i - 1 + k]
@@ -551,7 +612,7 @@ __global__ __launch_bounds__(256) void tapsum_bwd_kernel(const float* __restrict
     }
 }
 
-inline int em_bwd_blocks(int npos) { return npos < 512 ? npos : 512; }
+inline int em_bwd_blocks(int npos) { return npos < 256 ? npos : 256; }
 constexpr size_t EM_PART = NB * MAXC * 16 + MAXC * 16 + 32;
 
 }  // namespace
@@ -581,11 +642,11 @@ extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* be
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(x && W && beta_u && beta_a && dout && dx && dW && dbeta_u && dbeta_a && ws, "pc_em_routing_bwd: null");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_bwd: B must be 32 and C <= 24");
-    const size_t lds = (2 * (size_t)NB * MAXC * 16 + MAXC * 16 + 32) * 4 + sizeof(FwdState) + sizeof(BwdState);
+    const size_t lds = (2 * (size_t)NB * MAXC * 16 + MAXC * 16 + 32) * 4 + sizeof(FwdState) + sizeof(BwdState) + 2 * BWD_WAVES * MAXC * 16 * 4;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)em_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     const int nblk = em_bwd_blocks(npos);
-    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
+    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64 * BWD_WAVES), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
     PC_CHECK_LAUNCH("em_bwd");
     hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, 256)), dim3(256), 0, s, ws, nblk, C, dW, dbeta_u, dbeta_a);
     PC_CHECK_LAUNCH("em_reduce");
@@ -617,9 +678,9 @@ extern "C" int pc_class_mask_bwd(const float* dmasked, const float* dactor_pred,
 
 extern "C" int pc_tapsum_fwd(const float* proj, int N, int T, int H, int W, const float* bias, float* out, pc_stream s) {
     PC_CHECK_ARG(proj && out, "pc_tapsum_fwd: null");
-    const int64_t total = (int64_t)N * T * H * W;
-    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(tapsum_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, proj, N, T, H, W, bias, out);
+    const int64_t grid = (int64_t)N * T * ((H + TS_H - 1) / TS_H) * ((W + TS_W - 1) / TS_W);
+    PC_CHECK_ARG(grid < (1ll << 31), "pc_tapsum_fwd: grid too large");
+    hipLaunchKernelGGL(tapsum_fwd_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)s, proj, N, T, H, W, bias, out);
     PC_CHECK_LAUNCH("tapsum_fwd");
     return PC_OK;
 }

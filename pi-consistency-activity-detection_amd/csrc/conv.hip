@@ -20,7 +20,7 @@ struct ConvK {
 constexpr int BK = 32;       // K chunk (floats)
 constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool FAST>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
@@ -64,43 +64,65 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
 
     f32x4 areg[AR], breg[BR];
     const int tapHW = p.ntap[1] * p.ntap[2];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-    auto gload = [&](int c) {
-        const int kk = c * BK + lcol;
-        const bool kval = kk < p.K;
-        const int tap = kk / p.Ci, ci = kk - tap * p.Ci;
-        const int a_ = tap / tapHW, rem = tap - a_ * tapHW;
-        const int b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
-        const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
-        const int wtap = ((p.wk0[0] + a_ * p.wkstep[0]) * p.KH + p.wk0[1] + b_ * p.wkstep[1]) * p.KW +
-                         p.wk0[2] + c_ * p.wkstep[2];
+    // Branch-free tile fetch: invalid rows / taps read a safe address and are zeroed by a select, so the
+    // compiler emits straight-line global_load_dwordx4 instead of one exec-masked branch per load.
+    unsigned vmask = 0;   // validity bits of the in-flight tile (A rows then B rows); applied when the tile is stored to LDS
+    auto fetch = [&](int dt, int dh, int dw, int wtap, int ci, bool kval) {
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < AR; ++j) {
             const int t = ri[j].y + dt, h = ri[j].z + dh, w = ri[j].w + dw;
             const bool v = kval && ri[j].x >= 0 && (unsigned)t < (unsigned)p.Ti &&
                            (unsigned)h < (unsigned)p.Hi && (unsigned)w < (unsigned)p.Wi;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v) {
-                const size_t pos = (size_t)(((ri[j].x * p.Ti + t) * p.Hi + h) * p.Wi + w);
-                val = *(const f32x4*)(p.in + pos * p.ldi + ci);
-            }
-            areg[j] = val;
+            const size_t pos = (size_t)(((ri[j].x * p.Ti + t) * p.Hi + h) * p.Wi + w);
+            const float* src = v ? p.in + pos * p.ldi + ci : p.in;
+            areg[j] = *(const f32x4*)src;
+            m |= (v ? 1u : 0u) << j;
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j) {
             const int co = n0 + lrow + 32 * j;
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (kval && co < p.Co) val = *(const f32x4*)(p.w + ((size_t)co * p.wtaps + wtap) * p.ldw + ci);
-            breg[j] = val;
+            const bool v = kval && co < p.Co;
+            const float* src = v ? p.w + ((size_t)co * p.wtaps + wtap) * p.ldw + ci : p.w;
+            breg[j] = *(const f32x4*)src;
+            m |= (v ? 1u : 0u) << (AR + j);
+        }
+        vmask = m;
+    };
+    // FAST (Ci % 32 == 0): a K chunk lies inside one tap, so the tap walk is wave-uniform scalar state
+    // advanced once per chunk; otherwise decode (tap, ci) per thread with integer division.
+    int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
+    auto gload = [&](int c) {
+        if (FAST) {
+            const int dt = u_a * p.istep[0], dh = u_b * p.istep[1], dw = u_c * p.istep[2];
+            const int wtap = ((p.wk0[0] + u_a * p.wkstep[0]) * p.KH + p.wk0[1] + u_b * p.wkstep[1]) * p.KW +
+                             p.wk0[2] + u_c * p.wkstep[2];
+            fetch(dt, dh, dw, wtap, u_ci + lcol, true);
+            u_ci += BK;
+            if (u_ci >= p.Ci) {
+                u_ci = 0;
+                if (++u_c == p.ntap[2]) { u_c = 0; if (++u_b == p.ntap[1]) { u_b = 0; ++u_a; } }
+            }
+        } else {
+            const int kk = c * BK + lcol;
+            const bool kval = kk < p.K;
+            const int tap = kk / p.Ci, ci = kk - tap * p.Ci;
+            const int a_ = tap / tapHW, rem = tap - a_ * tapHW;
+            const int b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
+            const int wtap = ((p.wk0[0] + a_ * p.wkstep[0]) * p.KH + p.wk0[1] + b_ * p.wkstep[1]) * p.KW +
+                             p.wk0[2] + c_ * p.wkstep[2];
+            fetch(a_ * p.istep[0], b_ * p.istep[1], c_ * p.istep[2], kval ? wtap : 0, kval ? ci : 0, kval);
         }
     };
     auto lstore = [&](int buf) {
         float* a = As + buf * BM * LDK;
         float* b = Bs + buf * BN * LDK;
 #pragma unroll
-        for (int j = 0; j < AR; ++j) *(f32x4*)(a + (lrow + 32 * j) * LDK + lcol) = areg[j];
+        for (int j = 0; j < AR; ++j) *(f32x4*)(a + (lrow + 32 * j) * LDK + lcol) = ((vmask >> j) & 1u) ? areg[j] : zero4;
 #pragma unroll
-        for (int j = 0; j < BR; ++j) *(f32x4*)(b + (lrow + 32 * j) * LDK + lcol) = breg[j];
+        for (int j = 0; j < BR; ++j) *(f32x4*)(b + (lrow + 32 * j) * LDK + lcol) = ((vmask >> (AR + j)) & 1u) ? breg[j] : zero4;
     };
 
     f32x16 acc[TM][TN];
@@ -185,22 +207,27 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_conv(const ConvK& k, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, bool FAST>
+int launch_conv2(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * (BM + BN) * LDK + BM * 5) * sizeof(float);
     if (!attr_set) {
-        hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, FAST>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     ConvK p = k;
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
     const int grid = p.groups * p.mtiles_g * p.ntiles;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN>), dim3(grid), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, FAST>), dim3(grid), dim3(256), lds, s, p);
     PC_CHECK_LAUNCH("conv_gemm_kernel");
     return PC_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv(const ConvK& k, hipStream_t s) {
+    return (k.Ci % BK == 0) ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
 }
 
 // tile choice: minimise padded work, prefer larger tiles when the grid still fills the chip
@@ -324,34 +351,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     };
     constexpr int DN = BK / DRP, SN = BK / SRP;        // loads per thread
     f32x4 dreg[DN], sreg[SN];
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    unsigned vmask = 0;   // validity of the in-flight tile; applied at the LDS store so the loads stay branch-free
     auto gload = [&](int c) {
+        unsigned m = 0;
 #pragma unroll
         for (int j = 0; j < DN; ++j) {
             const int r = drow0 + DRP * j;
             const int pos = c * BK + r;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (mval && pos < p.P) v = *(const f32x4*)(p.D + (size_t)pos * p.ldd + m0 + dcol);
-            dreg[j] = v;
+            const bool v = mval && pos < p.P;
+            const float* src = v ? p.D + (size_t)pos * p.ldd + m0 + dcol : p.D;
+            dreg[j] = *(const f32x4*)src;
+            m |= (v ? 1u : 0u) << j;
         }
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
             const int r = srow0 + SRP * j;
             const int4 info = ptab[c % 3][r];
             const int t = info.y + dt, h = info.z + dh, w = info.w + dw;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
-                (unsigned)w < (unsigned)p.Ws) {
-                const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
-                v = *(const f32x4*)(p.S + ps * p.lds + cs);
-            }
-            sreg[j] = v;
+            const bool v = nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
+                           (unsigned)w < (unsigned)p.Ws;
+            const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
+            const float* src = v ? p.S + ps * p.lds + cs : p.S;
+            sreg[j] = *(const f32x4*)src;
+            m |= (v ? 1u : 0u) << (DN + j);
         }
+        vmask = m;
     };
     auto lstore = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < DN; ++j) *(f32x4*)&Ds[buf][drow0 + DRP * j][dcol] = dreg[j];
+        for (int j = 0; j < DN; ++j) *(f32x4*)&Ds[buf][drow0 + DRP * j][dcol] = ((vmask >> j) & 1u) ? dreg[j] : zero4;
 #pragma unroll
-        for (int j = 0; j < SN; ++j) *(f32x4*)&Ss[buf][srow0 + SRP * j][scol] = sreg[j];
+        for (int j = 0; j < SN; ++j) *(f32x4*)&Ss[buf][srow0 + SRP * j][scol] = ((vmask >> (DN + j)) & 1u) ? sreg[j] : zero4;
     };
 
     f32x16 acc[TM][TN];

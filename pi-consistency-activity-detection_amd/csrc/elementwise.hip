@@ -8,29 +8,44 @@ namespace {
 
 // ------------------------------------------------------------------------------ BN forward
 // part [groups][npg][2][C]; stat [groups][4][C] = mean, invstd, scale, shift.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ part, int npg, int groups,
-                                                          int C, double count, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, float eps, float mom,
-                                                          float* rmean, float* rvar, float* __restrict__ stat) {
-    __shared__ double sh[2][4][64];
+constexpr int FIN_RL = 16;   // row lanes of the partial-sum finalize kernels (1024-thread blocks)
+
+// sum over partial rows [npg][2][C] for 64 channels; result valid on threads with rl == 0
+__device__ __forceinline__ void partial_colsum(const float* __restrict__ part, int npg, int C, int c, int rl,
+                                               double (*sh)[FIN_RL][64], int cl, double& s, double& s2) {
+    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    if (c < C) {
+        int i = rl;
+        for (; i + FIN_RL < npg; i += 2 * FIN_RL) {
+            const float* q0 = part + (size_t)i * 2 * C + c;
+            const float* q1 = part + (size_t)(i + FIN_RL) * 2 * C + c;
+            const float x0 = q0[0], y0 = q0[C], x1 = q1[0], y1 = q1[C];
+            a0 += (double)x0; b0 += (double)y0; a1 += (double)x1; b1 += (double)y1;
+        }
+        if (i < npg) { const float* q0 = part + (size_t)i * 2 * C + c; a0 += (double)q0[0]; b0 += (double)q0[C]; }
+    }
+    sh[0][rl][cl] = a0 + a1; sh[1][rl][cl] = b0 + b1;
+    __syncthreads();
+    s = 0; s2 = 0;
+    if (rl == 0)
+        for (int r = 0; r < FIN_RL; ++r) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int npg, int groups,
+                                                           int C, double count, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float eps, float mom,
+                                                           float* rmean, float* rvar, float* __restrict__ stat) {
+    __shared__ double sh[2][FIN_RL][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float rm = 0.f, rv = 0.f;
-    const bool upd = (rmean != nullptr) && c < C;
+    const bool upd = (rmean != nullptr) && c < C && rl == 0;
     if (upd) { rm = rmean[c]; rv = rvar[c]; }
     for (int g = 0; g < groups; ++g) {
-        double s = 0.0, s2 = 0.0;
-        if (c < C)
-            for (int i = rl; i < npg; i += 4) {
-                const float* q = part + ((size_t)(g * npg + i) * 2) * C + c;
-                s += (double)q[0];
-                s2 += (double)q[C];
-            }
-        sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
-        __syncthreads();
+        double s, s2;
+        partial_colsum(part + (size_t)g * npg * 2 * C, npg, C, c, rl, sh, cl, s, s2);
         if (rl == 0 && c < C) {
-            s = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-            s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
             const double mean = s / count;
             double var = s2 / count - mean * mean;
             if (var < 0.0) var = 0.0;
@@ -44,9 +59,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                 rv = (1.f - mom) * rv + mom * (float)unb;
             }
         }
-        __syncthreads();
     }
-    if (upd && rl == 0) { rmean[c] = rm; rvar[c] = rv; }
+    if (upd) { rmean[c] = rm; rvar[c] = rv; }
 }
 
 __global__ __launch_bounds__(256) void bn_eval_stat_kernel(const float* gamma, const float* beta, const float* rm,
@@ -135,31 +149,21 @@ __global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
 
 // partials [groups][npg][2][C] -> coef [groups][2][C] = (sum_dzh/count, sum_dzh_xhat/count);
 // dgamma/dbeta (+)= sums over all groups.
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
-                                                              double count, float* coef, float* dgamma, float* dbeta,
-                                                              int accum) {
-    __shared__ double sh[2][4][64];
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
+                                                               double count, float* coef, float* dgamma, float* dbeta,
+                                                               int accum) {
+    __shared__ double sh[2][FIN_RL][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < groups; ++g) {
-        double s = 0.0, s2 = 0.0;
-        if (c < C)
-            for (int i = rl; i < npg; i += 4) {
-                const float* q = part + ((size_t)(g * npg + i) * 2) * C + c;
-                s += (double)q[0];
-                s2 += (double)q[C];
-            }
-        sh[0][rl][cl] = s; sh[1][rl][cl] = s2;
-        __syncthreads();
+        double s, s2;
+        partial_colsum(part + (size_t)g * npg * 2 * C, npg, C, c, rl, sh, cl, s, s2);
         if (rl == 0 && c < C) {
-            s = sh[0][0][cl] + sh[0][1][cl] + sh[0][2][cl] + sh[0][3][cl];
-            s2 = sh[1][0][cl] + sh[1][1][cl] + sh[1][2][cl] + sh[1][3][cl];
             coef[(size_t)g * 2 * C + c] = (float)(s / count);
             coef[(size_t)g * 2 * C + C + c] = (float)(s2 / count);
             tb += s; tg += s2;
         }
-        __syncthreads();
     }
     if (rl == 0 && c < C) {
         if (dbeta) dbeta[c] = (accum ? dbeta[c] : 0.f) + (float)tb;
@@ -194,16 +198,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // partial [nblk][2][C] -> dbias (+)=
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
-    __shared__ double sh[4][64];
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
+    __shared__ double sh[2][FIN_RL][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
-    double s = 0.0;
-    if (c < C)
-        for (int i = rl; i < nblk; i += 4) s += (double)part[(size_t)i * 2 * C + c];
-    sh[rl][cl] = s;
-    __syncthreads();
-    if (rl == 0 && c < C) out[c] = (accum ? out[c] : 0.f) + (float)(sh[0][cl] + sh[1][cl] + sh[2][cl] + sh[3][cl]);
+    double s, s2;
+    partial_colsum(part, nblk, C, c, rl, sh, cl, s, s2);
+    if (rl == 0 && c < C) out[c] = (accum ? out[c] : 0.f) + (float)s;
 }
 
 __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
@@ -378,7 +379,7 @@ inline int grid_for(int64_t n, int per_thread = 1) {
     return (int)b;
 }
 inline int64_t red_rows_per_block(int64_t rows) {
-    int64_t r = (rows + 2047) / 2048;
+    int64_t r = (rows + 1023) / 1024;
     if (r < 32) r = 32;
     return r;
 }
@@ -390,7 +391,7 @@ extern "C" int pc_bn_finalize(const float* part, int nparts_per_group, int group
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* stat, pc_stream s) {
     PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
                        (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
     PC_CHECK_LAUNCH("bn_finalize");
     return PC_OK;
@@ -436,7 +437,7 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg), dim3(256), 0, s, p);
     }
     PC_CHECK_LAUNCH("bn_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, z, ldz, stat, coef, C / 4, total4, rpg, relu, dz, lddz);
     PC_CHECK_LAUNCH("bn_bwd apply");
@@ -486,7 +487,7 @@ extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, in
         p.a = dy; p.lda = lddy; p.b = y; p.ldb = ldy; p.stat = nullptr; p.C4 = C / 4; p.rows = rows; p.rows_per_group = rows;
         p.rows_per_block = rpb; p.act = act; p.part = ws;
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, s, ws, nblk, C, dbias, accum);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, nblk, C, dbias, accum);
     }
     if (dz && (act != PC_ACT_NONE || dz != dy)) {
         PC_CHECK_ARG(lddz % 4 == 0, "pc_act_bwd: lddz");

@@ -42,8 +42,11 @@ def off(ref, nfloats):
 
 
 class Plan:
-    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False):
-        """n = clips per forward pass; the batch the kernels see is N = groups*n."""
+    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False):
+        """n = clips per forward pass; the batch the kernels see is N = groups*n.
+        accum_grads: backward adds into the flat G buffer instead of overwriting it (drop-in nn.Module path,
+        where the reference's two forward passes are two separate autograd graphs)."""
+        self.acc = 1 if accum_grads else 0
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -140,7 +143,7 @@ class Plan:
             if need_tr:
                 self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst="prep")
             # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]  (flushed right after the wgrad, see flush_grad)
-            w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, 0], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
+            w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, self.acc], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
             o0 += Oi
         self.kw[key] = w
         return w
@@ -154,7 +157,7 @@ class Plan:
         src = self.P(name)
         self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst="prep")
         self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst="prep")
-        w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, 0], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
+        w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, self.acc], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
         self.kw[name] = w
         return w
 
@@ -204,7 +207,7 @@ class Plan:
             dy = self.grad_of(y)
             dz = self.tensor(x.N, othw, cout, pre + ".dz")
             ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
-            self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, 0], l=[z.rows],
+            self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
                       p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
@@ -264,7 +267,7 @@ class Plan:
             dy = self.grad_of(out)
             dz = self.tensor(x.N, othw, cout, name + ".dz")
             ws = self.alloc(_act_bwd_ws(out.rows, cout))
-            self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, 0], l=[out.rows],
+            self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
@@ -296,10 +299,10 @@ class Plan:
             if cscale is not None:        # d(acc+bias) = dy * scale  (out itself is already scaled)
                 assert act == capi.ACT_NONE
                 self.emit(capi.OP_CHSCALE, i=[dy.ld, x.N, cout, dz.ld, 0], l=[out.rows // x.N], p=[dy.ref, cscale, dz.ref])
-                self.emit(capi.OP_ACT_BWD, i=[dz.ld, dz.ld, capi.ACT_NONE, cout, dz.ld, 0], l=[out.rows],
+                self.emit(capi.OP_ACT_BWD, i=[dz.ld, dz.ld, capi.ACT_NONE, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dz.ref, dz.ref, None, self.G(name + ".bias"), ws])
             else:
-                self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, 0], l=[out.rows],
+                self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad), D.WGRAD_FIELDS),
                       p=[x.ref, dz.ref, w["kg"]])
@@ -389,15 +392,16 @@ class Plan:
             dcaps = self.tensor(N, (1, s20, s20), npose + spec.IN_CAPS, "d_caps_in")
             ws = self.alloc(_em_ws(npos, spec.IN_CAPS, C))
             for nm in ("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a"):
-                self.emit(capi.OP_FILL, p=[self.G(nm)], l=[int(np.prod(self.pshape[nm]))], f=[0.0])
+                if not self.acc:
+                    self.emit(capi.OP_FILL, p=[self.G(nm)], l=[int(np.prod(self.pshape[nm]))], f=[0.0])
             self.emit(capi.OP_EM_BWD, i=[npos, spec.IN_CAPS, C],
                       p=[caps_in.ref, Wc, bu, ba, dcomb.ref, dcaps.ref, self.G("conv_caps.weights"), self.G("conv_caps.beta_u"), self.G("conv_caps.beta_a"), ws])
             # primary caps backward: sigmoid on the activation channels, bias grads, wgrad, dgrad
             ws2 = self.alloc(_act_bwd_ws(caps_in.rows, npose))
             a_sl, da_sl = caps_in.slice(npose, spec.IN_CAPS), dcaps.slice(npose, spec.IN_CAPS)
-            self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_SIGMOID, spec.IN_CAPS, dcaps.ld, 0], l=[caps_in.rows],
+            self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_SIGMOID, spec.IN_CAPS, dcaps.ld, self.acc], l=[caps_in.rows],
                       p=[da_sl.ref, a_sl.ref, da_sl.ref, self.G("primary_caps.a.bias"), ws2])
-            self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_NONE, npose, dcaps.ld, 0], l=[caps_in.rows],
+            self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_NONE, npose, dcaps.ld, self.acc], l=[caps_in.rows],
                       p=[dcaps.ref, caps_in.ref, None, self.G("primary_caps.pose.bias"), ws2])
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
                       p=[dcaps.ref, xd.ref, wpc["kg"]])
@@ -443,11 +447,12 @@ class Plan:
             tmp32 = self.alloc(32)
             ws = self.alloc(_act_bwd_ws(dproj.rows, 32))
             self.emit(capi.OP_ACT_BWD, i=[32, 32, capi.ACT_NONE, 32, 32, 0], l=[dproj.rows], p=[dproj.ref, dproj.ref, None, tmp32, ws])
-            self.emit(capi.OP_FILL, p=[self.G("smooth.bias")], l=[1], f=[0.0])
+            if not self.acc:
+                self.emit(capi.OP_FILL, p=[self.G("smooth.bias")], l=[1], f=[0.0])
             self.emit(capi.OP_AXPY, p=[self.G("smooth.bias"), off(tmp32, 13)], l=[1], f=[1.0])   # centre tap: sum of dout
             self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, u4.thw, 32, 32, u4.thw, 128, u4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
                       p=[dproj.ref, u4.ref, kgproj])
-            self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, 0], l=[0, 0], p=[kgproj, self.G("smooth.weight")])
+            self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, self.acc], l=[0, 0], p=[kgproj, self.G("smooth.weight")])
             self.mark_final("smooth.weight", "smooth.bias")
             du4, acc = self.grad_for_write(u4)
             self.conv_op(D.conv_fwd(N, u4.thw, 32, 32, 128, du4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0), u4.thw, ldw=32), dproj.ref, wprojT, du4.ref)
@@ -477,6 +482,12 @@ class Plan:
         self.emit(capi.OP_LOSS, i=[n, T, hw, hw, int(args.bv), int(args.gv), int(args.n_frames), int(args.predict_maps), int(self.jhmdb)],
                   f=[lower, upper, float(args.bv_wt), float(args.gv_wt), float(args.wt_loc), float(args.wt_cons), 0.0],
                   p=[self.out.ref, off(self.out.ref, n * per), self.seg32, self.in_labeled, self.scalars, self.dout, off(self.dout, n * per), None, None, ws])
+
+    def build_seeds(self):
+        """Gradient seeds for the nn.Module path (no fused loss): autograd hands d(out_1), d(actor_prediction)."""
+        per = spec.FRAMES * self.hw * self.hw
+        self.dout = self.alloc(self.N * per)
+        self.dpred = self.alloc(self.N * self.C)
 
     def build_backward(self):
         self.cur = "bwd"
