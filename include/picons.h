@@ -74,7 +74,7 @@ int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const fl
 int pc_conv_bnpart_rows(const pc_conv_desc* d);
 
 /* Weight gradient:  g[m][ (a,b,c) , cs ] += sum_{n,q} D[n,q,m] * S[n, q*istr+ioff0+(a,b,c)*istep, cs]
- * D dense over the lattice (Tq,Hq,Wq), S gathered.  g layout [Cd][ntap_t*ntap_h*ntap_w][Cs],
+ * D dense over the lattice (Tq,Hq,Wq), S gathered.  g layout [Cd][KT*KH*KW][Cs], tap (a,b,c) -> wk0+(a,b,c),
  * accumulated with fp32 atomics (g must be initialised).  Conv3d wgrad: D=dY, S=X;
  * ConvTranspose wgrad: D=X, S=dOut.  (replaces ATen convolution_backward's weight branch.) */
 typedef struct pc_wgrad_desc {
@@ -82,6 +82,8 @@ typedef struct pc_wgrad_desc {
     int32_t Tq, Hq, Wq, Cd, ldd;
     int32_t Ts, Hs, Ws, Cs, lds;
     int32_t istr[3], ntap[3], ioff0[3], istep[3];
+    int32_t wk0[3];                 /* first weight tap per dim (taps that only ever see padding are trimmed by the host) */
+    int32_t KT, KH, KW;             /* full weight tap extents: g is [Cd][KT*KH*KW][Cs] */
     int32_t splitk;                 /* 0 = choose */
 } pc_wgrad_desc;
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);

@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds")] + \
-               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep")] + [("splitk", i32)]
+               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk")]
 
 
 class PoolDesc(C.Structure):

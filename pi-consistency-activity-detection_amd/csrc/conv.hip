@@ -302,7 +302,8 @@ namespace {
 struct WgK {
     const float* D; const float* S; float* g;
     int N, Tq, Hq, Wq, Cd, ldd, Ts, Hs, Ws, Cs, lds;
-    int istr[3], ntap[3], ioff0[3], istep[3];
+    int istr[3], ntap[3], ioff0[3], istep[3], wk0[3];
+    int KH, KW, NtotFull;
     int P, Ntot, chunks_per_split, nchunks;
 };
 
@@ -333,6 +334,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     const int a_ = tap / tapHW, rem = tap - a_ * tapHW, b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
     const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
     const bool mval = (m0 + dcol) < p.Cd;
+    (void)rem;
 
     auto ptab_fill = [&](int c) {
         if (tid < BK) {
@@ -429,7 +431,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-                if (n < p.Ntot) atomicAdd(p.g + (size_t)m * p.Ntot + n, acc[i][j][r]);
+                if (n < p.Ntot) {
+                    // trimmed column (tap_local, cs) -> column of the full [KT*KH*KW][Cs] layout
+                    const int tl = n / p.Cs, cc = n - tl * p.Cs;
+                    const int ta = tl / tapHW, tr = tl - ta * tapHW, tb = tr / p.ntap[2], tc = tr - tb * p.ntap[2];
+                    const int full = ((p.wk0[0] + ta) * p.KH + p.wk0[1] + tb) * p.KW + p.wk0[2] + tc;
+                    atomicAdd(p.g + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc, acc[i][j][r]);
+                }
             }
         }
 }
@@ -446,7 +454,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.D = D; k.S = S; k.g = g;
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
     k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
-    for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; }
+    for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; }
+    PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
+    k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad: position count out of range");
     k.P = (int)P;

@@ -62,7 +62,50 @@ def wgrad(N, dense_thw, Cd, ldd, gath_thw, Cs, lds_, k, stride, pad_front, split
     """g[cd][k][cs] += sum_{n,q} D[n,q,cd] * S[n, q*s - pf + k, cs]."""
     return dict(N=N, Tq=dense_thw[0], Hq=dense_thw[1], Wq=dense_thw[2], Cd=Cd, ldd=ldd,
                 Ts=gath_thw[0], Hs=gath_thw[1], Ws=gath_thw[2], Cs=Cs, lds=lds_,
-                istr=_t3(stride), ntap=_t3(k), ioff0=[-int(p) for p in pad_front], istep=[1, 1, 1], splitk=splitk)
+                istr=_t3(stride), ntap=_t3(k), ioff0=[-int(p) for p in pad_front], istep=[1, 1, 1],
+                wk0=[0, 0, 0], KT=k[0], KH=k[1], KW=k[2], splitk=splitk)
+
+
+def _valid_tap_range(Q, istr, ioff0, istep, ntap, I):
+    """Taps a in [0, ntap) for which SOME lattice point q in [0,Q) reads inside [0,I):  contiguous [lo, hi]."""
+    ok = []
+    for a in range(ntap):
+        base = ioff0 + a * istep
+        lo_pos, hi_pos = base, (Q - 1) * istr + base            # istr >= 0
+        ok.append(hi_pos >= 0 and lo_pos < I)
+    if not any(ok):
+        return 0, 0            # keep one (all-padding) tap so the kernel still writes zeros
+    lo = ok.index(True)
+    hi = len(ok) - 1 - ok[::-1].index(True)
+    return lo, hi
+
+
+def trim_conv(d):
+    """Drop taps that can only ever gather zero padding (e.g. the two outer temporal taps of every 3x3x3 conv of
+    Mixed_4b..4f, whose input has T = 1).  Exact: the result is unchanged, the K loop shrinks."""
+    d = dict(d)
+    I = (d["Ti"], d["Hi"], d["Wi"]); Q = (d["Tq"], d["Hq"], d["Wq"])
+    nt, io, wk = list(d["ntap"]), list(d["ioff0"]), list(d["wk0"])
+    for i in range(3):
+        lo, hi = _valid_tap_range(Q[i], d["istr"][i], d["ioff0"][i], d["istep"][i], d["ntap"][i], I[i])
+        nt[i] = hi - lo + 1
+        io[i] = d["ioff0"][i] + lo * d["istep"][i]
+        wk[i] = d["wk0"][i] + lo * d["wkstep"][i]
+    d.update(ntap=nt, ioff0=io, wk0=wk)
+    return d
+
+
+def trim_wgrad(d):
+    d = dict(d)
+    I = (d["Ts"], d["Hs"], d["Ws"]); Q = (d["Tq"], d["Hq"], d["Wq"])
+    nt, io, wk = list(d["ntap"]), list(d["ioff0"]), list(d["wk0"])
+    for i in range(3):
+        lo, hi = _valid_tap_range(Q[i], d["istr"][i], d["ioff0"][i], d["istep"][i], d["ntap"][i], I[i])
+        nt[i] = hi - lo + 1
+        io[i] = d["ioff0"][i] + lo * d["istep"][i]
+        wk[i] = d["wk0"][i] + lo
+    d.update(ntap=nt, ioff0=io, wk0=wk)
+    return d
 
 
 def pool(N, in_thw, C, ldi, out_thw, ldo, k, s, padf):
@@ -74,7 +117,7 @@ CONV_FIELDS = ["N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho",
                "ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep", "KT", "KH", "KW", "ldw",
                "act", "flags", "act_c0", "groups"]
 WGRAD_FIELDS = ["N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds", "istr", "ntap", "ioff0",
-                "istep", "splitk"]
+                "istep", "wk0", "KT", "KH", "KW", "splitk"]
 POOL_FIELDS = ["N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo", "k", "s", "padf"]
 
 

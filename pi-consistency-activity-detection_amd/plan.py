@@ -78,6 +78,7 @@ class Plan:
         self.nrunning = o
         self.kg_ranges = []       # (ref, nfloats) of kernel-layout grad buffers to zero each step
         self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
+        self.alg_flops = {}       # list name -> algorithmic conv FLOPs (all taps, as the reference's convs count them)
 
     # ------------------------------------------------------------------ memory
     def alloc(self, nfloats, name=""):
@@ -161,6 +162,9 @@ class Plan:
         self.kw[name] = w
         return w
 
+    def alg_dgrad(self, fwd_flops):
+        self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + fwd_flops
+
     def flush_grad(self, w):
         """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
         wgrad so a gradient bucket is final (all-reduce can start) as early as possible."""
@@ -173,8 +177,12 @@ class Plan:
             self.final_at[nm] = len(self.lists["bwd"])
 
     # ------------------------------------------------------------------ layers
-    def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None):
-        self.emit(capi.OP_CONV, i=D.flatten(d, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+    def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None):
+        """alg: algorithmic FLOPs to book for this launch (default: the descriptor's own 2*M*N*K with all taps).
+        Dgrad launches book the layer's FORWARD FLOPs once (alg_dgrad) and pass alg=0, so gather-form overheads
+        (padding taps, the 28x28 gather of the 20x20 PrimaryCaps dgrad) never inflate the roofline numerator."""
+        self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + (_conv_flops(d) if alg is None else alg)
+        self.emit(capi.OP_CONV, i=D.flatten(D.trim_conv(d), D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
 
     def unit3d(self, pre, x, cout, k, stride, out=None, need_dx=True):
         """Unit3D (pytorch_i3d.py:89-120): SAME conv (no bias) -> BN(train) -> ReLU."""
@@ -186,6 +194,7 @@ class Plan:
         y = out if out is not None else self.tensor(x.N, othw, cout, pre + ".y")
         stat = self.alloc(self.groups * 4 * cout)
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
+        F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw))
         if self.training:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART, groups=self.groups)
             nrows = _bnpart_rows(d)
@@ -209,14 +218,15 @@ class Plan:
             ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
             self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
                       p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf), D.WGRAD_FIELDS),
+            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf)), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
             self.flush_grad(w)
             self.mark_final(pre + ".bn.weight", pre + ".bn.bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
+                self.alg_dgrad(F_fwd)
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
-                    self.conv_op(dd, dz.ref, w["tr"], dx.ref)
+                    self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
         self.tape.append(bwd)
         return y
 
@@ -262,6 +272,7 @@ class Plan:
         """Decoder skip convs conv28/conv56/conv112 (capsules_ucf101.py:380-384,490,497,501)."""
         w = self.prep_conv_weight([name + ".weight"], [cout], x.C, k, need_dx)
         othw = self.conv_bias_act(name + ".weight", x, cout, k, pad, act, out, bias_ref=self.P(name + ".bias"))
+        F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
 
         def bwd():
             dy = self.grad_of(out)
@@ -269,14 +280,15 @@ class Plan:
             ws = self.alloc(_act_bwd_ws(out.rows, cout))
             self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad), D.WGRAD_FIELDS),
+            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), D.WGRAD_FIELDS),
                       p=[dz.ref, x.ref, w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
+                self.alg_dgrad(F_fwd)
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
-                    self.conv_op(dd, dz.ref, w["tr"], dx.ref)
+                    self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
         self.tape.append(bwd)
 
     def convT_layer(self, name, x, cout, k, stride, pad, opad, act, out, cscale=None):
@@ -286,7 +298,9 @@ class Plan:
         assert othw == tuple(out.thw), (name, othw, out.thw)
         w = self.prep_convT_weight(name + ".weight", Ci, cout, k)
         flags = capi.F_BIAS | (capi.F_CSCALE if cscale is not None else 0)
+        F_fwd = 0
         for dd in D.transposed_classes(x.N, x.thw, Ci, x.ld, othw, cout, out.ld, k, stride, pad, act=act, flags=flags):
+            F_fwd += _conv_flops(dd)
             self.conv_op(dd, x.ref, w["fwd"], out.ref, bias=self.P(name + ".bias"), cscale=cscale)
 
         def bwd():
@@ -304,13 +318,13 @@ class Plan:
             else:
                 self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad), D.WGRAD_FIELDS),
+            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), D.WGRAD_FIELDS),
                       p=[x.ref, dz.ref, w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
             dd = D.conv_fwd(x.N, othw, cout, dz.ld, Ci, dx.ld, k, stride, pad, x.thw, flags=capi.F_ACCUM if acc else 0, ldw=cout)
-            self.conv_op(dd, dz.ref, w["tr"], dx.ref)
+            self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=F_fwd)
         self.tape.append(bwd)
 
     # ------------------------------------------------------------------ whole model
@@ -403,14 +417,15 @@ class Plan:
                       p=[da_sl.ref, a_sl.ref, da_sl.ref, self.G("primary_caps.a.bias"), ws2])
             self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_NONE, npose, dcaps.ld, self.acc], l=[caps_in.rows],
                       p=[dcaps.ref, caps_in.ref, None, self.G("primary_caps.pose.bias"), ws2])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
+            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
                       p=[dcaps.ref, xd.ref, wpc["kg"]])
             self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
             dx, acc = self.grad_for_write(xd)
+            self.alg_dgrad(2 * caps_in.rows * caps_in.C * xd.C * KP * KP)
             for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
                                            flags=capi.F_ACCUM if acc else 0, ldw=caps_in.C):
-                self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref)
+                self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
         self.tape.append(bwd_caps)
         # decoder (capsules_ucf101.py:486-510)
         cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")
@@ -450,7 +465,7 @@ class Plan:
             if not self.acc:
                 self.emit(capi.OP_FILL, p=[self.G("smooth.bias")], l=[1], f=[0.0])
             self.emit(capi.OP_AXPY, p=[self.G("smooth.bias"), off(tmp32, 13)], l=[1], f=[1.0])   # centre tap: sum of dout
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.wgrad(N, u4.thw, 32, 32, u4.thw, 128, u4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0)), D.WGRAD_FIELDS),
+            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, u4.thw, 32, 32, u4.thw, 128, u4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
                       p=[dproj.ref, u4.ref, kgproj])
             self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, self.acc], l=[0, 0], p=[kgproj, self.G("smooth.weight")])
             self.mark_final("smooth.weight", "smooth.bias")
@@ -539,6 +554,8 @@ class Plan:
     def flops(self, only_kind=None):
         """Algorithmic FLOPs (2*M*N*K, real channel counts) of the conv / wgrad ops per list."""
         tot = {}
+        if only_kind == capi.OP_CONV:
+            return {name: self.alg_flops.get(name, 0) for name in self.lists}
         for name, lst in self.lists.items():
             s = 0
             for kind, i, f, p, l in lst:
@@ -554,6 +571,11 @@ class Plan:
                     s += 2 * N * Tq * Hq * Wq * (27 if (Cd == 32 and Cs == 128 and nt == 1) else Cd) * (3 if Cs == 4 else Cs) * nt
             tot[name] = s
         return tot
+
+
+def _conv_flops(d):
+    return 2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * (27 if (d["Co"] == 32 and d["Ci"] == 128) else d["Co"]) * \
+        (3 if d["Ci"] == 4 else (27 if (d["Ci"] == 32 and d["Co"] == 128) else d["Ci"])) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
 
 
 # --- workspace sizing mirrors of the C side (kept in sync by tests/test_plan_cpu.py on CPU)

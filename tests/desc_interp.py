@@ -44,18 +44,17 @@ def run_conv(d, x, w, bias=None, cscale=None, out=None):
 def run_wgrad(d, D, S):
     """D [N,Tq,Hq,Wq,ldd], S [N,Ts,Hs,Ws,lds] -> g [Cd, ntaps, Cs]."""
     nt = d["ntap"]
-    g = np.zeros((d["Cd"], nt[0] * nt[1] * nt[2], d["Cs"]))
+    g = np.zeros((d["Cd"], d["KT"] * d["KH"] * d["KW"], d["Cs"]))
     for tq in range(d["Tq"]):
         for hq in range(d["Hq"]):
             for wq in range(d["Wq"]):
                 q = (tq, hq, wq)
-                tap = 0
                 for a in range(nt[0]):
                     for b in range(nt[1]):
                         for c in range(nt[2]):
                             abc = (a, b, c)
+                            tap = ((d["wk0"][0] + a) * d["KH"] + d["wk0"][1] + b) * d["KW"] + d["wk0"][2] + c
                             pos = [q[i] * d["istr"][i] + d["ioff0"][i] + abc[i] * d["istep"][i] for i in range(3)]
                             if 0 <= pos[0] < d["Ts"] and 0 <= pos[1] < d["Hs"] and 0 <= pos[2] < d["Ws"]:
                                 g[:, tap, :] += D[:, tq, hq, wq, :d["Cd"]].T @ S[:, pos[0], pos[1], pos[2], :d["Cs"]]
-                            tap += 1
     return g

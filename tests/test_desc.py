@@ -73,3 +73,31 @@ def test_conv_transpose_fwd_dgrad_wgrad(Ci, Co, k, s, pd, op, thw):
     np.testing.assert_allclose(run_conv(d, cl(dy), w_iko), cl(x.grad), atol=1e-10)
     gw = run_wgrad(desc.wgrad(2, thw, Ci, Ci, othw, Co, Co, k, s, pd), cl(x), cl(dy))    # [I][taps][O]
     np.testing.assert_allclose(gw, w.grad.reshape(Ci, Co, taps).permute(0, 2, 1).numpy(), atol=1e-9)
+
+
+@pytest.mark.parametrize("thw,k,s", [((1, 5, 6), (3, 3, 3), (1, 1, 1)), ((2, 4, 4), (3, 3, 3), (2, 1, 1)), ((1, 1, 7), (3, 3, 3), (1, 1, 1))])
+def test_tap_trimming_is_exact(thw, k, s):
+    """Taps that can only read zero padding are dropped from the descriptors (T = 1 inputs of Mixed_4b..4f):
+    same result, shorter K loop; wgrad leaves the dropped taps' gradient at zero."""
+    g = torch.Generator().manual_seed(3)
+    Ci, Co = 4, 5
+    x = torch.randn(2, Ci, *thw, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, *k, generator=g, dtype=torch.float64, requires_grad=True)
+    pads = [spec.same_pad(thw[i], k[i], s[i]) for i in range(3)]
+    y = F.conv3d(F.pad(x, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1])), w, None, s)
+    dy = torch.randn(y.shape, generator=g, dtype=torch.float64)
+    y.backward(dy)
+    othw = tuple(y.shape[2:]); pf = [p[0] for p in pads]; taps = k[0] * k[1] * k[2]
+    w_oki = w.detach().reshape(Co, Ci, taps).permute(0, 2, 1).contiguous().numpy()
+    w_iko = w.detach().reshape(Co, Ci, taps).permute(1, 2, 0).contiguous().numpy()
+    d0 = desc.conv_fwd(2, thw, Ci, Ci, Co, Co, k, s, pf, othw)
+    d = desc.trim_conv(d0)
+    assert np.prod(d["ntap"]) < np.prod(d0["ntap"])
+    np.testing.assert_allclose(run_conv(d, cl(x), w_oki), cl(y), atol=1e-10)
+    dx = np.zeros((2,) + thw + (Ci,))
+    for dd in desc.transposed_classes(2, othw, Co, Co, thw, Ci, Ci, k, s, pf):
+        run_conv(desc.trim_conv(dd), cl(dy), w_iko, out=dx)
+    np.testing.assert_allclose(dx, cl(x.grad), atol=1e-10)
+    wd = desc.trim_wgrad(desc.wgrad(2, othw, Co, Co, thw, Ci, Ci, k, s, pf))
+    assert np.prod(wd["ntap"]) < taps
+    np.testing.assert_allclose(run_wgrad(wd, cl(dy), cl(x)), w.grad.reshape(Co, Ci, taps).permute(0, 2, 1).numpy(), atol=1e-9)
