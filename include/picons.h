@@ -63,6 +63,8 @@ typedef struct pc_conv_desc {
     int32_t wk0[3], wkstep[3];
     int32_t KT, KH, KW, ldw;
     int32_t act, flags;
+    int32_t wgstride, bgstride;     /* per-group weight / bias offsets (floats): group g uses w + g*wgstride, bias + g*bgstride
+                                       (per-sample collapsed decoder-tail weights); 0 = shared */
     int32_t act_c0;                 /* activation applies to output channels >= act_c0 (merged pose|activation conv) */
     int32_t groups;                 /* >=1: rows are tiled per batch group (N/groups samples each) so BatchNorm
                                        partials never straddle the two forward passes of one step */
@@ -177,6 +179,20 @@ int pc_class_mask_bwd(const float* dmasked, const float* dactor_pred, const floa
 int pc_tapsum_fwd(const float* proj, int N, int T, int H, int W, const float* bias, float* out, pc_stream s);
 int pc_tapsum_bwd(const float* dout, int N, int T, int H, int W, float* dproj, pc_stream s);
 
+/* Collapsed decoder tail: upsample4 -> Dropout3d -> smooth (capsules_ucf101.py:504-509) are three linear ops, so
+ * they run as ONE 128->27 transposed conv with per-sample combined weights
+ *   Wc[n][ci][tap][j] = sum_co W4[ci][co][tap] * cs[n][co] * Wp[co][j],  bc[n][j] = sum_co b4[co]*cs[n][co]*Wp[co][j]
+ * followed by pc_tapsum_fwd.  W4 = upsample4.weight (Ci,Co,taps), Wp = smooth.weight (Co,J=27), cs = Dropout3d scale
+ * (N,Co) or NULL.  Wt [N][Ci][taps][32] is the dgrad layout, Wf [N][32][taps][Ci] the forward layout, bc [N][32]. */
+int pc_tail_combine(const float* W4, const float* b4, const float* cs, const float* Wp, int N, int Ci,
+                    int Co, int taps, int J, float* Wt, float* Wf, float* bc, pc_stream s);
+/* sums[n][32] = per-sample column sums of dproj [N][rows_per_n][32] */
+int pc_tail_colsum(const float* dproj, int N, int64_t rows_per_n, float* sums, pc_stream s);
+/* G [N][Ci][taps][32] = per-sample dWc (from pc_conv_wgrad) -> upsample4.weight/bias and smooth.weight/bias grads (+)= */
+int pc_tail_grads(const float* G, const float* sums, const float* W4, const float* b4, const float* cs,
+                  const float* Wp, int N, int Ci, int Co, int taps, int J, int center, float* dW4,
+                  float* db4, float* dWp, float* dbp, int accum, pc_stream s);
+
 /* ------------------------------------------------------------------------------------------
  * Fused loss: everything main_ucf101.py:89-148 computes from (output, flip_op, loc_msk):
  * BCEWithLogits + Dice on labeled rows, equal-weight L2, bv (utils/helpers.py:8-67) and gv
@@ -224,6 +240,7 @@ enum {
     PC_OP_POOL_FWD, PC_OP_POOL_BWD, PC_OP_CHSCALE, PC_OP_ACT_BWD, PC_OP_TO_NDHWC, PC_OP_TO_NCDHW,
     PC_OP_TRANSPOSE, PC_OP_FILL, PC_OP_AXPY, PC_OP_EM_FWD, PC_OP_EM_BWD, PC_OP_CMASK_FWD,
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
+    PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS,
     PC_OP__COUNT
 };
 int pc_run_ops(const pc_op* ops, int n, pc_stream s);

@@ -15,7 +15,7 @@ i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 class ConvDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho", "Wo", "Co", "ldo")] + \
                [(n, i32 * 3) for n in ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")] + \
-               [(n, i32) for n in ("KT", "KH", "KW", "ldw", "act", "flags", "act_c0", "groups")]
+               [(n, i32) for n in ("KT", "KH", "KW", "ldw", "act", "flags", "wgstride", "bgstride", "act_c0", "groups")]
 
 
 class WgradDesc(C.Structure):
@@ -39,7 +39,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
 
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
- OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM) = range(1, 25)
+ OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS) = range(1, 28)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART = 1, 2, 4, 8
@@ -78,6 +78,9 @@ _SIGS = {
     "pc_grad_mask": (i32, [vp, i32, i32, i32, i32, f32, f32, vp, vp, vp]),
     "pc_spread_loss": (i32, [vp, vp, vp, i32, i32, f32, f32, vp, vp, vp]),
     "pc_adam_step": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, i32, f32, vp]),
+    "pc_tail_combine": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
+    "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
+    "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),
 }
@@ -96,7 +99,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        assert C.sizeof(ConvDesc) == 46 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
+        assert C.sizeof(ConvDesc) == 48 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
         _lib = L
     return _lib
 

@@ -93,6 +93,14 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_spread_loss(P(const float*, 0), P(const float*, 1), P(const int32_t*, 2), op.i[0], op.i[1], op.f[0], op.f[1], P(float*, 3), P(float*, 4), s);
         case PC_OP_ADAM:
             return pc_adam_step(P(float*, 0), P(const float*, 1), P(float*, 2), P(float*, 3), op.l[0], op.f[0], op.f[1], op.f[2], op.f[3], op.i[0], op.f[4], s);
+        case PC_OP_TAIL_COMBINE:
+            return pc_tail_combine(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), op.i[0], op.i[1], op.i[2], op.i[3],
+                                   op.i[4], P(float*, 4), P(float*, 5), P(float*, 6), s);
+        case PC_OP_TAIL_COLSUM:
+            return pc_tail_colsum(P(const float*, 0), op.i[0], op.l[0], P(float*, 1), s);
+        case PC_OP_TAIL_GRADS:
+            return pc_tail_grads(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), P(const float*, 4), P(const float*, 5),
+                                 op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), op.i[6], s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

@@ -14,7 +14,7 @@ struct ConvK {
     int ostr[3], ooff[3], istr[3], ntap[3], ioff0[3], istep[3], wk0[3], wkstep[3];
     int KH, KW, wtaps, ldw;
     int K, M, Mg, groups, mtiles_g, ntiles;
-    int act, flags, act_c0;
+    int act, flags, act_c0, wgstride, bgstride;
 };
 
 constexpr int BK = 32;       // K chunk (floats)
@@ -37,6 +37,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
     const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
     const int n0 = nt * BN;
+    const float* wbase = p.w + (size_t)g * p.wgstride;          // per-group weights (0 stride = shared)
+    const float* bbase = p.bias + (size_t)g * p.bgstride;
 
     for (int r = tid; r < BM; r += 256) {
         const int lm = lt * BM + r;
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
         for (int j = 0; j < BR; ++j) {
             const int co = n0 + lrow + 32 * j;
             const bool v = kval && co < p.Co;
-            const float* src = v ? p.w + ((size_t)co * p.wtaps + wtap) * p.ldw + ci : p.w;
+            const float* src = v ? wbase + ((size_t)co * p.wtaps + wtap) * p.ldw + ci : wbase;
             breg[j] = *(const f32x4*)src;
             m |= (v ? 1u : 0u) << (AR + j);
         }
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
                 const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
                 if (col >= p.Co) continue;
                 float v = acc[i][j][r];
-                if (has_bias) v += p.bias[col];
+                if (has_bias) v += bbase[col];
                 if (col >= p.act_c0) {
                     if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (p.act == PC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
@@ -281,7 +283,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     const int64_t M = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
-    k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0;
+    k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
     const TileCfg c = choose_tile(k.Mg, groups, d->Co);
     if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128, 2, 2>(k, s);
     if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64, 2, 2>(k, s);

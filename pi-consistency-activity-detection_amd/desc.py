@@ -21,7 +21,7 @@ def conv_fwd(N, in_thw, Ci, ldi, Co, ldo, k, stride, pad_front, out_thw, act=0, 
                 Tq=out_thw[0], Hq=out_thw[1], Wq=out_thw[2], To=out_thw[0], Ho=out_thw[1], Wo=out_thw[2],
                 Co=Co, ldo=ldo, ostr=[1, 1, 1], ooff=[0, 0, 0], istr=_t3(stride), ntap=_t3(k),
                 ioff0=[-int(p) for p in pad_front], istep=[1, 1, 1], wk0=[0, 0, 0], wkstep=[1, 1, 1],
-                KT=k[0], KH=k[1], KW=k[2], ldw=ldw or Ci, act=act, flags=flags, act_c0=0, groups=groups)
+                KT=k[0], KH=k[1], KW=k[2], ldw=ldw or Ci, act=act, flags=flags, wgstride=0, bgstride=0, act_c0=0, groups=groups)
 
 
 def transposed_classes(N, small_thw, Cs, lds_, big_thw, Cb, ldb, k, stride, pad_front, act=0, flags=0, groups=1, ldw=None):
@@ -38,7 +38,7 @@ def transposed_classes(N, small_thw, Cs, lds_, big_thw, Cb, ldb, k, stride, pad_
                 d = dict(N=N, Ti=small_thw[0], Hi=small_thw[1], Wi=small_thw[2], Ci=Cs, ldi=lds_,
                          To=big_thw[0], Ho=big_thw[1], Wo=big_thw[2], Co=Cb, ldo=ldb, ostr=s, ooff=p,
                          istr=[1, 1, 1], istep=[-1, -1, -1], KT=k[0], KH=k[1], KW=k[2], ldw=ldw or Cs,
-                         act=act, flags=flags, act_c0=0, groups=groups)
+                         act=act, flags=flags, wgstride=0, bgstride=0, act_c0=0, groups=groups)
                 q, ntap, ioff0, wk0 = [], [], [], []
                 empty = False
                 for dim in range(3):
@@ -115,7 +115,7 @@ def pool(N, in_thw, C, ldi, out_thw, ldo, k, s, padf):
 
 CONV_FIELDS = ["N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho", "Wo", "Co", "ldo",
                "ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep", "KT", "KH", "KW", "ldw",
-               "act", "flags", "act_c0", "groups"]
+               "act", "flags", "wgstride", "bgstride", "act_c0", "groups"]
 WGRAD_FIELDS = ["N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds", "istr", "ntap", "ioff0",
                 "istep", "wk0", "KT", "KH", "KW", "splitk"]
 POOL_FIELDS = ["N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo", "k", "s", "padf"]

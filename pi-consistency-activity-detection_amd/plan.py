@@ -437,40 +437,48 @@ class Plan:
         cat112 = self.tensor(N, (4, 4 * s28, 4 * s28), 128, "cat112")
         self.convT_layer("upsample3", cat56, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), capi.ACT_RELU, cat112.slice(0, 64))
         self.conv_layer("conv112", out112, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat112.slice(64, 64))
-        u4 = self.tensor(N, (8, 8 * s28, 8 * s28), 128, "u4")
-        self.convT_layer("upsample4", cat112, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), capi.ACT_NONE, u4,
-                         cscale=self.in_drop128 if self.training else None)
-        # smooth = 27-tap projection (1x1x1 conv 128->32) + tap sum (capsules_ucf101.py:373,509)
-        wproj = self.alloc(32 * 128)
-        wprojT = self.alloc(128 * 32)
-        kgproj = self.alloc(32 * 128)
-        self.kg_ranges.append((kgproj, 32 * 128))
-        self.emit(capi.OP_FILL, p=[wproj], l=[32 * 128], f=[0.0], lst="prep")
-        self.emit(capi.OP_FILL, p=[wprojT], l=[128 * 32], f=[0.0], lst="prep")
-        # smooth.weight (128,1,3,3,3) = [ch][27]  -> wproj [27 of 32][128]; wprojT [128][27 of 32]
-        self.emit(capi.OP_TRANSPOSE, i=[1, 128, 27, 27, 128, 0], l=[0, 0], p=[self.P("smooth.weight"), wproj], lst="prep")
-        self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 32, 0], l=[0, 0], p=[wproj, wprojT], lst="prep")
-        proj = self.tensor(N, u4.thw, 32, "proj")
-        self.conv_op(D.conv_fwd(N, u4.thw, 128, u4.ld, 32, 32, (1, 1, 1), (1, 1, 1), (0, 0, 0), u4.thw), u4.ref, wproj, proj.ref)
-        out = self.tensor(N, u4.thw, 1, "out")
-        self.emit(capi.OP_TAPSUM_FWD, i=[N, u4.thw[0], u4.thw[1], u4.thw[2]], p=[proj.ref, self.P("smooth.bias"), out.ref])
+        # upsample4 -> Dropout3d -> smooth are linear: collapsed into ONE 128->27 transposed conv with per-sample combined
+        # weights + the 27-tap shifted sum (csrc/tail.hip; capsules_ucf101.py:504-509).  u4 (205 MB/clip) never exists.
+        othw = (8, 8 * s28, 8 * s28)
+        k3, s2, p1 = (3, 3, 3), (2, 2, 2), (1, 1, 1)
+        J = 27
+        wt = self.alloc(N * 128 * 27 * 32)          # [n][ci][tap][32]  (dgrad layout)
+        wf = self.alloc(N * 32 * 27 * 128)          # [n][32][tap][ci]  (forward layout)
+        bc = self.alloc(N * 32)
+        cs_ref = self.in_drop128 if self.training else None
+        W4, b4, Wp = self.P("upsample4.weight"), self.P("upsample4.bias"), self.P("smooth.weight")
+        self.emit(capi.OP_TAIL_COMBINE, i=[N, 128, 128, 27, J], p=[W4, b4, cs_ref, Wp, wt, wf, bc])
+        proj = self.tensor(N, othw, 32, "proj")
+        F_tail = 0
+        for dd in D.transposed_classes(N, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1, flags=capi.F_BIAS, groups=N):
+            dd["wgstride"] = 32 * 27 * 128
+            dd["bgstride"] = 32
+            F_tail += _conv_flops(dd)
+            self.conv_op(dd, cat112.ref, wf, proj.ref, bias=bc)
+        out = self.tensor(N, othw, 1, "out")
+        self.emit(capi.OP_TAPSUM_FWD, i=[N, othw[0], othw[1], othw[2]], p=[proj.ref, self.P("smooth.bias"), out.ref])
         self.out = out
 
         def bwd_smooth():
-            dproj = self.tensor(N, u4.thw, 32, "d_proj")
-            self.emit(capi.OP_TAPSUM_BWD, i=[N, u4.thw[0], u4.thw[1], u4.thw[2]], p=[self.dout, dproj.ref])
-            tmp32 = self.alloc(32)
-            ws = self.alloc(_act_bwd_ws(dproj.rows, 32))
-            self.emit(capi.OP_ACT_BWD, i=[32, 32, capi.ACT_NONE, 32, 32, 0], l=[dproj.rows], p=[dproj.ref, dproj.ref, None, tmp32, ws])
-            if not self.acc:
-                self.emit(capi.OP_FILL, p=[self.G("smooth.bias")], l=[1], f=[0.0])
-            self.emit(capi.OP_AXPY, p=[self.G("smooth.bias"), off(tmp32, 13)], l=[1], f=[1.0])   # centre tap: sum of dout
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, u4.thw, 32, 32, u4.thw, 128, u4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
-                      p=[dproj.ref, u4.ref, kgproj])
-            self.emit(capi.OP_TRANSPOSE, i=[1, 27, 128, 128, 27, self.acc], l=[0, 0], p=[kgproj, self.G("smooth.weight")])
-            self.mark_final("smooth.weight", "smooth.bias")
-            du4, acc = self.grad_for_write(u4)
-            self.conv_op(D.conv_fwd(N, u4.thw, 32, 32, 128, du4.ld, (1, 1, 1), (1, 1, 1), (0, 0, 0), u4.thw, ldw=32), dproj.ref, wprojT, du4.ref)
+            dproj = self.tensor(N, othw, 32, "d_proj")
+            self.emit(capi.OP_TAPSUM_BWD, i=[N, othw[0], othw[1], othw[2]], p=[self.dout, dproj.ref])
+            sums = self.alloc(N * 32)
+            per_n = othw[0] * othw[1] * othw[2]
+            self.emit(capi.OP_TAIL_COLSUM, i=[N], l=[per_n], p=[dproj.ref, sums])
+            Gc = self.alloc(N * 128 * 27 * 32)
+            self.emit(capi.OP_FILL, p=[Gc], l=[N * 128 * 27 * 32], f=[0.0])
+            xin_per = cat112.thw[0] * cat112.thw[1] * cat112.thw[2] * cat112.ld
+            for n in range(N):        # per-sample dWc[n][ci][tap][j] = sum_i x[n,i,ci] * dproj[n, 2i-1+k, j]
+                wd = D.trim_wgrad(D.wgrad(1, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1))
+                self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS),
+                          p=[off(cat112.ref, n * xin_per), off(dproj.ref, n * per_n * 32), off(Gc, n * 128 * 27 * 32)])
+            self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
+                      p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
+            self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
+            dx, acc = self.grad_for_write(cat112)
+            dd = D.conv_fwd(N, othw, 32, 32, 128, dx.ld, k3, s2, p1, cat112.thw, flags=capi.F_ACCUM if acc else 0, groups=N, ldw=32)
+            dd["wgstride"] = 128 * 27 * 32
+            self.conv_op(dd, dproj.ref, wt, dx.ref, alg=F_tail)
         self.tape.append(bwd_smooth)
         return out
 

@@ -32,12 +32,12 @@ def test_header_symbols_exported(built):
 
 def test_struct_layouts_match_header(built):
     import ctypes as C
-    assert C.sizeof(capi.ConvDesc) == 46 * 4
+    assert C.sizeof(capi.ConvDesc) == 48 * 4
     assert C.sizeof(capi.WgradDesc) == 30 * 4
     assert C.sizeof(capi.PoolDesc) == 19 * 4
     assert C.sizeof(capi.LossDesc) == 16 * 4
     assert capi.OP_DTYPE.itemsize == 360 and capi.OP_DTYPE.fields["p"][1] == 232
-    assert len(desc.flatten(desc.conv_fwd(1, (1, 2, 2), 4, 4, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)), desc.CONV_FIELDS)) == 46
+    assert len(desc.flatten(desc.conv_fwd(1, (1, 2, 2), 4, 4, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)), desc.CONV_FIELDS)) == 48
 
 
 def test_no_cpu_fallback(built):

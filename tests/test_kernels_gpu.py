@@ -421,3 +421,61 @@ def test_errors_are_loud():
     with pytest.raises(RuntimeError):
         ops.conv_fwd(desc.conv_fwd(1, (1, 4, 4), 4, 4, 8, 8, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 4, 4)),
                      torch.zeros(1, 1, 4, 4, 4), torch.zeros(8, 1, 4), torch.zeros(1, 1, 4, 4, 8))   # CPU tensors
+
+
+def test_collapsed_tail_kernels_vs_torch():
+    """pc_tail_combine / pc_tail_colsum / pc_tail_grads against einsum, and the algebraic identity
+    smooth(drop(upsample4(x))) == tapsum(convT(x, Wc[n]) + bc[n]) on a small case (capsules_ucf101.py:504-509)."""
+    import ctypes as C
+    g = torch.Generator().manual_seed(13)
+    N, Ci, Co, taps, J = 2, 8, 12, 27, 27
+    W4 = (torch.randn(Ci, Co, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b4 = torch.randn(Co, generator=g).requires_grad_(True)
+    Wp = (torch.randn(Co, 1, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    bp = torch.randn(1, generator=g).requires_grad_(True)
+    cs = (torch.rand(N, Co, generator=g) < 0.5).float() * 2
+    x = torch.randn(N, Ci, 2, 3, 4, generator=g)
+    u = F.conv_transpose3d(x, W4, b4, stride=2, padding=1, output_padding=1) * cs.view(N, Co, 1, 1, 1)
+    out = F.conv_transpose3d(u, Wp, bp, padding=1)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    dev = lambda t: t.detach().contiguous().to(DEV)
+    Wt = torch.empty(N, Ci, taps, 32, device=DEV); Wf = torch.empty(N, 32, taps, Ci, device=DEV); bc = torch.empty(N, 32, device=DEV)
+    capi.call("pc_tail_combine", ops.ptr(dev(W4)), ops.ptr(dev(b4)), ops.ptr(dev(cs)), ops.ptr(dev(Wp)), N, Ci, Co, taps, J,
+              ops.ptr(Wt), ops.ptr(Wf), ops.ptr(bc), ops.stream())
+    Wc = torch.einsum("iot,no,oj->nitj", W4.detach().reshape(Ci, Co, taps), cs, Wp.detach().reshape(Co, J))
+    close(Wt[..., :27], Wc, what="Wt"); close(Wf[:, :27].permute(0, 3, 2, 1), Wc, what="Wf")
+    assert (Wt[..., 27:] == 0).all()
+    close(bc[:, :27], torch.einsum("o,no,oj->nj", b4.detach(), cs, Wp.detach().reshape(Co, J)), what="bc")
+    # forward identity through the conv kernel with per-sample weights + tap sum
+    othw = tuple(out.shape[2:])
+    proj = torch.zeros(N, *othw, 32, device=DEV)
+    Cp = 8
+    for dd in desc.transposed_classes(N, (2, 3, 4), Cp, Cp, othw, 32, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), flags=capi.F_BIAS, groups=N):
+        dd["wgstride"] = 32 * taps * Ci; dd["bgstride"] = 32
+        ops.conv_fwd(dd, cl(x), Wf, proj, bias=bc)
+    o = ops.tapsum_fwd(proj, dev(bp))
+    close(o.cpu(), out[:, 0], what="collapsed forward")
+    # backward pieces
+    dproj = ops.tapsum_bwd(dev(dout[:, 0]))
+    sums = torch.empty(N, 32, device=DEV)
+    per_n = int(np.prod(othw))
+    capi.call("pc_tail_colsum", ops.ptr(dproj), N, per_n, ops.ptr(sums), ops.stream())
+    close(sums, dproj.reshape(N, per_n, 32).sum(1), what="colsum")
+    G = torch.zeros(N, Ci, taps, 32, device=DEV)
+    xg = cl(x)
+    for n in range(N):
+        ops.conv_wgrad(desc.wgrad(1, (2, 3, 4), Ci, Ci, othw, 32, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), xg[n], dproj[n], G[n])
+    dW4 = torch.zeros(Ci, Co, taps, device=DEV); db4 = torch.zeros(Co, device=DEV); dWp = torch.zeros(Co, J, device=DEV); dbp = torch.zeros(1, device=DEV)
+    capi.call("pc_tail_grads", ops.ptr(G), ops.ptr(sums), ops.ptr(dev(W4)), ops.ptr(dev(b4)), ops.ptr(dev(cs)), ops.ptr(dev(Wp)), N, Ci, Co, taps, J, 13,
+              ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 0, ops.stream())
+    close(dW4.cpu(), W4.grad.reshape(Ci, Co, taps), what="dW4"); close(db4.cpu(), b4.grad, what="db4")
+    close(dWp.cpu(), Wp.grad.reshape(Co, J), what="dWp"); close(dbp.cpu(), bp.grad, what="dbp")
+    dx = torch.empty(N, 2, 3, 4, Ci, device=DEV)
+    dd = desc.conv_fwd(N, othw, 32, 32, Ci, Ci, (3, 3, 3), (2, 2, 2), (1, 1, 1), (2, 3, 4), groups=N, ldw=32)
+    dd["wgstride"] = Ci * taps * 32
+    ops.conv_fwd(dd, dproj, Wt, dx)
+    xr = x.clone().requires_grad_(True)
+    F.conv_transpose3d(F.conv_transpose3d(xr, W4.detach(), b4.detach(), stride=2, padding=1, output_padding=1) * cs.view(N, Co, 1, 1, 1),
+                       Wp.detach(), bp.detach(), padding=1).backward(dout)
+    close(uncl(dx), xr.grad, what="collapsed dgrad")
