@@ -4,6 +4,7 @@
 // parity classes and ConvTranspose dgrad; a second form computes weight gradients.
 // Replaces the ATen/cuDNN convolution call sites listed in SURVEY.md §2a (K1, K6, K9-K12).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -20,7 +21,7 @@ struct ConvK {
 constexpr int BK = 32;       // K chunk (floats)
 constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
 
-template <int BM, int BN, int WM, int WN, bool FAST>
+template <int BM, int BN, int WM, int WN, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
@@ -142,17 +143,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
     const int kof = (lane >> 5) * 4;
     for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (c + 1 < nchunks) gload(c + 1);
+        const int buf = (ABL >= 1) ? 0 : (c & 1);
+        if (ABL == 0 && c + 1 < nchunks) gload(c + 1);
         const float* a = As + buf * BM * LDK + arow * LDK + kof;
         const float* b = Bs + buf * BN * LDK + brow * LDK + kof;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f32x4 af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + i * 32 * LDK + ks * 8);
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + i * 32 * LDK + ((ABL >= 3) ? 0 : ks * 8));
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + j * 32 * LDK + ks * 8);
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + j * 32 * LDK + ((ABL >= 3) ? 0 : ks * 8));
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -161,8 +162,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < nchunks) lstore(buf ^ 1);
-        __syncthreads();
+        if (ABL == 0 && c + 1 < nchunks) lstore(buf ^ 1);
+        if (ABL <= 1) __syncthreads();
     }
 
     // ---- epilogue: C/D map row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31
@@ -227,8 +228,28 @@ int launch_conv2(const ConvK& k, hipStream_t s) {
     return PC_OK;
 }
 
+// PICONS_CONV_ABLATE=1|2|3 (diagnostic, tools/ablate_conv.py): 1 = no tile fetch / LDS store in the K loop,
+// 2 = also no barrier, 3 = also a fixed fragment address.  Results are WRONG in these modes; they only price phases.
+template <int BM, int BN, int WM, int WN, int ABL>
+int launch_ablate(const ConvK& k, hipStream_t s) {
+    const size_t lds = (size_t)(2 * (BM + BN) * LDK + BM * 5) * sizeof(float);
+    (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, true, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    ConvK p = k;
+    p.mtiles_g = cdiv(p.Mg, BM);
+    p.ntiles = cdiv(p.Co, BN);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, true, ABL>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
+    PC_CHECK_LAUNCH("conv_gemm_kernel(ablate)");
+    return PC_OK;
+}
+
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvK& k, hipStream_t s) {
+    static const int abl = getenv("PICONS_CONV_ABLATE") ? atoi(getenv("PICONS_CONV_ABLATE")) : 0;
+    if (abl && k.Ci % BK == 0 && BM == 128 && BN >= 64) {
+        if (abl == 1) return launch_ablate<BM, BN, WM, WN, 1>(k, s);
+        if (abl == 2) return launch_ablate<BM, BN, WM, WN, 2>(k, s);
+        return launch_ablate<BM, BN, WM, WN, 3>(k, s);
+    }
     return (k.Ci % BK == 0) ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
 }
 

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Diagnostic: price the phases of conv_gemm_kernel on representative layer shapes.
+Run one process per mode:  PICONS_CONV_ABLATE=<0|1|2|3> python tools/ablate_conv.py
+(0 = product kernel; 1-3 are wrong-result ablations, see csrc/conv.hip launch_conv)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import picons_amd  # noqa
+from picons_amd import desc, ops
+
+SHAPES = [  # name, N, thw, Ci, Co, k
+    ("conv112 3x3x3 64->64 @4x112x112", 16, (4, 112, 112), 64, 64, (3, 3, 3)),
+    ("1x1x1 128->128 @4x112x112", 16, (4, 112, 112), 128, 128, (1, 1, 1)),
+    ("3x3x3 128->128 @4x112x112", 16, (4, 112, 112), 128, 128, (3, 3, 3)),
+    ("primary caps 9x9 832->544 @28x28", 16, (1, 28, 28), 832, 544, (1, 9, 9)),
+    ("3x3 160->320 @28x28", 16, (1, 28, 28), 160, 320, (1, 3, 3)),
+]
+mode = os.environ.get("PICONS_CONV_ABLATE", "0")
+for name, N, thw, Ci, Co, k in SHAPES:
+    valid = name.startswith("primary")
+    pad = (0, 0, 0) if valid else tuple(x // 2 for x in k)
+    othw = tuple(thw[i] + 2 * pad[i] - k[i] + 1 for i in range(3))
+    d = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, (1, 1, 1), pad, othw)
+    x = torch.randn(N, *thw, Ci, device="cuda")
+    w = torch.randn(Co, k[0] * k[1] * k[2], Ci, device="cuda") * 0.05
+    out = torch.empty(N, *othw, Co, device="cuda")
+    for _ in range(2):
+        ops.conv_fwd(d, x, w, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    R = 5
+    for _ in range(R):
+        ops.conv_fwd(d, x, w, out)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / R
+    fl = 2.0 * N * othw[0] * othw[1] * othw[2] * Co * Ci * k[0] * k[1] * k[2]
+    print("ABL=%s %-40s %8.3f ms  %6.1f TF/s" % (mode, name, dt * 1e3, fl / dt / 1e12), flush=True)
