@@ -210,6 +210,210 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Fast path (Ci % 32 == 0, <= 10 taps per dim): tiles go global -> LDS directly (global_load_lds_dwordx4, no VGPR
+// staging, no ds_write), per-row pointers and per-dim tap-validity bit masks are computed once per block, and the
+// tap walk is wave-uniform scalar state, so a K chunk costs ~6 VALU per 1 KiB fetched instead of ~20.  The LDS image
+// is un-padded [row][32 floats] with the 16-byte slots of a row XOR-swizzled by (row>>1)&7; the swizzle is applied on
+// the SOURCE address (LDS-DMA writes lane-linear) and again on the fragment read, which keeps ds_read_b128
+// conflict-free for both 16-lane groups.
+__device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void glds16(const float* g, float* l) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int AR = BM / 32, BR = BN / 32;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                          // [2][BM][32]
+    float* Bs = smem + 2 * BM * BK;            // [2][BN][32]
+    int* rinfo = (int*)(Bs + 2 * BN * BK);     // [BM][4] n,t0,h0,w0
+    int* rout = rinfo + BM * 4;                // [BM] output position index or -1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
+    const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
+    const int n0 = nt * BN;
+    const float* wbase = p.w + (size_t)g * p.wgstride;
+    const float* bbase = p.bias + (size_t)g * p.bgstride;
+
+    for (int r = tid; r < BM; r += 256) {
+        const int lm = lt * BM + r;
+        int4 info = make_int4(-1, 0, 0, 0);
+        int op = -1;
+        if (lm < p.Mg) {
+            int m = g * p.Mg + lm;
+            const int wq = m % p.Wq; m /= p.Wq;
+            const int hq = m % p.Hq; m /= p.Hq;
+            const int tq = m % p.Tq; const int n = m / p.Tq;
+            info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1], wq * p.istr[2] + p.ioff0[2]);
+            op = ((n * p.To + tq * p.ostr[0] + p.ooff[0]) * p.Ho + hq * p.ostr[1] + p.ooff[1]) * p.Wo + wq * p.ostr[2] + p.ooff[2];
+        }
+        ((int4*)rinfo)[r] = info;
+        rout[r] = op;
+    }
+    __syncthreads();
+
+    // per-thread fetch rows: row = lrow + 32*j, 16-byte slot (tid&7), source slot XOR-swizzled
+    const int lrow = tid >> 3, slot = tid & 7;
+    const float* aptr[AR]; unsigned amask[AR];
+    const float* bptr[BR];
+#pragma unroll
+    for (int j = 0; j < AR; ++j) {
+        const int row = lrow + 32 * j;
+        const int4 ri = ((int4*)rinfo)[row];
+        const int ks = (slot ^ ((row >> 1) & 7)) * 4;
+        unsigned m = 0;
+        if (ri.x >= 0) {
+            for (int a = 0; a < p.ntap[0]; ++a) m |= ((unsigned)(ri.y + a * p.istep[0]) < (unsigned)p.Ti ? 1u : 0u) << a;
+            for (int a = 0; a < p.ntap[1]; ++a) m |= ((unsigned)(ri.z + a * p.istep[1]) < (unsigned)p.Hi ? 1u : 0u) << (10 + a);
+            for (int a = 0; a < p.ntap[2]; ++a) m |= ((unsigned)(ri.w + a * p.istep[2]) < (unsigned)p.Wi ? 1u : 0u) << (20 + a);
+        }
+        amask[j] = m;
+        const long long pos = ((long long)(ri.x * p.Ti + ri.y) * p.Hi + ri.z) * p.Wi + ri.w;   // may be "out of range": only used when valid
+        aptr[j] = p.in + pos * p.ldi + ks;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+        const int row = lrow + 32 * j, co = n0 + row;
+        const int ks = (slot ^ ((row >> 1) & 7)) * 4;
+        bptr[j] = co < p.Co ? wbase + (size_t)co * p.wtaps * p.ldw + ks : nullptr;
+    }
+
+    int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
+    auto fetch = [&](int buf) {
+        const long long da = ((long long)(u_a * p.istep[0] * p.Hi + u_b * p.istep[1]) * p.Wi + u_c * p.istep[2]) * p.ldi + u_ci;
+        const unsigned sel = (1u << u_a) | (1u << (10 + u_b)) | (1u << (20 + u_c));
+        const int wtap = ((p.wk0[0] + u_a * p.wkstep[0]) * p.KH + p.wk0[1] + u_b * p.wkstep[1]) * p.KW + p.wk0[2] + u_c * p.wkstep[2];
+        const long long db = (long long)wtap * p.ldw + u_ci;
+        float* la = As + buf * BM * BK + (wave * 8) * BK;     // wave-uniform base; the DMA adds lane*16 B itself
+        float* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) {
+            const float* src = ((amask[j] & sel) == sel) ? aptr[j] + da : g_zero16;
+            glds16(src, la + j * 32 * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            const float* src = bptr[j] ? bptr[j] + db : g_zero16;
+            glds16(src, lb + j * 32 * BK);
+        }
+        u_ci += BK;
+        if (u_ci >= p.Ci) {
+            u_ci = 0;
+            if (++u_c == p.ntap[2]) { u_c = 0; if (++u_b == p.ntap[1]) { u_b = 0; ++u_a; } }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = p.K / BK;
+    fetch(0);
+    __syncthreads();
+    const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
+    const int kh = lane >> 5;
+    int aoff[TM], boff[TN], asw[TM], bsw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { const int r = arow + i * 32; aoff[i] = r * BK; asw[i] = (r >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { const int r = brow + j * 32; boff[j] = r * BK; bsw[j] = (r >> 1) & 7; }
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) fetch(buf ^ 1);
+        const float* a = As + buf * BM * BK;
+        const float* b = Bs + buf * BN * BK;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f32x4 af[TM], bf[TN];
+            const int q = ks * 2 + kh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + aoff[i] + ((q ^ asw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + boff[j] + ((q ^ bsw[j]) << 2));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
+    }
+
+    // ---- epilogue (same as conv_gemm_kernel)
+    const bool has_bias = p.flags & PC_F_BIAS, has_cs = p.flags & PC_F_CSCALE, accum = p.flags & PC_F_ACCUM;
+    if (p.flags & PC_F_BNPART) {
+        float* part = p.bnpart + ((size_t)(g * p.mtiles_g + lt) * WM + wm) * 2 * p.Co;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            float s = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float v = acc[i][j][r]; s += v; s2 += v * v; }
+            s += __shfl_xor(s, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+            if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int op = rout[row];
+            if (op < 0) continue;
+            const int nb = rinfo[row * 4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+                if (col >= p.Co) continue;
+                float v = acc[i][j][r];
+                if (has_bias) v += bbase[col];
+                if (col >= p.act_c0) {
+                    if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (p.act == PC_ACT_SIGMOID) v = 1.0f / (1.0f + expf(-v));
+                }
+                if (has_cs) v *= p.cscale[(size_t)nb * p.Co + col];
+                float* o = p.out + (size_t)op * p.ldo + col;
+                if (accum) v += *o;
+                *o = v;
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_conv_glds(const ConvK& k, hipStream_t s) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)(2 * (BM + BN) * BK + BM * 5) * sizeof(float);
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr_set = true;
+    }
+    ConvK p = k;
+    p.mtiles_g = cdiv(p.Mg, BM);
+    p.ntiles = cdiv(p.Co, BN);
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
+    PC_CHECK_LAUNCH("conv_gemm_glds_kernel");
+    return PC_OK;
+}
+
 template <int BM, int BN, int WM, int WN, bool FAST>
 int launch_conv2(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
@@ -250,7 +454,11 @@ int launch_conv(const ConvK& k, hipStream_t s) {
         if (abl == 2) return launch_ablate<BM, BN, WM, WN, 2>(k, s);
         return launch_ablate<BM, BN, WM, WN, 3>(k, s);
     }
-    return (k.Ci % BK == 0) ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
+    static const int no_glds = getenv("PICONS_CONV_NO_GLDS") ? atoi(getenv("PICONS_CONV_NO_GLDS")) : 0;
+    const bool fast = k.Ci % BK == 0;
+    if (fast && !no_glds && k.ntap[0] <= 10 && k.ntap[1] <= 10 && k.ntap[2] <= 10 && ((uintptr_t)k.in % 16 == 0) && k.ldi % 4 == 0)
+        return launch_conv_glds<BM, BN, WM, WN>(k, s);
+    return fast ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
 }
 
 // tile choice: minimise padded work, prefer larger tiles when the grid still fills the chip
