@@ -583,19 +583,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
         }
     };
     constexpr int DN = BK / DRP, SN = BK / SRP;        // loads per thread
-    f32x4 dreg[DN], sreg[SN];
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    unsigned vmask = 0;   // validity of the in-flight tile; applied at the LDS store so the loads stay branch-free
-    auto gload = [&](int c) {
-        unsigned m = 0;
+    // tiles go global -> LDS directly (global_load_lds_dwordx4): each wave-instruction writes 1 KiB = consecutive
+    // float4 columns of consecutive position rows, which is exactly the lane-linear image the DMA produces
+    // (LDS float offset of thread tid in pass j = (tid + 256*j) * 4); invalid rows / taps read a zero line.
+    auto gload = [&](int c, int buf) {
+        float* ld = &Ds[buf][0][0] + wave * 256;      // wave-uniform base; the DMA adds lane*16 B
+        float* ls = &Ss[buf][0][0] + wave * 256;
 #pragma unroll
         for (int j = 0; j < DN; ++j) {
             const int r = drow0 + DRP * j;
             const int pos = c * BK + r;
             const bool v = mval && pos < p.P;
-            const float* src = v ? p.D + (size_t)pos * p.ldd + m0 + dcol : p.D;
-            dreg[j] = *(const f32x4*)src;
-            m |= (v ? 1u : 0u) << j;
+            const float* src = v ? p.D + (size_t)pos * p.ldd + m0 + dcol : g_zero16;
+            glds16(src, ld + j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
@@ -605,17 +605,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
             const bool v = nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
                            (unsigned)w < (unsigned)p.Ws;
             const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
-            const float* src = v ? p.S + ps * p.lds + cs : p.S;
-            sreg[j] = *(const f32x4*)src;
-            m |= (v ? 1u : 0u) << (DN + j);
+            const float* src = v ? p.S + ps * p.lds + cs : g_zero16;
+            glds16(src, ls + j * 1024);
         }
-        vmask = m;
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < DN; ++j) *(f32x4*)&Ds[buf][drow0 + DRP * j][dcol] = ((vmask >> j) & 1u) ? dreg[j] : zero4;
-#pragma unroll
-        for (int j = 0; j < SN; ++j) *(f32x4*)&Ss[buf][srow0 + SRP * j][scol] = ((vmask >> (DN + j)) & 1u) ? sreg[j] : zero4;
     };
 
     f32x16 acc[TM][TN];
@@ -629,14 +621,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     ptab_fill(c_begin);
     ptab_fill(c_begin + 1);
     __syncthreads();
-    gload(c_begin);
-    lstore(0);
+    gload(c_begin, 0);
     __syncthreads();
     const int ml = wm * (BM / 2) + (lane & 31), nl = wn * (BN / 2) + (lane & 31), kh = lane >> 5;
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         ptab_fill(c + 2);
-        if (c + 1 < c_end) gload(c + 1);
+        if (c + 1 < c_end) gload(c + 1, buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float af[TM], bf[TN];
@@ -650,8 +641,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < c_end) lstore(buf ^ 1);
-        __syncthreads();
+        __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)

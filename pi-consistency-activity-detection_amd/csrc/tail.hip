@@ -80,42 +80,43 @@ __global__ __launch_bounds__(256) void tail_dw4_kernel(const float* __restrict__
     }
 }
 
-// per output channel co: dWp[co][j], db4[co]; block (0) thread 0 also dbp
-__global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__ G, const float* __restrict__ s, const float* __restrict__ W4,
-                                                       const float* __restrict__ b4, const float* __restrict__ cs, const float* __restrict__ Wp,
-                                                       int N, int Ci, int Co, int taps, int J, int center, float* __restrict__ dWp,
-                                                       float* __restrict__ db4, float* __restrict__ dbp, int accum) {
+// dWp[co][j] += cs[n][co] * sum_{ci,tap} W4[ci][co][tap] * G[n][ci][tap][j]     (grid Co x N, atomics over n)
+__global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__ G, const float* __restrict__ W4, const float* __restrict__ cs,
+                                                       int Ci, int Co, int taps, int J, float* __restrict__ dWp) {
     __shared__ float sh[8][32];
-    const int co = blockIdx.x, j = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int co = blockIdx.x, n = blockIdx.y, j = threadIdx.x & 31, sl = threadIdx.x >> 5;
     const int per_n = Ci * taps;
-    float acc = 0.f;
-    for (int n = 0; n < N; ++n) {
-        const float sc = cs ? cs[n * Co + co] : 1.f;
-        float a = 0.f;
-        for (int e = sl; e < per_n; e += 8) {
-            const int ci = e / taps, tap = e - ci * taps;
-            a += W4[((size_t)ci * Co + co) * taps + tap] * G[(((size_t)n * Ci + ci) * taps + tap) * J32 + j];
-        }
-        acc += sc * a;
+    float a = 0.f;
+    for (int e = sl; e < per_n; e += 8) {
+        const int ci = e / taps, tap = e - ci * taps;
+        a += W4[((size_t)ci * Co + co) * taps + tap] * G[(((size_t)n * Ci + ci) * taps + tap) * J32 + j];
     }
-    sh[sl][j] = acc;
+    sh[sl][j] = a;
     __syncthreads();
-    if (sl == 0) {
+    if (sl == 0 && j < J) {
         float t = 0.f;
         for (int q = 0; q < 8; ++q) t += sh[q][j];
-        float sb = 0.f;
-        for (int n = 0; n < N; ++n) sb += (cs ? cs[n * Co + co] : 1.f) * s[n * J32 + j];
-        if (j < J) dWp[co * J + j] = (accum ? dWp[co * J + j] : 0.f) + t + b4[co] * sb;
-        // db4[co] = sum_j Wp[co][j] * sum_n cs[n][co] s[n][j]
-        float v = j < J ? Wp[co * J + j] * sb : 0.f;
+        atomicAdd(dWp + co * J + j, (cs ? cs[n * Co + co] : 1.f) * t);
+    }
+}
+
+// bias-path terms: dWp[co][j] += b4[co]*sb[j], db4[co] (+)= sum_j Wp[co][j]*sb[j], dbp (+)= sum_n s[n][center];  sb[j] = sum_n cs[n][co] s[n][j]
+__global__ __launch_bounds__(64) void tail_dbias_kernel(const float* __restrict__ s, const float* __restrict__ b4, const float* __restrict__ cs,
+                                                        const float* __restrict__ Wp, int N, int Co, int J, int center, float* __restrict__ dWp,
+                                                        float* __restrict__ db4, float* __restrict__ dbp, int accum) {
+    const int co = blockIdx.x, j = threadIdx.x & 31;
+    if (threadIdx.x >= 32) return;
+    float sb = 0.f;
+    for (int n = 0; n < N; ++n) sb += (cs ? cs[n * Co + co] : 1.f) * s[n * J32 + j];
+    if (j < J) dWp[co * J + j] += b4[co] * sb;
+    float v = j < J ? Wp[co * J + j] * sb : 0.f;
 #pragma unroll
-        for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-        if (j == 0) db4[co] = (accum ? db4[co] : 0.f) + v;
-        if (co == 0 && j == 0) {
-            float t2 = 0.f;
-            for (int n = 0; n < N; ++n) t2 += s[n * J32 + center];
-            dbp[0] = (accum ? dbp[0] : 0.f) + t2;
-        }
+    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if (j == 0) db4[co] = (accum ? db4[co] : 0.f) + v;
+    if (co == 0 && j == 0) {
+        float t2 = 0.f;
+        for (int n = 0; n < N; ++n) t2 += s[n * J32 + center];
+        dbp[0] = (accum ? dbp[0] : 0.f) + t2;
     }
 }
 
@@ -149,7 +150,9 @@ extern "C" int pc_tail_grads(const float* G, const float* sums, const float* W4,
     const int64_t total = (int64_t)Ci * Co * taps;
     int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(tail_dw4_kernel, dim3(grid), dim3(256), 0, s, G, cs, Wp, N, Ci, Co, taps, J, dW4, accum);
-    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Co), dim3(256), 0, s, G, sums, W4, b4, cs, Wp, N, Ci, Co, taps, J, center, dWp, db4, dbp, accum);
+    if (!accum) (void)hipMemsetAsync(dWp, 0, sizeof(float) * Co * J, s);
+    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Co, N), dim3(256), 0, s, G, W4, cs, Ci, Co, taps, J, dWp);
+    hipLaunchKernelGGL(tail_dbias_kernel, dim3(Co), dim3(64), 0, s, sums, b4, cs, Wp, N, Co, J, center, dWp, db4, dbp, accum);
     PC_CHECK_LAUNCH("tail_grads");
     return PC_OK;
 }
