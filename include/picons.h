@@ -38,6 +38,9 @@ typedef void* pc_stream;            /* hipStream_t */
 #define PC_F_BIAS    2
 #define PC_F_CSCALE  4              /* multiply by cscale[n][co] (Dropout3d draw, capsules_ucf101.py:428,507) */
 #define PC_F_BNPART  8              /* emit per-block BatchNorm partial sums (sum, sumsq) */
+#define PC_F_NFAST   16             /* GEMM rows ordered (t,h,w,n) instead of (n,t,h,w): a 128-row tile is a narrow spatial
+                                       patch of all samples, so taps that are padding for the whole tile are skipped
+                                       (9x9 ConvTranspose / PrimaryCaps dgrad: 784 gathered vs 400 real positions) */
 
 int         pc_version(void);
 const char* pc_last_error(void);

@@ -42,7 +42,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS) = range(1, 28)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-F_ACCUM, F_BIAS, F_CSCALE, F_BNPART = 1, 2, 4, 8
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST = 1, 2, 4, 8, 16
 
 _SIGS = {
     "pc_version": (i32, []),

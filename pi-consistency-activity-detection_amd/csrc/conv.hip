@@ -47,9 +47,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
         int op = -1;
         if (lm < p.Mg) {
             int m = g * p.Mg + lm;
+            int n = 0;
+            if (p.flags & PC_F_NFAST) { n = m % p.N; m /= p.N; }
             const int wq = m % p.Wq; m /= p.Wq;
             const int hq = m % p.Hq; m /= p.Hq;
-            const int tq = m % p.Tq; const int n = m / p.Tq;
+            const int tq = m % p.Tq;
+            if (!(p.flags & PC_F_NFAST)) n = m / p.Tq;
             info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1],
                              wq * p.istr[2] + p.ioff0[2]);
             op = ((n * p.To + tq * p.ostr[0] + p.ooff[0]) * p.Ho + hq * p.ostr[1] + p.ooff[1]) * p.Wo +
@@ -234,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     float* Bs = smem + 2 * BM * BK;            // [2][BN][32]
     int* rinfo = (int*)(Bs + 2 * BN * BK);     // [BM][4] n,t0,h0,w0
     int* rout = rinfo + BM * 4;                // [BM] output position index or -1
+    unsigned* tile_or = (unsigned*)(rout + BM);   // OR of every row's tap-validity mask
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     const int n0 = nt * BN;
     const float* wbase = p.w + (size_t)g * p.wgstride;
     const float* bbase = p.bias + (size_t)g * p.bgstride;
+    if (tid == 0) *tile_or = 0u;
 
     for (int r = tid; r < BM; r += 256) {
         const int lm = lt * BM + r;
@@ -250,9 +255,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         int op = -1;
         if (lm < p.Mg) {
             int m = g * p.Mg + lm;
+            int n = 0;
+            if (p.flags & PC_F_NFAST) { n = m % p.N; m /= p.N; }
             const int wq = m % p.Wq; m /= p.Wq;
             const int hq = m % p.Hq; m /= p.Hq;
-            const int tq = m % p.Tq; const int n = m / p.Tq;
+            const int tq = m % p.Tq;
+            if (!(p.flags & PC_F_NFAST)) n = m / p.Tq;
             info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1], wq * p.istr[2] + p.ioff0[2]);
             op = ((n * p.To + tq * p.ostr[0] + p.ooff[0]) * p.Ho + hq * p.ostr[1] + p.ooff[1]) * p.Wo + wq * p.ostr[2] + p.ooff[2];
         }
@@ -287,7 +295,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         bptr[j] = co < p.Co ? wbase + (size_t)co * p.wtaps * p.ldw + ks : nullptr;
     }
 
-    int u_a = 0, u_b = 0, u_c = 0, u_ci = 0;
+    // Tap box of the tile: per dimension a row's valid taps form an interval, and so does their union over the tile.
+    // Taps outside the box gather only padding for EVERY row, so the K loop walks the box instead of all taps.
+    {
+        unsigned mo = 0;
+#pragma unroll
+        for (int j = 0; j < AR; ++j) mo |= amask[j];
+        atomicOr(tile_or, mo);
+    }
+    __syncthreads();
+    const unsigned bo = __builtin_amdgcn_readfirstlane(*tile_or);
+    const unsigned bt = bo & 0x3ffu, bh = (bo >> 10) & 0x3ffu, bw = (bo >> 20) & 0x3ffu;
+    const bool any_tap = bt && bh && bw;
+    const int a_lo = any_tap ? __builtin_ctz(bt) : 0, a_hi = any_tap ? 31 - __builtin_clz(bt) : -1;
+    const int b_lo = any_tap ? __builtin_ctz(bh) : 0, b_hi = any_tap ? 31 - __builtin_clz(bh) : -1;
+    const int c_lo = any_tap ? __builtin_ctz(bw) : 0, c_hi = any_tap ? 31 - __builtin_clz(bw) : -1;
+    int u_a = a_lo, u_b = b_lo, u_c = c_lo, u_ci = 0;
     auto fetch = [&](int buf) {
         const long long da = ((long long)(u_a * p.istep[0] * p.Hi + u_b * p.istep[1]) * p.Wi + u_c * p.istep[2]) * p.ldi + u_ci;
         const unsigned sel = (1u << u_a) | (1u << (10 + u_b)) | (1u << (20 + u_c));
@@ -308,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         u_ci += BK;
         if (u_ci >= p.Ci) {
             u_ci = 0;
-            if (++u_c == p.ntap[2]) { u_c = 0; if (++u_b == p.ntap[1]) { u_b = 0; ++u_a; } }
+            if (++u_c > c_hi) { u_c = c_lo; if (++u_b > b_hi) { u_b = b_lo; ++u_a; } }
         }
     };
 
@@ -320,8 +343,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = p.K / BK;
-    fetch(0);
+    const int nchunks = (a_hi - a_lo + 1) * (b_hi - b_lo + 1) * (c_hi - c_lo + 1) * (p.Ci / BK);
+    if (nchunks > 0) fetch(0);
     __syncthreads();
     const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
     const int kh = lane >> 5;
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 template <int BM, int BN, int WM, int WN>
 int launch_conv_glds(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * (BM + BN) * BK + BM * 5) * sizeof(float);
+    const size_t lds = (size_t)(2 * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -497,6 +520,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     PC_CHECK_ARG(!(d->flags & PC_F_BIAS) || bias, "pc_conv_fwd: bias flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_CSCALE) || cscale, "pc_conv_fwd: cscale flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_BNPART) || bnpart, "pc_conv_fwd: bnpart flag without pointer");
+    PC_CHECK_ARG(!(d->flags & PC_F_NFAST) || (groups == 1 && !(d->flags & (PC_F_BNPART | PC_F_CSCALE))), "pc_conv_fwd: NFAST needs groups == 1 and no BN partials / cscale");
     PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)w % 16 == 0), "pc_conv_fwd: in/w must be 16-byte aligned");
     ConvK k;
     k.in = in; k.w = w; k.bias = bias; k.cscale = cscale; k.out = out; k.bnpart = bnpart;

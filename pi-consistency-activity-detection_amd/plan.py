@@ -424,7 +424,7 @@ class Plan:
             dx, acc = self.grad_for_write(xd)
             self.alg_dgrad(2 * caps_in.rows * caps_in.C * xd.C * KP * KP)
             for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
-                                           flags=capi.F_ACCUM if acc else 0, ldw=caps_in.C):
+                                           flags=(capi.F_ACCUM if acc else 0) | capi.F_NFAST, ldw=caps_in.C):
                 self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
         self.tape.append(bwd_caps)
         # decoder (capsules_ucf101.py:486-510)

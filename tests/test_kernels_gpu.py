@@ -103,6 +103,7 @@ def test_conv_epilogue_bias_act_cscale_accum_slice():
 
 
 TCASES = [
+    (64, 96, (1, 9, 9), (1, 1, 1), (0, 0, 0), (0, 0, 0), (1, 20, 20), 6),
     (128, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (1, 7, 7), 2),
     (16, 128, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), (2, 6, 5), 2),
     (48, 64, (1, 9, 9), (1, 1, 1), (0, 0, 0), (0, 0, 0), (1, 6, 6), 2),
@@ -125,6 +126,11 @@ def test_conv_transpose(Ci, Co, k, s, pd, op, thw, N):
     for dd in desc.transposed_classes(N, thw, Ci, Ci, othw, Co, Co, k, s, pd):
         ops.conv_fwd(dd, cl(x), wt_oki, out)
     close(uncl(out), y, what="convT fwd")
+    if s == (1, 1, 1):      # n-fastest row order + tile-level tap skipping must not change the result
+        out2 = torch.full((N, *othw, Co), -5.0, device=DEV)
+        for dd in desc.transposed_classes(N, thw, Ci, Ci, othw, Co, Co, k, s, pd, flags=capi.F_NFAST):
+            ops.conv_fwd(dd, cl(x), wt_oki, out2)
+        close(uncl(out2), y, what="convT fwd (NFAST)")
     dx = torch.empty(N, *thw, Ci, device=DEV)
     ops.conv_fwd(desc.conv_fwd(N, othw, Co, Co, Ci, Ci, k, s, pd, thw), cl(dy), wt_iko, dx)
     close(uncl(dx), x.grad, what="convT dgrad")
@@ -441,7 +447,8 @@ def test_collapsed_tail_kernels_vs_torch():
     out.backward(dout)
     dev = lambda t: t.detach().contiguous().to(DEV)
     Wt = torch.empty(N, Ci, taps, 32, device=DEV); Wf = torch.empty(N, 32, taps, Ci, device=DEV); bc = torch.empty(N, 32, device=DEV)
-    capi.call("pc_tail_combine", ops.ptr(dev(W4)), ops.ptr(dev(b4)), ops.ptr(dev(cs)), ops.ptr(dev(Wp)), N, Ci, Co, taps, J,
+    W4g, b4g, csg, Wpg, bpg = dev(W4), dev(b4), dev(cs), dev(Wp), dev(bp)      # keep the device copies alive across the raw-pointer calls
+    capi.call("pc_tail_combine", ops.ptr(W4g), ops.ptr(b4g), ops.ptr(csg), ops.ptr(Wpg), N, Ci, Co, taps, J,
               ops.ptr(Wt), ops.ptr(Wf), ops.ptr(bc), ops.stream())
     Wc = torch.einsum("iot,no,oj->nitj", W4.detach().reshape(Ci, Co, taps), cs, Wp.detach().reshape(Co, J))
     close(Wt[..., :27], Wc, what="Wt"); close(Wf[:, :27].permute(0, 3, 2, 1), Wc, what="Wf")
@@ -454,7 +461,7 @@ def test_collapsed_tail_kernels_vs_torch():
     for dd in desc.transposed_classes(N, (2, 3, 4), Cp, Cp, othw, 32, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1), flags=capi.F_BIAS, groups=N):
         dd["wgstride"] = 32 * taps * Ci; dd["bgstride"] = 32
         ops.conv_fwd(dd, cl(x), Wf, proj, bias=bc)
-    o = ops.tapsum_fwd(proj, dev(bp))
+    o = ops.tapsum_fwd(proj, bpg)
     close(o.cpu(), out[:, 0], what="collapsed forward")
     # backward pieces
     dproj = ops.tapsum_bwd(dev(dout[:, 0]))
@@ -467,7 +474,7 @@ def test_collapsed_tail_kernels_vs_torch():
     for n in range(N):
         ops.conv_wgrad(desc.wgrad(1, (2, 3, 4), Ci, Ci, othw, 32, 32, (3, 3, 3), (2, 2, 2), (1, 1, 1)), xg[n], dproj[n], G[n])
     dW4 = torch.zeros(Ci, Co, taps, device=DEV); db4 = torch.zeros(Co, device=DEV); dWp = torch.zeros(Co, J, device=DEV); dbp = torch.zeros(1, device=DEV)
-    capi.call("pc_tail_grads", ops.ptr(G), ops.ptr(sums), ops.ptr(dev(W4)), ops.ptr(dev(b4)), ops.ptr(dev(cs)), ops.ptr(dev(Wp)), N, Ci, Co, taps, J, 13,
+    capi.call("pc_tail_grads", ops.ptr(G), ops.ptr(sums), ops.ptr(W4g), ops.ptr(b4g), ops.ptr(csg), ops.ptr(Wpg), N, Ci, Co, taps, J, 13,
               ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 0, ops.stream())
     close(dW4.cpu(), W4.grad.reshape(Ci, Co, taps), what="dW4"); close(db4.cpu(), b4.grad, what="db4")
     close(dWp.cpu(), Wp.grad.reshape(Co, J), what="dWp"); close(dbp.cpu(), bp.grad, what="dbp")
