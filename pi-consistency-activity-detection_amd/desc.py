@@ -58,6 +58,26 @@ def transposed_classes(N, small_thw, Cs, lds_, big_thw, Cb, ldb, k, stride, pad_
     return out
 
 
+def split_lattice(d, dim, starts):
+    """Split a conv descriptor's output lattice along `dim` (0/1/2) at the given start indices -> list of
+    descriptors covering [starts[i], starts[i+1]).  Used to align 128-row tiles with narrow spatial zones so the
+    kernel's tile-level tap box is tight (PC_F_NFAST launches)."""
+    key = ("Tq", "Hq", "Wq")[dim]
+    total = d[key]
+    bounds = [b for b in starts if b < total] + [total]
+    out = []
+    for q0, q1 in zip(bounds[:-1], bounds[1:]):
+        if q1 <= q0:
+            continue
+        e = dict(d)
+        e[key] = q1 - q0
+        e["ooff"] = list(d["ooff"]); e["ioff0"] = list(d["ioff0"])
+        e["ooff"][dim] += q0 * d["ostr"][dim]
+        e["ioff0"][dim] += q0 * d["istr"][dim]
+        out.append(e)
+    return out
+
+
 def wgrad(N, dense_thw, Cd, ldd, gath_thw, Cs, lds_, k, stride, pad_front, splitk=0):
     """g[cd][k][cs] += sum_{n,q} D[n,q,cd] * S[n, q*s - pf + k, cs]."""
     return dict(N=N, Tq=dense_thw[0], Hq=dense_thw[1], Wq=dense_thw[2], Cd=Cd, ldd=ldd,

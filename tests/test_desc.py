@@ -101,3 +101,20 @@ def test_tap_trimming_is_exact(thw, k, s):
     wd = desc.trim_wgrad(desc.wgrad(2, othw, Co, Co, thw, Ci, Ci, k, s, pf))
     assert np.prod(wd["ntap"]) < taps
     np.testing.assert_allclose(run_wgrad(wd, cl(dy), cl(x)), w.grad.reshape(Co, Ci, taps).permute(0, 2, 1).numpy(), atol=1e-9)
+
+
+def test_split_lattice_is_exact():
+    g = torch.Generator().manual_seed(4)
+    Ci, Co, k, thw = 4, 3, (1, 5, 5), (1, 4, 6)
+    x = torch.randn(2, Ci, *thw, generator=g, dtype=torch.float64)
+    w = torch.randn(Ci, Co, *k, generator=g, dtype=torch.float64)
+    y = F.conv_transpose3d(x, w)
+    othw = tuple(y.shape[2:]); taps = 25
+    w_oki = w.reshape(Ci, Co, taps).permute(1, 2, 0).contiguous().numpy()
+    out = np.zeros((2,) + othw + (Co,))
+    n = 0
+    for dd in desc.transposed_classes(2, thw, Ci, Ci, othw, Co, Co, k, (1, 1, 1), (0, 0, 0)):
+        for dz in desc.split_lattice(dd, 2, [0, 4, 8]):
+            run_conv(desc.trim_conv(dz), cl(x), w_oki, out=out); n += 1
+    assert n == 3
+    np.testing.assert_allclose(out, cl(y), atol=1e-10)
