@@ -97,6 +97,16 @@ def main():
     fl = eng.plan.flops()
     fc = eng.plan.flops(capi.OP_CONV)
     conv_flops_step = fc["fwd"] + fc["bwd"]              # algorithmic (real channel counts), DESIGN.md §4
+    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
+    # FETCH_SIZE / WRITE_SIZE in their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run
+    traffic = None
+    for tag in ("r01",):
+        tp = os.path.join(ROOT, "profiles", tag + "_traffic.json")
+        if os.path.exists(tp) and a.bs == 8:
+            try:
+                traffic = json.load(open(tp))["conv_gemm_hbm_bytes_per_launch"]
+            except Exception:
+                traffic = None
     roof = None
     if kind is not None and eng.kind_count:
         avg_ms = eng.kind_ms / eng.kind_count
@@ -104,7 +114,7 @@ def main():
         ach = flops_per_launch / (avg_ms * 1e-3) / 1e12
         roof = {"bound": "mfma", "kernel": "conv_gemm_kernel (fp32 MFMA gather-GEMM: conv fwd / dgrad / convT)",
                 "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "traffic": None, "launches_per_step": eng.kind_count // a.steps, "avg_launch_ms": avg_ms,
+                "traffic": traffic, "launches_per_step": eng.kind_count // a.steps, "avg_launch_ms": avg_ms,
                 "kernel_ms_per_step": eng.kind_ms / a.steps,
                 "flops_per_launch": flops_per_launch}
     out = {

@@ -303,10 +303,7 @@ class Plan:
         F_fwd = 0
         for dd in D.transposed_classes(x.N, x.thw, Ci, x.ld, othw, cout, out.ld, k, stride, pad, act=act, flags=flags):
             F_fwd += _conv_flops(dd)
-            zones = D.split_lattice(dd, 2, list(range(0, othw[2], max(1, 128 // x.N)))) if flags & capi.F_NFAST else [dd]
-            for dz in zones:
-                self.conv_op(dz, x.ref, w["fwd"], out.ref, bias=self.P(name + ".bias"), cscale=cscale, alg=0)
-            self.alg_dgrad(_conv_flops(dd))
+            self.conv_op(dd, x.ref, w["fwd"], out.ref, bias=self.P(name + ".bias"), cscale=cscale)
 
         def bwd():
             dy = self.grad_of(out)
@@ -430,9 +427,9 @@ class Plan:
             self.alg_dgrad(2 * caps_in.rows * caps_in.C * xd.C * KP * KP)
             for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
                                            flags=(capi.F_ACCUM if acc else 0) | capi.F_NFAST, ldw=caps_in.C):
-                # 8-wide W zones: with n-fastest rows a 128-row tile is then exactly (one h, 8 w, 16 samples)
-                for dz in D.split_lattice(dd, 2, list(range(0, xd.thw[2], max(1, 128 // N)))):
-                    self.conv_op(dz, dcaps.ref, wpc["tr"], dx.ref, alg=0)
+                # (splitting W into 8-wide zones so tiles align with (h, 8w, N) patches was measured SLOWER: 4 launches of
+                # 182-364 blocks under-fill the chip; the in-kernel tap box on the un-split launch is kept)
+                self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
         self.tape.append(bwd_caps)
         # decoder (capsules_ucf101.py:486-510)
         cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")
