@@ -223,27 +223,26 @@ __device__ __forceinline__ void load_pos(FwdState* st, const float* x, int64_t p
 
 constexpr int FWD_WAVES = 4;
 
-// Forward: FWD_WAVES waves cooperate on one position at a time (W^T + one FwdState + reduction buffer = 76 KB of LDS,
-// so two blocks = 8 waves are resident per CU).
+// Forward: one wave per position, FWD_WAVES independent waves per block sharing W^T in LDS.  (A cooperative
+// 4-waves-per-position variant with 2 blocks/CU was measured slower: 1.78 vs 1.27 ms per step - more barriers.)
 __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ beta_u, const float* __restrict__ beta_a,
                                                                  int npos, int C, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* WT = smem;
-    FwdState* st = (FwdState*)(smem + NB * MAXC * 16);
-    float* red = (float*)(st + 1);
-    const int tid = threadIdx.x;
-    constexpr int NT = 64 * FWD_WAVES;
-    load_WT(WT, W, C, tid, NT);
+    FwdState* sts = (FwdState*)(smem + NB * MAXC * 16);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    load_WT(WT, W, C, threadIdx.x, blockDim.x);
     __syncthreads();
-    for (int64_t pos = blockIdx.x; pos < npos; pos += gridDim.x) {
-        __syncthreads();
-        load_pos(st, x, pos, tid, NT);
-        __syncthreads();
-        em_forward<FWD_WAVES>(st, WT, beta_u, beta_a, C, tid, red);
+    FwdState* st = sts + wave;
+    for (int64_t pos = (int64_t)blockIdx.x * FWD_WAVES + wave; pos < npos; pos += (int64_t)gridDim.x * FWD_WAVES) {
+        WSYNC();
+        load_pos(st, x, pos, lane, 64);
+        WSYNC();
+        em_forward<1>(st, WT, beta_u, beta_a, C, lane, nullptr);
         float* o = out + pos * (C * 17);
-        for (int e = tid; e < C * 16; e += NT) o[e] = (&st->mu[2][0][0])[e];
-        if (tid < C) o[C * 16 + tid] = st->aout[2][tid];
+        for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[2][0][0])[e];
+        if (lane < C) o[C * 16 + lane] = st->aout[2][lane];
     }
 }
 
@@ -629,10 +628,11 @@ extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* be
     PC_CHECK_ARG(x && W && beta_u && beta_a && out, "pc_em_routing_fwd: null");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_fwd: B must be 32 and C <= 24 (B=%d C=%d)", B, C);
     PC_CHECK_ARG((uintptr_t)x % 16 == 0, "pc_em_routing_fwd: x alignment");
-    const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdState) + FWD_WAVES * MAXC * 16 * 4;
+    const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdState) * FWD_WAVES;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)em_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    int grid = npos < 512 ? npos : 512;
+    int grid = cdiv(npos, FWD_WAVES);
+    if (grid > 512) grid = 512;
     hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out);
     PC_CHECK_LAUNCH("em_fwd");
     return PC_OK;
