@@ -19,6 +19,7 @@ struct ConvK {
 };
 
 constexpr int BK = 32;       // K chunk (floats)
+constexpr int CONV_DEFAULT_VARIANT = 0;
 constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
 
 template <int BM, int BN, int WM, int WN, bool FAST, int ABL = 0>
@@ -227,7 +228,7 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
@@ -355,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     for (int j = 0; j < TN; ++j) { const int r = brow + j * 32; boff[j] = r * BK; bsw[j] = (r >> 1) & 7; }
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (c + 1 < nchunks) fetch(buf ^ 1);
+        if (!(VAR & 2) && c + 1 < nchunks) fetch(buf ^ 1);
         const float* a = As + buf * BM * BK;
         const float* b = Bs + buf * BN * BK;
 #pragma unroll
@@ -366,6 +367,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
             for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + aoff[i] + ((q ^ asw[i]) << 2));
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + boff[j] + ((q ^ bsw[j]) << 2));
+            if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -373,6 +375,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+            if (VAR & 1) __builtin_amdgcn_s_setprio(0);
+            if ((VAR & 2) && ks == 0 && c + 1 < nchunks) fetch(buf ^ 1);   // issue the next tile's DMA behind the first MFMA group
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
     }
@@ -421,20 +425,33 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_conv_glds(const ConvK& k, hipStream_t s) {
+template <int BM, int BN, int WM, int WN, int VAR>
+int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
     const size_t lds = (size_t)(2 * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
     }
     ConvK p = k;
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
-    hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
+    hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
     PC_CHECK_LAUNCH("conv_gemm_glds_kernel");
     return PC_OK;
+}
+
+// PICONS_CONV_VARIANT (tuning, tools/ablate_conv.py): bit 0 = s_setprio around the MFMA groups, bit 1 = issue the next
+// tile's LDS-DMA after the first MFMA group instead of before it.  Same results in every variant.
+template <int BM, int BN, int WM, int WN>
+int launch_conv_glds(const ConvK& k, hipStream_t s) {
+    static const int var = getenv("PICONS_CONV_VARIANT") ? atoi(getenv("PICONS_CONV_VARIANT")) : CONV_DEFAULT_VARIANT;
+    switch (var & 3) {
+        case 1: return launch_conv_glds_v<BM, BN, WM, WN, 1>(k, s);
+        case 2: return launch_conv_glds_v<BM, BN, WM, WN, 2>(k, s);
+        case 3: return launch_conv_glds_v<BM, BN, WM, WN, 3>(k, s);
+        default: return launch_conv_glds_v<BM, BN, WM, WN, 0>(k, s);
+    }
 }
 
 template <int BM, int BN, int WM, int WN, bool FAST>

@@ -17,8 +17,10 @@ SHAPES = [  # name, N, thw, Ci, Co, k
     ("3x3x3 128->128 @4x112x112", 16, (4, 112, 112), 128, 128, (3, 3, 3)),
     ("primary caps 9x9 832->544 @28x28", 16, (1, 28, 28), 832, 544, (1, 9, 9)),
     ("3x3 160->320 @28x28", 16, (1, 28, 28), 160, 320, (1, 3, 3)),
+    ("1x1 832->256 @28x28", 16, (1, 28, 28), 832, 256, (1, 1, 1)),
+    ("3x3x3 64->192 @2x56x56", 16, (2, 56, 56), 64, 192, (3, 3, 3)),
 ]
-mode = os.environ.get("PICONS_CONV_ABLATE", "0")
+mode = os.environ.get("PICONS_CONV_ABLATE", "0") + "/var" + os.environ.get("PICONS_CONV_VARIANT", "-")
 for name, N, thw, Ci, Co, k in SHAPES:
     valid = name.startswith("primary")
     pad = (0, 0, 0) if valid else tuple(x // 2 for x in k)
