@@ -554,7 +554,14 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
     k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
-    const TileCfg c = choose_tile(k.Mg, groups, d->Co);
+    TileCfg c = choose_tile(k.Mg, groups, d->Co);
+    if (d->flags & PC_F_NFAST) {
+        // n-fastest rows: a tile should hold whole groups of N samples of consecutive w so its tap box is tight;
+        // when Wq*N is not a multiple of 128 use 64-row tiles (28 w x 16 samples = 7 tiles of 64, none straddles a row)
+        const long long per_row = (long long)d->Wq * d->N;
+        if (per_row % 128 != 0 && per_row % 64 == 0) { c.bm = 64; c.bn = d->Co >= 128 ? 128 : 64; c.wm = d->Co >= 128 ? 1 : 2; }
+    }
+    if (c.bm == 64 && c.bn == 128) return launch_conv<64, 128, 1, 4>(k, s);
     if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128, 2, 2>(k, s);
     if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64, 2, 2>(k, s);
     if (c.bm == 64 && c.bn == 64) return launch_conv<64, 64, 2, 2>(k, s);
