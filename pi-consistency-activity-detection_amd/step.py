@@ -215,7 +215,9 @@ class StepEngine:
 
 def smoke_check(device="cuda:0", hw=224):
     """One bs=2 train step on the GPU checked against the CPU oracle (used by __graft_entry__.smoke)."""
+    import os
     from oracle import step as ostep
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # the oracle crawls when torch oversubscribes a 256-thread host
     args = default_args(bv=True, n_frames=5, wt_cons=0.1, lr=1e-4, epochs=100)
     eng = StepEngine(args, bs=2, hw=hw, device=device)
     lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=0, hw=hw)

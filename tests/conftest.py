@@ -10,6 +10,12 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import picons_amd  # noqa: E402,F401  (registers the alias for the hyphen-named package)
 
+try:    # the CPU oracle crawls when torch oversubscribes a many-core host (256 threads on the GPU box)
+    import torch as _torch
+    _torch.set_num_threads(min(os.cpu_count() or 1, 16))
+except Exception:
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
