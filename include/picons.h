@@ -147,6 +147,11 @@ int pc_ndhwc_to_ncdhw(const float* src, int ld, int N, int C, int64_t thw, float
 int pc_transpose_batched(const float* src, int batch, int R, int Cc, int64_t src_batch_stride,
                          int src_ld, float* dst, int64_t dst_batch_stride, int dst_ld, int accum,
                          pc_stream s);
+/* dx[n,h,w,c] (+)= sum over valid taps of cols[n, h-b, w-c'][(b*KW+c')*C + c]: gather half of an exact stride-1 'full'
+ * correlation (PrimaryCaps dgrad, capsules_ucf101.py:44-45 backward) computed as GEMM + col2im, so only the
+ * Ho*Wo real output positions are multiplied instead of the (Ho+KH-1)*(Wo+KW-1) gathered ones. */
+int pc_col2im(const float* cols, int N, int Ho, int Wo, int KH, int KW, int C, float* dx, int lddx,
+              int accum, pc_stream s);
 int pc_fill(float* p, int64_t n, float v, pc_stream s);
 int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
 
@@ -243,7 +248,7 @@ enum {
     PC_OP_POOL_FWD, PC_OP_POOL_BWD, PC_OP_CHSCALE, PC_OP_ACT_BWD, PC_OP_TO_NDHWC, PC_OP_TO_NCDHW,
     PC_OP_TRANSPOSE, PC_OP_FILL, PC_OP_AXPY, PC_OP_EM_FWD, PC_OP_EM_BWD, PC_OP_CMASK_FWD,
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
-    PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS,
+    PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS, PC_OP_COL2IM,
     PC_OP__COUNT
 };
 int pc_run_ops(const pc_op* ops, int n, pc_stream s);

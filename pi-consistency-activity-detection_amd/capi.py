@@ -39,7 +39,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
 
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
- OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS) = range(1, 28)
+ OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM) = range(1, 29)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST = 1, 2, 4, 8, 16
@@ -63,6 +63,7 @@ _SIGS = {
     "pc_ncdhw_to_ndhwc": (i32, [vp, i32, i32, i32, i64, i32, i32, i32, vp, vp]),
     "pc_ndhwc_to_ncdhw": (i32, [vp, i32, i32, i32, i64, vp, vp]),
     "pc_transpose_batched": (i32, [vp, i32, i32, i32, i64, i32, vp, i64, i32, i32, vp]),
+    "pc_col2im": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
     "pc_fill": (i32, [vp, i64, f32, vp]),
     "pc_axpy": (i32, [vp, vp, i64, f32, vp]),
     "pc_em_ws_floats": (i64, [i32, i32, i32]),

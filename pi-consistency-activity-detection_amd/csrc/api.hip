@@ -101,6 +101,8 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_TAIL_GRADS:
             return pc_tail_grads(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), P(const float*, 4), P(const float*, 5),
                                  op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), op.i[6], s);
+        case PC_OP_COL2IM:
+            return pc_col2im(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 1), op.i[6], op.i[7], s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

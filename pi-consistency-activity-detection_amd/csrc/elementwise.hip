@@ -372,6 +372,31 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     }
 }
 
+// dx[n,h,w,c] (+)= sum_{b,c'} cols[n, h-b, w-c'][(b*KW+c')*C + c]   (valid (h-b, w-c') only): the gather half of an exact
+// 'full' 2-D correlation computed as GEMM (cols = dY x W^T, one column block per tap) + col2im.
+__global__ __launch_bounds__(256) void col2im_kernel(const float* __restrict__ cols, int N, int Ho, int Wo, int KH, int KW, int C4,
+                                                     float* __restrict__ dx, int lddx, int accum, int64_t total4) {
+    const int Hi = Ho + KH - 1, Wi = Wo + KW - 1, C = C4 * 4;
+    const size_t ldc = (size_t)KH * KW * C;
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
+        int64_t pos = idx / C4;
+        const int c = (int)(idx - pos * C4) * 4;
+        const int64_t ipos = pos;
+        const int w = (int)(pos % Wi); pos /= Wi;
+        const int h = (int)(pos % Hi); const int n = (int)(pos / Hi);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int b0 = max(0, h - (Ho - 1)), b1 = min(KH - 1, h), c0 = max(0, w - (Wo - 1)), c1 = min(KW - 1, w);
+        for (int b = b0; b <= b1; ++b)
+            for (int cc = c0; cc <= c1; ++cc) {
+                const size_t op = (size_t)((n * Ho + (h - b)) * Wo + (w - cc));
+                acc += *(const f32x4*)(cols + op * ldc + (size_t)(b * KW + cc) * C + c);
+            }
+        float* o = dx + ipos * lddx + c;
+        if (accum) acc += *(const f32x4*)o;
+        *(f32x4*)o = acc;
+    }
+}
+
 inline int grid_for(int64_t n, int per_thread = 1) {
     int64_t b = (n + 256ll * per_thread - 1) / (256ll * per_thread);
     if (b > 256 * 16) b = 256 * 16;
@@ -521,6 +546,14 @@ extern "C" int pc_transpose_batched(const float* src, int batch, int R, int Cc, 
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), batch), dim3(256), 0, (hipStream_t)s, src, R, Cc, src_batch_stride,
                        src_ld, dst, dst_batch_stride, dst_ld, accum);
     PC_CHECK_LAUNCH("transpose");
+    return PC_OK;
+}
+
+extern "C" int pc_col2im(const float* cols, int N, int Ho, int Wo, int KH, int KW, int C, float* dx, int lddx, int accum, pc_stream s) {
+    PC_CHECK_ARG(cols && dx && C % 4 == 0 && lddx % 4 == 0, "pc_col2im: bad args");
+    const int64_t total4 = (int64_t)N * (Ho + KH - 1) * (Wo + KW - 1) * (C / 4);
+    hipLaunchKernelGGL(col2im_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, cols, N, Ho, Wo, KH, KW, C / 4, dx, lddx, accum, total4);
+    PC_CHECK_LAUNCH("col2im");
     return PC_OK;
 }
 

@@ -383,6 +383,9 @@ class Plan:
         npose = spec.IN_CAPS * spec.POSE
         caps_in = self.tensor(N, (1, s20, s20), npose + spec.IN_CAPS, "caps_in")
         wpc = self.prep_conv_weight(["primary_caps.pose.weight", "primary_caps.a.weight"], [npose, spec.IN_CAPS], xd.C, (1, KP, KP), True)
+        wpc["tio"] = self.alloc(KP * KP * xd.C * (npose + spec.IN_CAPS))       # [tap][ci][co]: GEMM weights of the col2im dgrad
+        self.emit(capi.OP_TRANSPOSE, i=[1, npose + spec.IN_CAPS, KP * KP * xd.C, KP * KP * xd.C, npose + spec.IN_CAPS, 0], l=[0, 0],
+                  p=[wpc["fwd"], wpc["tio"]], lst="prep")
         pc_bias = self.alloc(npose + spec.IN_CAPS)
         self.emit(capi.OP_TRANSPOSE, i=[1, 1, npose, npose, 1, 0], l=[0, 0], p=[self.P("primary_caps.pose.bias"), pc_bias], lst="prep")
         self.emit(capi.OP_TRANSPOSE, i=[1, 1, spec.IN_CAPS, spec.IN_CAPS, 1, 0], l=[0, 0], p=[self.P("primary_caps.a.bias"), off(pc_bias, npose)], lst="prep")
@@ -424,12 +427,20 @@ class Plan:
             self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
             dx, acc = self.grad_for_write(xd)
-            self.alg_dgrad(2 * caps_in.rows * caps_in.C * xd.C * KP * KP)
-            for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
-                                           flags=(capi.F_ACCUM if acc else 0) | capi.F_NFAST, ldw=caps_in.C):
-                # (splitting W into 8-wide zones so tiles align with (h, 8w, N) patches was measured SLOWER: 4 launches of
-                # 182-364 blocks under-fill the chip; the in-kernel tap box on the un-split launch is kept)
-                self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
+            F_pc = 2 * caps_in.rows * caps_in.C * xd.C * KP * KP
+            if xd.thw[0] == 1 and caps_in.thw[1] + KP - 1 == xd.thw[1]:
+                # exact 'full' correlation as GEMM + col2im: cols[o][(tap, ci)] = dcaps[o][:] . W[:, tap, ci] over the
+                # 20x20 real output positions only (the gather form multiplies 28x28 positions x 81 taps: 2x the FLOPs)
+                cols = self.alloc(caps_in.rows * KP * KP * xd.C)
+                dg = D.conv_fwd(N, caps_in.thw, caps_in.C, dcaps.ld, KP * KP * xd.C, KP * KP * xd.C, (1, 1, 1), (1, 1, 1), (0, 0, 0),
+                                caps_in.thw, ldw=caps_in.C)
+                self.conv_op(dg, dcaps.ref, wpc["tio"], cols, alg=F_pc)
+                self.emit(capi.OP_COL2IM, i=[N, caps_in.thw[1], caps_in.thw[2], KP, KP, xd.C, dx.ld, int(acc)], p=[cols, dx.ref])
+            else:
+                self.alg_dgrad(F_pc)
+                for dd in D.transposed_classes(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, dx.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0),
+                                               flags=(capi.F_ACCUM if acc else 0) | capi.F_NFAST, ldw=caps_in.C):
+                    self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
         self.tape.append(bwd_caps)
         # decoder (capsules_ucf101.py:486-510)
         cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")

@@ -486,3 +486,24 @@ def test_collapsed_tail_kernels_vs_torch():
     F.conv_transpose3d(F.conv_transpose3d(xr, W4.detach(), b4.detach(), stride=2, padding=1, output_padding=1) * cs.view(N, Co, 1, 1, 1),
                        Wp.detach(), bp.detach(), padding=1).backward(dout)
     close(uncl(dx), xr.grad, what="collapsed dgrad")
+
+
+def test_full_correlation_as_gemm_plus_col2im():
+    """PrimaryCaps dgrad form: cols = dY x W^T (1x1 conv with Co = taps*Ci) then pc_col2im == conv2d dgrad."""
+    g = torch.Generator().manual_seed(14)
+    N, Ci, Co, K, Ho = 3, 32, 64, 5, 6
+    x = torch.randn(N, Ci, Ho + K - 1, Ho + K - 1, generator=g, requires_grad=True)
+    w = torch.randn(Co, Ci, K, K, generator=g) * 0.1
+    y = F.conv2d(x, w)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    # weights [tap][ci][co]
+    wt = w.reshape(Co, Ci, K * K).permute(2, 1, 0).contiguous().to(DEV)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().to(DEV).view(N, 1, Ho, Ho, Co)
+    cols = torch.empty(N, 1, Ho, Ho, K * K * Ci, device=DEV)
+    ops.conv_fwd(desc.conv_fwd(N, (1, Ho, Ho), Co, Co, K * K * Ci, K * K * Ci, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, Ho, Ho), ldw=Co), dyg, wt, cols)
+    dx = torch.full((N, Ho + K - 1, Ho + K - 1, Ci), 1.5, device=DEV)
+    capi.call("pc_col2im", ops.ptr(cols), N, Ho, Ho, K, K, Ci, ops.ptr(dx), Ci, 0, ops.stream())
+    close(dx.permute(0, 3, 1, 2).cpu(), x.grad, what="col2im dgrad")
+    capi.call("pc_col2im", ops.ptr(cols), N, Ho, Ho, K, K, Ci, ops.ptr(dx), Ci, 1, ops.stream())
+    close(dx.permute(0, 3, 1, 2).cpu(), 2 * x.grad, what="col2im accumulate")
