@@ -586,7 +586,7 @@ struct WgK {
     int P, Ntot, chunks_per_split, nchunks;
 };
 
-template <int BM, int BN>
+template <int BM, int BN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -673,9 +673,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     __syncthreads();
     const int ml = wm * (BM / 2) + (lane & 31), nl = wn * (BN / 2) + (lane & 31), kh = lane >> 5;
     for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        ptab_fill(c + 2);
-        if (c + 1 < c_end) gload(c + 1, buf ^ 1);
+        const int buf = ABL ? 0 : ((c - c_begin) & 1);
+        if (!ABL) ptab_fill(c + 2);
+        if (!ABL && c + 1 < c_end) gload(c + 1, buf ^ 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float af[TM], bf[TN];
@@ -748,7 +748,11 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     splitk = cdiv(k.nchunks, k.chunks_per_split);
     PC_CHECK_ARG(ntl <= 65535, "pc_conv_wgrad: too many column tiles");
     dim3 grid(mt, ntl, splitk);
-    if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, k);
+    static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic: no tile fetch in the K loop (wrong results)
+    if (abl) {
+        if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, k);
+    } else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, k);
     else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, k);
     PC_CHECK_LAUNCH("wgrad_kernel");
     return PC_OK;
