@@ -65,6 +65,19 @@ __device__ __forceinline__ float vote(const float* WT, const f32x4 prow, int i, 
     return prow[0] * w[0] + prow[1] * w[1] + prow[2] * w[2] + prow[3] * w[3];
 }
 
+// segment reductions over W consecutive lanes (W = 2 or 8, segments aligned): used to spread the per-capsule scalar
+// reductions (sum over c for one i, sum over i for one c) over all threads instead of 24-32 serial lanes
+template <int W> __device__ __forceinline__ float seg_sum(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+template <int W> __device__ __forceinline__ float seg_max(float v) {
+#pragma unroll
+    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
 // NW cooperating waves work on ONE position: wave wv owns input capsules [wv*NB/NW, (wv+1)*NB/NW); sums over i
 // are combined through `red` ([NW][MAXC*16] floats per quantity).  NW == 1: a single wave, no block barrier.
 template <int NW>
@@ -96,13 +109,17 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
     const int lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
     const int i0 = wv * (NB / NW), i1 = i0 + NB / NW;
+    constexpr int RP = 64 * NW / NB;           // lanes per input capsule in the row-parallel sections (2 or 8)
+    constexpr int CPT = NW == 1 ? 2 : 8;       // lanes per output capsule in the column-parallel sections
     for (int t = 0; t < 3; ++t) {
         // ---- M-step (capsules_ucf101.py:127-152)
-        if (tid < NB) {
-            const float ai = st->a[tid];
+        {   // S_i = sum_c r[i][c]*a_i : RP lanes per input capsule
+            const int i = tid / RP, part = tid % RP;
+            const float ai = st->a[i];
             float S = 0.f;
-            for (int c = 0; c < C; ++c) S += Rt(st, t, tid, c, C) * ai;
-            st->invS[t][tid] = 1.0f / (S + EPS);
+            for (int c = part; c < C; c += RP) S += Rt(st, t, i, c, C) * ai;
+            S = seg_sum<RP>(S);
+            if (part == 0) st->invS[t][i] = 1.0f / (S + EPS);
         }
         SYNC<NW>();
         for (int e = tid; e < NB * C; e += 64 * NW) {
@@ -110,10 +127,12 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             st->rn[i][c] = Rt(st, t, i, c, C) * st->a[i] * st->invS[t][i];
         }
         SYNC<NW>();
-        if (tid < C) {
+        if (tid < C * CPT) {   // r_sum[c] = sum_i rn[i][c] : CPT lanes per output capsule
+            const int c = tid / CPT, part = tid % CPT;
             float s = 0.f;
-            for (int i = 0; i < NB; ++i) s += st->rn[i][tid];
-            st->rs[t][tid] = s;
+            for (int i = part; i < NB; i += CPT) s += st->rn[i][c];
+            s = seg_sum<CPT>(s);
+            if (part == 0) st->rs[t][c] = s;
         }
         SYNC<NW>();
         float m[CJ], sg[CJ], irs[CJ];
@@ -195,13 +214,16 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             }
         }
         SYNC<NW>();
-        if (tid < NB) {   // softmax over c
+        {   // softmax over c, RP lanes per input capsule
+            const int i = tid / RP, part = tid % RP;
             float mx = -INFINITY;
-            for (int c = 0; c < C; ++c) mx = fmaxf(mx, st->R[t][tid][c]);
+            for (int c = part; c < C; c += RP) mx = fmaxf(mx, st->R[t][i][c]);
+            mx = seg_max<RP>(mx);
             float s = 0.f;
-            for (int c = 0; c < C; ++c) { const float e = expf(st->R[t][tid][c] - mx); st->R[t][tid][c] = e; s += e; }
+            for (int c = part; c < C; c += RP) { const float e = expf(st->R[t][i][c] - mx); st->R[t][i][c] = e; s += e; }
+            s = seg_sum<RP>(s);
             const float inv = 1.0f / s;
-            for (int c = 0; c < C; ++c) st->R[t][tid][c] *= inv;
+            for (int c = part; c < C; c += RP) st->R[t][i][c] *= inv;
         }
         SYNC<NW>();
     }
@@ -266,6 +288,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
     const int i0 = wv * (NB / BW), i1 = i0 + NB / BW;
     constexpr int NT = 64 * BW;
+    constexpr int RP = NT / NB, CPT = 8;
     load_WT(WT, W, C, tid, NT);
     for (int e = tid; e < NB * MAXC * 16 + MAXC * 16 + 32; e += NT) dWacc[e] = 0.f;
     __syncthreads();
@@ -346,11 +369,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
             }
             __syncthreads();
             // ---- step C: co -> rn -> ra -> (R_t, a_in)
-            if (tid < C) {
-                const float irs = 1.0f / (st->rs[t][tid] + EPS);
+            if (tid < C * CPT) {
+                const int c = tid / CPT, part = tid % CPT;
+                const float irs = 1.0f / (st->rs[t][c] + EPS);
                 float T = 0.f;
-                for (int i = 0; i < NB; ++i) T += bs->dco[i][tid] * st->rn[i][tid] * irs * irs;
-                bs->drs[tid] -= T;
+                for (int i = part; i < NB; i += CPT) T += bs->dco[i][c] * st->rn[i][c] * irs * irs;
+                T = seg_sum<CPT>(T);
+                if (part == 0) bs->drs[c] -= T;
             }
             __syncthreads();
             for (int e = tid; e < NB * C; e += NT) {     // dco now holds drn
@@ -358,31 +383,37 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
                 bs->dco[i][c] = bs->dco[i][c] / (st->rs[t][c] + EPS) + bs->drs[c];
             }
             __syncthreads();
-            if (tid < NB) {                               // ... and then dR_t (in place)
-                const float iS = st->invS[t][tid], ai = st->a[tid];
+            {                                             // ... and then dR_t (in place): RP lanes per input capsule
+                const int i = tid / RP, part = tid % RP;
+                const float iS = st->invS[t][i], ai = st->a[i];
                 float dot = 0.f;
-                for (int c = 0; c < C; ++c) dot += bs->dco[tid][c] * st->rn[tid][c];
+                for (int c = part; c < C; c += RP) dot += bs->dco[i][c] * st->rn[i][c];
+                dot = seg_sum<RP>(dot);
                 const float dS = -dot * iS;
-                float dai = 0.f;
-                for (int c = 0; c < C; ++c) {
-                    const float dra = bs->dco[tid][c] * iS + dS;
-                    dai += dra * Rt(st, t, tid, c, C);
-                    bs->dco[tid][c] = dra * ai;
+                float dai = 0.f, dot2 = 0.f;
+                for (int c = part; c < C; c += RP) {
+                    const float dra = bs->dco[i][c] * iS + dS;
+                    dai += dra * Rt(st, t, i, c, C);
+                    const float dR = dra * ai;
+                    bs->dco[i][c] = dR;
+                    if (t > 0) dot2 += st->R[t - 1][i][c] * dR;
                 }
-                bs->da_in[tid] += dai;
+                dai = seg_sum<RP>(dai);
+                if (part == 0) bs->da_in[i] += dai;
                 if (t > 0) {
                     // ---- step D(i): E-step (t-1) backward from dR_t  (capsules_ucf101.py:176-181)
-                    float dot2 = 0.f;
-                    for (int c = 0; c < C; ++c) dot2 += st->R[t - 1][tid][c] * bs->dco[tid][c];
-                    for (int c = 0; c < C; ++c) bs->dlnp[t - 1][tid][c] = st->R[t - 1][tid][c] * (bs->dco[tid][c] - dot2);
+                    dot2 = seg_sum<RP>(dot2);
+                    for (int c = part; c < C; c += RP) bs->dlnp[t - 1][i][c] = st->R[t - 1][i][c] * (bs->dco[i][c] - dot2);
                 }
             }
             __syncthreads();
             if (t == 0) break;
-            if (tid < C) {
+            if (tid < C * CPT) {
+                const int c = tid / CPT, part = tid % CPT;
                 float s = 0.f;
-                for (int i = 0; i < NB; ++i) s += bs->dlnp[t - 1][i][tid];
-                bs->da_out[tid] = s / (EPS + st->aout[t - 1][tid]);
+                for (int i = part; i < NB; i += CPT) s += bs->dlnp[t - 1][i][c];
+                s = seg_sum<CPT>(s);
+                if (part == 0) bs->da_out[c] = s / (EPS + st->aout[t - 1][c]);
             }
             {
                 float am[CJ], as2[CJ], muv[CJ], is2[CJ];

@@ -592,7 +592,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     static_assert(TM >= 1 && TN >= 1, "tile");
     __shared__ __attribute__((aligned(16))) float Ds[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Ss[2][BK][BN];
-    __shared__ int2 ptab[3][BK];                     // per chunk, per position: {per-dim tap-validity bit masks, linear base index}
+    __shared__ int4 ptab[3][BK];                     // per chunk: n, t0, h0, w0 of its 32 positions
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -611,30 +611,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     const int tap = nval ? ncol / p.Cs : 0, cs = ncol - tap * p.Cs;
     const int tapHW = p.ntap[1] * p.ntap[2];
     const int a_ = tap / tapHW, rem = tap - a_ * tapHW, b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
+    const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
     const bool mval = (m0 + dcol) < p.Cd;
-    // this thread's tap as a mask selector and as a linear position delta in S
-    const unsigned sel = nval ? ((1u << a_) | (1u << (10 + b_)) | (1u << (20 + c_))) : 0xffffffffu;
-    const int sdelta = (a_ * p.istep[0] * p.Hs + b_ * p.istep[1]) * p.Ws + c_ * p.istep[2];
-    const float* sbase = p.S + cs;
-    const float* dbase = p.D + m0 + dcol;
+    (void)rem;
 
     auto ptab_fill = [&](int c) {
         if (tid < BK) {
             const int pos = c * BK + tid;
-            int2 e = make_int2(0, 0);
+            int4 info = make_int4(-1, 0, 0, 0);
             if (c < c_end && pos < p.P) {
                 int m = pos;
                 const int wq = m % p.Wq; m /= p.Wq;
                 const int hq = m % p.Hq; m /= p.Hq;
                 const int tq = m % p.Tq; const int n = m / p.Tq;
-                const int t0 = tq * p.istr[0] + p.ioff0[0], h0 = hq * p.istr[1] + p.ioff0[1], w0 = wq * p.istr[2] + p.ioff0[2];
-                unsigned mk = 0;
-                for (int a = 0; a < p.ntap[0]; ++a) mk |= ((unsigned)(t0 + a * p.istep[0]) < (unsigned)p.Ts ? 1u : 0u) << a;
-                for (int a = 0; a < p.ntap[1]; ++a) mk |= ((unsigned)(h0 + a * p.istep[1]) < (unsigned)p.Hs ? 1u : 0u) << (10 + a);
-                for (int a = 0; a < p.ntap[2]; ++a) mk |= ((unsigned)(w0 + a * p.istep[2]) < (unsigned)p.Ws ? 1u : 0u) << (20 + a);
-                e = make_int2((int)mk, ((n * p.Ts + t0) * p.Hs + h0) * p.Ws + w0);
+                info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1],
+                                 wq * p.istr[2] + p.ioff0[2]);
             }
-            ptab[c % 3][tid] = e;
+            ptab[c % 3][tid] = info;
         }
     };
     constexpr int DN = BK / DRP, SN = BK / SRP;        // loads per thread
@@ -644,19 +637,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     auto gload = [&](int c, int buf) {
         float* ld = &Ds[buf][0][0] + wave * 256;      // wave-uniform base; the DMA adds lane*16 B
         float* ls = &Ss[buf][0][0] + wave * 256;
-        const float* dchunk = dbase + (size_t)c * BK * p.ldd;
-        const bool full = (c + 1) * BK <= p.P;
 #pragma unroll
         for (int j = 0; j < DN; ++j) {
             const int r = drow0 + DRP * j;
-            const bool v = mval && (full || c * BK + r < p.P);
-            glds16(v ? dchunk + (size_t)r * p.ldd : g_zero16, ld + j * 1024);
+            const int pos = c * BK + r;
+            const bool v = mval && pos < p.P;
+            const float* src = v ? p.D + (size_t)pos * p.ldd + m0 + dcol : g_zero16;
+            glds16(src, ld + j * 1024);
         }
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
-            const int2 e = ptab[c % 3][srow0 + SRP * j];
-            const bool v = ((unsigned)e.x & sel) == sel;
-            glds16(v ? sbase + (size_t)(e.y + sdelta) * p.lds : g_zero16, ls + j * 1024);
+            const int r = srow0 + SRP * j;
+            const int4 info = ptab[c % 3][r];
+            const int t = info.y + dt, h = info.z + dh, w = info.w + dw;
+            const bool v = nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
+                           (unsigned)w < (unsigned)p.Ws;
+            const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
+            const float* src = v ? p.S + ps * p.lds + cs : g_zero16;
+            glds16(src, ls + j * 1024);
         }
     };
 
@@ -726,7 +724,6 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
     k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
     for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; }
-    PC_CHECK_ARG(d->ntap[0] <= 10 && d->ntap[1] <= 10 && d->ntap[2] <= 10, "pc_conv_wgrad: at most 10 taps per dimension");
     PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
     k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
