@@ -359,19 +359,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         if (!(VAR & 2) && c + 1 < nchunks) fetch(buf ^ 1);
         const float* a = As + buf * BM * BK;
         const float* b = Bs + buf * BN * BK;
-        f32x4 af[2][TM], bf[2][TN];
-        auto ldfrag = [&](int ks, int set) {
-            const int q = ks * 2 + kh;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[set][i] = *(const f32x4*)(a + aoff[i] + ((q ^ asw[i]) << 2));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[set][j] = *(const f32x4*)(b + boff[j] + ((q ^ bsw[j]) << 2));
-        };
-        ldfrag(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) ldfrag(ks + 1, (ks + 1) & 1);      // next fragments in flight behind this group's 16 MFMAs
-            __builtin_amdgcn_sched_barrier(0);
+            f32x4 af[TM], bf[TN];
+            const int q = ks * 2 + kh;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *(const f32x4*)(a + aoff[i] + ((q ^ asw[i]) << 2));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + boff[j] + ((q ^ bsw[j]) << 2));
             if (VAR & 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -379,9 +374,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i][e], bf[ks & 1][j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
             if (VAR & 1) __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_sched_barrier(0);
             if ((VAR & 2) && ks == 0 && c + 1 < nchunks) fetch(buf ^ 1);   // issue the next tile's DMA behind the first MFMA group
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
@@ -682,27 +676,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
         const int buf = ABL ? 0 : ((c - c_begin) & 1);
         if (!ABL) ptab_fill(c + 2);
         if (!ABL && c + 1 < c_end) gload(c + 1, buf ^ 1);
-        // operands of k-step ks+2 are read from LDS before the MFMAs of k-step ks issue (3 register sets), so the
-        // ds_read latency is never exposed behind a 4-MFMA group
-        float af[3][TM], bf[3][TN];
-        auto ldfrag = [&](int ks, int set) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[set][i] = Ds[buf][ks * 2 + kh][ml + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[set][j] = Ss[buf][ks * 2 + kh][nl + j * 32];
-        };
-        ldfrag(0, 0);
-        ldfrag(1, 1);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            if (ks + 2 < BK / 2) ldfrag(ks + 2, (ks + 2) % 3);
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this group's MFMAs (hipcc otherwise sinks it)
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][ks * 2 + kh][ml + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][ks * 2 + kh][nl + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks % 3][i], bf[ks % 3][j], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
     }
