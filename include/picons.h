@@ -240,6 +240,7 @@ typedef struct pc_op {
     int32_t  kind;                  /* PC_OP_* */
     int32_t  i[48];
     float    f[8];
+    int32_t  lane;                  /* which of the runner's streams the op is enqueued on (0 = main) */
     uint64_t p[12];                 /* device pointers */
     int64_t  l[4];
 } pc_op;
@@ -249,12 +250,21 @@ enum {
     PC_OP_TRANSPOSE, PC_OP_FILL, PC_OP_AXPY, PC_OP_EM_FWD, PC_OP_EM_BWD, PC_OP_CMASK_FWD,
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
     PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS, PC_OP_COL2IM,
+    PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */
+    PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP__COUNT
 };
+#define PC_MAX_LANES 8
+/* Replays the list on one stream (lane tags ignored: FORK/JOIN are no-ops, order = list order). */
 int pc_run_ops(const pc_op* ops, int n, pc_stream s);
-/* same, with a hipEvent pair recorded around every op of `kind` on stream s; returns elapsed
- * ms summed over those ops in *ms and their count in *count (bench.py roofline leg). */
-int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, pc_stream s);
+/* Replays the list over `nlanes` HIP streams: op k is enqueued on lanes[ops[k].lane]; the independent
+ * branches of an Inception module (pytorch_i3d.py:149-154) and their backward run concurrently between
+ * a FORK and the matching JOIN.  Lanes >= nlanes fold onto lane 0.  Every list must end joined. */
+int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes);
+/* same, with a hipEvent pair recorded around every op of `kind` on the stream that op runs on;
+ * returns elapsed ms summed over those ops in *ms and their count in *count (bench.py roofline
+ * leg).  Synchronises all lanes before returning. */
+int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes);
 
 #ifdef __cplusplus
 }

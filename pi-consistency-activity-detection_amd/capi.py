@@ -33,13 +33,15 @@ class LossDesc(C.Structure):
                [(n, f32) for n in ("lower_thresh", "upper_thresh", "bv_wt", "gv_wt", "wt_loc", "wt_cons", "wt_ramp")]
 
 
-# numpy mirror of struct pc_op (kind, i[48], f[8], p[12], l[4]) -- 4+192+32 = 228 -> padded to 232
-OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 8), ("_pad", np.int32),
+# numpy mirror of struct pc_op (kind, i[48], f[8], lane, p[12], l[4])
+OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 8), ("lane", np.int32),
                      ("p", np.uint64, 12), ("l", np.int64, 4)], align=False)
 
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
- OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM) = range(1, 29)
+ OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
+ OP_FORK, OP_JOIN) = range(1, 31)
+MAX_LANES = 8
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST = 1, 2, 4, 8, 16
@@ -83,7 +85,8 @@ _SIGS = {
     "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
     "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "pc_run_ops": (i32, [vp, i32, vp]),
-    "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp]),
+    "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),
+    "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp, i32]),
 }
 EXPORTS = sorted(_SIGS)
 

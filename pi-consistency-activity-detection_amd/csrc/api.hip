@@ -109,41 +109,76 @@ static int run_one(const pc_op& op, pc_stream s) {
     }
 }
 
-extern "C" int pc_run_ops(const pc_op* ops, int n, pc_stream s) {
+// Per-thread event pool for FORK/JOIN (timing disabled: they only order streams).
+static thread_local hipEvent_t g_ev[PC_MAX_LANES];
+static thread_local bool g_ev_init = false;
+
+static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes, int kind, float* ms, int* count) {
     if (!ops && n > 0) { pc_set_error("pc_run_ops: null ops"); return PC_E_ARG; }
-    for (int k = 0; k < n; ++k) {
-        const int rc = run_one(ops[k], s);
-        if (rc != PC_OK) {
-            char tmp[400];
-            snprintf(tmp, sizeof(tmp), "%s", g_err);
-            pc_set_error("op %d (kind %d): %s", k, ops[k].kind, tmp);
-            return rc;
-        }
+    if (nlanes < 1 || nlanes > PC_MAX_LANES || !lanes) { pc_set_error("pc_run_ops: nlanes=%d (1..%d)", nlanes, PC_MAX_LANES); return PC_E_ARG; }
+    if (nlanes > 1 && !g_ev_init) {
+        for (int i = 0; i < PC_MAX_LANES; ++i)
+            if (hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming) != hipSuccess) { pc_set_error("hipEventCreate failed"); return PC_E_LAUNCH; }
+        g_ev_init = true;
     }
-    return PC_OK;
+    int cnt = 0;
+    hipEvent_t* ev = nullptr;
+    if (kind > 0) {
+        for (int k = 0; k < n; ++k) cnt += ops[k].kind == kind;
+        ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (cnt > 0 ? cnt : 1));
+        for (int i = 0; i < 2 * cnt; ++i) (void)hipEventCreate(&ev[i]);
+    }
+    int j = 0, rc = PC_OK, k = 0;
+    for (; k < n && rc == PC_OK; ++k) {
+        const pc_op& op = ops[k];
+        if (op.kind == PC_OP_FORK || op.kind == PC_OP_JOIN) {
+            if (nlanes == 1) continue;
+            const bool fork = op.kind == PC_OP_FORK;
+            if (fork) (void)hipEventRecord(g_ev[0], (hipStream_t)lanes[0]);
+            for (int q = 1; q < nlanes; ++q) {
+                if (!((op.i[0] >> q) & 1)) continue;
+                if (fork) {
+                    (void)hipStreamWaitEvent((hipStream_t)lanes[q], g_ev[0], 0);
+                } else {
+                    (void)hipEventRecord(g_ev[q], (hipStream_t)lanes[q]);
+                    (void)hipStreamWaitEvent((hipStream_t)lanes[0], g_ev[q], 0);
+                }
+            }
+            continue;
+        }
+        const int ln = (op.lane > 0 && op.lane < nlanes) ? op.lane : 0;
+        const pc_stream s = lanes[ln];
+        const bool t = kind > 0 && op.kind == kind;
+        if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
+        rc = run_one(op, s);
+        if (t) { (void)hipEventRecord(ev[2 * j + 1], (hipStream_t)s); ++j; }
+    }
+    if (rc != PC_OK) {
+        char tmp[400];
+        snprintf(tmp, sizeof(tmp), "%s", g_err);
+        pc_set_error("op %d (kind %d): %s", k - 1, ops[k - 1].kind, tmp);
+    }
+    if (kind > 0) {
+        for (int q = 0; q < nlanes; ++q) (void)hipStreamSynchronize((hipStream_t)lanes[q]);
+        float total = 0.f;
+        for (int i = 0; i < j; ++i) { float e = 0.f; (void)hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]); total += e; }
+        for (int i = 0; i < 2 * cnt; ++i) (void)hipEventDestroy(ev[i]);
+        free(ev);
+        if (ms) *ms = total;
+        if (count) *count = j;
+    }
+    return rc;
 }
 
-// Times every op of `kind` with a hipEvent pair on the SAME stream the kernels run on
+extern "C" int pc_run_ops(const pc_op* ops, int n, pc_stream s) { return run_list(ops, n, &s, 1, 0, nullptr, nullptr); }
+
+extern "C" int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes) {
+    return run_list(ops, n, lanes, nlanes, 0, nullptr, nullptr);
+}
+
+// Times every op of `kind` with a hipEvent pair on the SAME stream that op's kernels run on
 // (torch.cuda.Event would only see torch's current stream).  Synchronises at the end.
-extern "C" int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, pc_stream s_) {
-    hipStream_t s = (hipStream_t)s_;
-    int cnt = 0;
-    for (int k = 0; k < n; ++k) cnt += ops[k].kind == kind;
-    hipEvent_t* ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (cnt > 0 ? cnt : 1));
-    for (int i = 0; i < 2 * cnt; ++i) (void)hipEventCreate(&ev[i]);
-    int j = 0, rc = PC_OK;
-    for (int k = 0; k < n && rc == PC_OK; ++k) {
-        const bool t = ops[k].kind == kind;
-        if (t) (void)hipEventRecord(ev[2 * j], s);
-        rc = run_one(ops[k], s);
-        if (t) { (void)hipEventRecord(ev[2 * j + 1], s); ++j; }
-    }
-    (void)hipStreamSynchronize(s);
-    float total = 0.f;
-    for (int i = 0; i < j; ++i) { float e = 0.f; (void)hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]); total += e; }
-    for (int i = 0; i < 2 * cnt; ++i) (void)hipEventDestroy(ev[i]);
-    free(ev);
-    if (ms) *ms = total;
-    if (count) *count = j;
-    return rc;
+extern "C" int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes) {
+    if (kind <= 0) { pc_set_error("pc_run_ops_timed: kind=%d", kind); return PC_E_ARG; }
+    return run_list(ops, n, lanes, nlanes, kind, ms, count);
 }

@@ -207,13 +207,25 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-6, gscale=1.0):
     capi.call("pc_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, step, gscale, stream())
 
 
-def run_ops(ops_np, n=None):
-    """ops_np: numpy array of capi.OP_DTYPE (host memory); replayed by the library."""
+def _lane_array(side):
+    """(c_void_p array, n): torch's current stream as lane 0 + the caller's side streams."""
+    hs = [torch.cuda.current_stream().cuda_stream] + [st.cuda_stream for st in (side or ())]
+    return (C.c_void_p * len(hs))(*hs), len(hs)
+
+
+def run_ops(ops_np, n=None, side=None):
+    """ops_np: numpy array of capi.OP_DTYPE (host memory); replayed by the library.  side: extra
+    torch.cuda.Stream objects for the plan's lanes 1.. (None -> everything on the current stream)."""
     n = len(ops_np) if n is None else n
-    capi.call("pc_run_ops", C.c_void_p(ops_np.ctypes.data), n, stream())
+    if not side:
+        capi.call("pc_run_ops", C.c_void_p(ops_np.ctypes.data), n, stream())
+    else:
+        arr, nl = _lane_array(side)
+        capi.call("pc_run_ops_lanes", C.c_void_p(ops_np.ctypes.data), n, arr, nl)
 
 
-def run_ops_timed(ops_np, kind):
+def run_ops_timed(ops_np, kind, side=None):
     ms = C.c_float(0); cnt = C.c_int32(0)
-    capi.call("pc_run_ops_timed", C.c_void_p(ops_np.ctypes.data), len(ops_np), kind, C.byref(ms), C.byref(cnt), stream())
+    arr, nl = _lane_array(side)
+    capi.call("pc_run_ops_timed", C.c_void_p(ops_np.ctypes.data), len(ops_np), kind, C.byref(ms), C.byref(cnt), arr, nl)
     return ms.value, cnt.value

@@ -42,11 +42,17 @@ def off(ref, nfloats):
 
 
 class Plan:
-    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False):
+    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1):
         """n = clips per forward pass; the batch the kernels see is N = groups*n.
         accum_grads: backward adds into the flat G buffer instead of overwriting it (drop-in nn.Module path,
-        where the reference's two forward passes are two separate autograd graphs)."""
+        where the reference's two forward passes are two separate autograd graphs).
+        lanes: HIP streams the runner may use; >1 tags the four branches of every Inception module (and their
+        backward) onto separate lanes between FORK/JOIN ops, so the under-filled 14x14 launches overlap."""
         self.acc = 1 if accum_grads else 0
+        if not 1 <= lanes <= capi.MAX_LANES:
+            raise ValueError("lanes must be 1..%d" % capi.MAX_LANES)
+        self.lanes = lanes
+        self.lane = 0
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -102,7 +108,18 @@ class Plan:
 
     # ------------------------------------------------------------------ op emission
     def emit(self, kind, i=(), f=(), p=(), l=(), lst=None):
-        self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l)))
+        lane = self.lane if lst in (None, self.cur) else 0
+        self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l), lane))
+
+    def fork(self):
+        """Side lanes wait for everything enqueued on lane 0 so far (no-op for a single-lane plan)."""
+        if self.lanes > 1:
+            self.lists[self.cur].append((capi.OP_FORK, [(1 << self.lanes) - 2], [], [], [], 0))
+
+    def join(self):
+        """Lane 0 waits for everything enqueued on the side lanes."""
+        if self.lanes > 1:
+            self.lists[self.cur].append((capi.OP_JOIN, [(1 << self.lanes) - 2], [], [], [], 0))
 
     def grad_for_write(self, x):
         """Gradient buffer of x's (whole) buffer for a consumer's backward: (TR, accumulate?)."""
@@ -169,7 +186,7 @@ class Plan:
         """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
         wgrad so a gradient bucket is final (all-reduce can start) as early as possible."""
         for nm, op in w["unprep"]:
-            self.lists[self.cur].append(op)
+            self.lists[self.cur].append(op + (self.lane,))
             self.mark_final(nm)
 
     def mark_final(self, *names):
@@ -212,17 +229,23 @@ class Plan:
             g_apply = 1
         self.emit(capi.OP_BN_APPLY, i=[z.ld, cout, g_apply, y.ld, 1], l=[z.rows], p=[z.ref, stat, y.ref])
 
-        def bwd():
-            dy = self.grad_of(y)
-            dz = self.tensor(x.N, othw, cout, pre + ".dz")
-            ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
-            self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
-                      p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf)), D.WGRAD_FIELDS),
-                      p=[dz.ref, x.ref, w["kg"]])
-            self.flush_grad(w)
-            self.mark_final(pre + ".bn.weight", pre + ".bn.bias")
-            if need_dx:
+        st = {}
+
+        def bwd(part="all"):
+            """part "A": BN backward + wgrad (touches only this unit's buffers); part "B": dgrad into the
+            input's gradient (shared by every consumer of x, so Inception serialises it on lane 0)."""
+            if part in ("all", "A"):
+                dy = self.grad_of(y)
+                dz = st["dz"] = self.tensor(x.N, othw, cout, pre + ".dz")
+                ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
+                self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
+                          p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
+                self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf)), D.WGRAD_FIELDS),
+                          p=[dz.ref, x.ref, w["kg"]])
+                self.flush_grad(w)
+                self.mark_final(pre + ".bn.weight", pre + ".bn.bias")
+            if need_dx and part in ("all", "B"):
+                dz = st["dz"]
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd)
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
@@ -247,15 +270,41 @@ class Plan:
         return y
 
     def inception(self, pre, x, oc):
+        """InceptionModule (pytorch_i3d.py:123-154): four branches off x, channel-concatenated (free here:
+        each branch's last BN-apply writes its slice of `out`).  The branches share nothing but x, so a
+        multi-lane plan puts each on its own stream, forward and backward."""
         out = self.tensor(x.N, x.thw, oc[0] + oc[2] + oc[4] + oc[5], pre + ".out")
-        c0 = 0
-        self.unit3d(pre + ".b0", x, oc[0], (1, 1, 1), (1, 1, 1), out=out.slice(c0, oc[0])); c0 += oc[0]
-        t1 = self.unit3d(pre + ".b1a", x, oc[1], (1, 1, 1), (1, 1, 1))
-        self.unit3d(pre + ".b1b", t1, oc[2], (3, 3, 3), (1, 1, 1), out=out.slice(c0, oc[2])); c0 += oc[2]
-        t2 = self.unit3d(pre + ".b2a", x, oc[3], (1, 1, 1), (1, 1, 1))
-        self.unit3d(pre + ".b2b", t2, oc[4], (3, 3, 3), (1, 1, 1), out=out.slice(c0, oc[4])); c0 += oc[4]
-        t3 = self.maxpool(x, (3, 3, 3), (1, 1, 1), pre + ".pool")
-        self.unit3d(pre + ".b3b", t3, oc[5], (1, 1, 1), (1, 1, 1), out=out.slice(c0, oc[5]))
+        c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
+        outer, self.tape = self.tape, []
+        L = lambda j: j % self.lanes
+        one = (1, 1, 1)
+        self.fork()
+        self.lane = L(0)
+        t1 = self.unit3d(pre + ".b1a", x, oc[1], one, one)
+        self.unit3d(pre + ".b1b", t1, oc[2], (3, 3, 3), one, out=out.slice(c1, oc[2]))
+        self.lane = L(1)
+        t2 = self.unit3d(pre + ".b2a", x, oc[3], one, one)
+        self.unit3d(pre + ".b2b", t2, oc[4], (3, 3, 3), one, out=out.slice(c2, oc[4]))
+        self.lane = L(2)
+        t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
+        self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
+        self.lane = L(3)
+        self.unit3d(pre + ".b0", x, oc[0], one, one, out=out.slice(0, oc[0]))
+        self.lane = 0
+        self.join()
+        (b1a, b1b, b2a, b2b, pool, b3b, b0), self.tape = self.tape, outer
+
+        def bwd():
+            self.fork()
+            self.lane = L(0); b1b(); b1a("A")
+            self.lane = L(1); b2b(); b2a("A")
+            self.lane = L(2); b3b()
+            self.lane = L(3); b0("A")
+            self.lane = 0
+            self.join()
+            # the four writers of d(x): first overwrites, the rest accumulate -> one lane, in order
+            b0("B"); b1a("B"); b2a("B"); pool()
+        self.tape.append(bwd)
         return out
 
     def conv_bias_act(self, wname, x, cout, k, pad, act, out, act_c0=0, bias_ref=None, wkey=None):
@@ -542,9 +591,20 @@ class Plan:
         if missing:
             raise RuntimeError("no backward op finalises %s" % missing[:4])
         names = list(self.pshape)
+        # inside a FORK..JOIN region the side lanes may still be writing: a bucket is ready after the JOIN
+        snap, open_at = list(range(len(self.lists["bwd"]) + 1)), None
+        for idx, op in enumerate(self.lists["bwd"]):
+            if op[0] == capi.OP_FORK:
+                open_at = idx
+            elif op[0] == capi.OP_JOIN:
+                for r in range(open_at + 1, idx + 1):
+                    snap[r] = idx + 1
+                open_at = None
+        if open_at is not None:
+            raise RuntimeError("backward list ends with an open FORK")
         buckets, cur_end, cur_ready, cur_size = [], self.nparams, 0, 0
         for nm in reversed(names):              # backward finalises parameters roughly in reverse flat order
-            cur_ready = max(cur_ready, self.final_at[nm])
+            cur_ready = max(cur_ready, snap[self.final_at[nm]])
             cur_size = cur_end - self.poff[nm]
             if cur_size >= target_floats:
                 buckets.append((cur_ready, self.poff[nm], cur_end))
@@ -564,8 +624,9 @@ class Plan:
         out = {}
         for name, lst in self.lists.items():
             arr = np.zeros(len(lst), dtype=capi.OP_DTYPE)
-            for j, (kind, i, f, p, l) in enumerate(lst):
+            for j, (kind, i, f, p, l, lane) in enumerate(lst):
                 arr[j]["kind"] = kind
+                arr[j]["lane"] = lane
                 arr[j]["i"][:len(i)] = i
                 arr[j]["f"][:len(f)] = f
                 arr[j]["l"][:len(l)] = l
@@ -581,7 +642,7 @@ class Plan:
             return {name: self.alg_flops.get(name, 0) for name in self.lists}
         for name, lst in self.lists.items():
             s = 0
-            for kind, i, f, p, l in lst:
+            for kind, i, f, p, l, _lane in lst:
                 if only_kind is not None and kind != only_kind:
                     continue
                 if kind == capi.OP_CONV:

@@ -6,6 +6,7 @@ zero_grad/backward/Adam loop :171-190, with both forward passes batched and ever
 PyTorch is used for device memory, streams and (in dist.py) the RCCL collective only.
 """
 import ctypes as C
+import os
 from types import SimpleNamespace
 
 import numpy as np
@@ -35,7 +36,7 @@ def exp_rampup(rampup_length):
 
 
 class StepEngine:
-    def __init__(self, args, bs=8, hw=224, num_classes=24, device="cuda:0", jhmdb=False, state=None, seed=47):
+    def __init__(self, args, bs=8, hw=224, num_classes=24, device="cuda:0", jhmdb=False, state=None, seed=47, lanes=None):
         if not torch.cuda.is_available():
             raise RuntimeError("StepEngine needs a GPU: the hot path is HIP-only (no CPU fallback)")
         capi.lib()
@@ -46,7 +47,10 @@ class StepEngine:
         self.C = num_classes
         self.hw = hw
         self.jhmdb = jhmdb
-        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb)
+        if lanes is None:
+            lanes = int(os.environ.get("PICONS_LANES", "4"))
+        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
+        self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         p.build_forward()
         p.build_loss(args)
         p.build_backward()
@@ -146,9 +150,9 @@ class StepEngine:
 
         def run(arr):
             if timed_kind is None or len(arr) == 0:
-                ops.run_ops(arr)
+                ops.run_ops(arr, side=self.side)
             else:
-                ms, cnt = ops.run_ops_timed(arr, timed_kind)
+                ms, cnt = ops.run_ops_timed(arr, timed_kind, side=self.side)
                 self.kind_ms += ms
                 self.kind_count += cnt
         run(o["prep"])

@@ -1,0 +1,88 @@
+"""CPU: structure of a multi-lane plan (the Inception branches on separate HIP streams between
+FORK/JOIN ops).  The runner trusts the plan, so the plan's invariants are checked here:
+balanced regions, lane tags only inside them, no buffer written by one lane and touched by
+another inside a region, gradient buckets ready only at joined points, and the same op multiset
+as the single-lane plan."""
+import collections
+
+import pytest
+
+from picons_amd import capi, step as pstep
+from picons_amd.plan import Plan
+
+# p[] slots each op kind writes (the kinds that may appear inside a FORK..JOIN region)
+WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4, 5), capi.OP_BN_APPLY: (2,),
+          capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_TRANSPOSE: (1,),
+          capi.OP_FILL: (0,), capi.OP_BN_EVAL_STAT: (4,)}
+
+
+def _plan(lanes, bs=1, hw=112):
+    args = pstep.default_args(bv=True, n_frames=5)
+    p = Plan(24, hw, n=bs, groups=2, lanes=lanes)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    return p
+
+
+def _regions(lst):
+    """-> [(fork_idx, join_idx)], asserting balance and that lane tags only occur inside regions."""
+    out, open_at = [], None
+    for idx, op in enumerate(lst):
+        kind, lane = op[0], op[5]
+        if kind == capi.OP_FORK:
+            assert open_at is None, "nested FORK at %d" % idx
+            open_at = idx
+        elif kind == capi.OP_JOIN:
+            assert open_at is not None, "JOIN without FORK at %d" % idx
+            out.append((open_at, idx)); open_at = None
+        else:
+            assert lane == 0 or open_at is not None, "op %d on lane %d outside a FORK..JOIN region" % (idx, lane)
+    assert open_at is None, "list ends with an open FORK"
+    return out
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_regions_balanced_and_private(lanes):
+    p = _plan(lanes)
+    for name in ("prep", "fwd", "loss", "bwd", "adam"):
+        lst = p.lists[name]
+        regs = _regions(lst)
+        if name in ("fwd", "bwd"):
+            assert len(regs) == 7, "one region per Inception module (Mixed_3b..4f)"
+        else:
+            assert not regs
+        for a, b in regs:
+            touched = collections.defaultdict(set)   # ref -> lanes that touch it
+            written = collections.defaultdict(set)   # ref -> lanes that write it
+            for op in lst[a + 1:b]:
+                kind, ptrs, lane = op[0], op[3], op[5]
+                assert kind in WRITES, "op kind %d inside a lane region has no write map" % kind
+                for q, r in enumerate(ptrs):
+                    if r is None:
+                        continue
+                    touched[r].add(lane)
+                    if q in WRITES[kind]:
+                        written[r].add(lane)
+            for r, wl in written.items():
+                assert len(touched[r]) == 1, "buffer %s written on lane(s) %s but touched on %s" % (r, wl, touched[r])
+
+
+def test_same_ops_as_single_lane_plan():
+    p1, p4 = _plan(1), _plan(4)
+    assert p1.arena_bytes == p4.arena_bytes
+    for name in ("prep", "fwd", "loss", "bwd", "adam"):
+        strip = lambda lst: collections.Counter((op[0], tuple(op[1]), tuple(op[2]), tuple(op[4])) for op in lst
+                                                if op[0] not in (capi.OP_FORK, capi.OP_JOIN))
+        assert strip(p1.lists[name]) == strip(p4.lists[name]), name
+    assert all(op[5] == 0 for lst in p1.lists.values() for op in lst)
+
+
+def test_buckets_ready_only_at_joined_points():
+    p = _plan(4)
+    regs = _regions(p.lists["bwd"])
+    b = p.grad_buckets(500_000)
+    assert len(b) > 8
+    for ready, _a, _e in b:
+        assert not any(f < ready <= j for f, j in regs), "bucket ready inside an open region (%d)" % ready
+    spans = sorted((a, e) for _r, a, e in b)
+    assert spans[0][0] == 0 and spans[-1][1] == p.nparams
+    assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
