@@ -48,7 +48,7 @@ class StepEngine:
         self.hw = hw
         self.jhmdb = jhmdb
         if lanes is None:
-            lanes = int(os.environ.get("PICONS_LANES", "4"))
+            lanes = int(os.environ.get("PICONS_LANES", "2"))   # measured best on MI355X
         p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         p.build_forward()
