@@ -514,7 +514,7 @@ inline TileCfg choose_tile(int Mg, int groups, int Co) {
         // waves of blocks over 512 slots (2 blocks/CU); partial last wave costs a full one
         const double slots = 512.0, wavesq = ceil(blocks / slots);
         const double fill = blocks / (wavesq * slots);
-        const double cost = work / (fill > 0.35 ? 1.0 : fill / 0.35) * (1.0 + 8.0 / eff);
+        const double cost = work / (fill > 0.9 ? 1.0 : fill / 0.9) * (1.0 + 8.0 / eff);   // swept 0.35..1.0 on the step
         if (cost < best) { best = cost; bc = c; }
     }
     return bc;
@@ -584,6 +584,7 @@ struct WgK {
     int istr[3], ntap[3], ioff0[3], istep[3], wk0[3];
     int KH, KW, NtotFull;
     int P, Ntot, chunks_per_split, nchunks;
+    int mbase, mend;                 // rows [mbase, mend) of D's channels handled by this launch
 };
 
 template <int BM, int BN, int ABL = 0>
@@ -596,7 +597,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int m0 = p.mbase + blockIdx.x * BM, n0 = blockIdx.y * BN;
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
@@ -612,7 +613,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     const int tapHW = p.ntap[1] * p.ntap[2];
     const int a_ = tap / tapHW, rem = tap - a_ * tapHW, b_ = rem / p.ntap[2], c_ = rem - b_ * p.ntap[2];
     const int dt = a_ * p.istep[0], dh = b_ * p.istep[1], dw = c_ * p.istep[2];
-    const bool mval = (m0 + dcol) < p.Cd;
+    const bool mval = (m0 + dcol) < p.mend;
     (void)rem;
 
     auto ptab_fill = [&](int c) {
@@ -676,18 +677,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
         const int buf = ABL ? 0 : ((c - c_begin) & 1);
         if (!ABL) ptab_fill(c + 2);
         if (!ABL && c + 1 < c_end) gload(c + 1, buf ^ 1);
+        // a wave's two 32-row MFMA tiles are the even / odd rows of its 64-row slab (same for columns): one
+        // ds_read_b64 feeds both tiles.  Fragments are double-buffered in registers: the reads of k-step ks+1
+        // are issued before the MFMAs of k-step ks, so no MFMA group waits on an LDS round trip.
+        float af[2][TM], bf[2][TN];
+        auto fread = [&](int ks, float (&a)[TM], float (&b)[TN]) {
+            if (TM == 2) {
+                const float2 v = *(const float2*)&Ds[buf][ks * 2 + kh][wm * 64 + 2 * (lane & 31)];
+                a[0] = v.x; a[TM - 1] = v.y;
+            } else {
+                a[0] = Ds[buf][ks * 2 + kh][ml];
+            }
+            if (TN == 2) {
+                const float2 v = *(const float2*)&Ss[buf][ks * 2 + kh][wn * 64 + 2 * (lane & 31)];
+                b[0] = v.x; b[TN - 1] = v.y;
+            } else {
+                b[0] = Ss[buf][ks * 2 + kh][nl];
+            }
+        };
+        fread(0, af[0], bf[0]);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            float af[TM], bf[TN];
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][ks * 2 + kh][ml + i * 32];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][ks * 2 + kh][nl + j * 32];
+            if (ks + 1 < BK / 2) fread(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+        }
+        // pin the software pipeline: hipcc pairs two k-steps per ds_read2st64, i.e. one A + one B read per group of
+        // 2*TM*TN MFMAs; keep the reads of group g+1 in flight while group g's MFMAs issue
+        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+        for (int g = 0; g < BK / 4; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
+            if (g + 2 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
     }
@@ -695,11 +719,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (m >= p.Cd) continue;
+            const int rho = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm * (BM / 2) + (TM == 2 ? 2 * rho + i : rho);
+            if (m >= p.mend) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+                const int n = n0 + wn * (BN / 2) + (TN == 2 ? 2 * (lane & 31) + j : (lane & 31));
                 if (n < p.Ntot) {
                     // trimmed column (tap_local, cs) -> column of the full [KT*KH*KW][Cs] layout
                     const int tl = n / p.Cs, cc = n - tl * p.Cs;
@@ -731,29 +756,44 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
     k.nchunks = cdiv(P, BK);
-    const bool small_m = d->Cd <= 64;
-    const int bm = small_m ? 64 : 128, bn = 128;
-    const int mt = cdiv(d->Cd, bm), ntl = cdiv(k.Ntot, bn);
-    int splitk = d->splitk;
-    if (splitk <= 0) {
-        // aim at ~4 blocks per CU overall, at least 8 chunks (256 positions) per slice
-        const int64_t tiles = (int64_t)mt * ntl;
-        splitk = (int)((1024 + tiles - 1) / tiles);
-        const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
-        if (splitk > maxsplit) splitk = maxsplit;
-        if (splitk < 1) splitk = 1;
-    }
-    if (splitk > 65535) splitk = 65535;
-    k.chunks_per_split = cdiv(k.nchunks, splitk);
-    splitk = cdiv(k.nchunks, k.chunks_per_split);
-    PC_CHECK_ARG(ntl <= 65535, "pc_conv_wgrad: too many column tiles");
-    dim3 grid(mt, ntl, splitk);
+    PC_CHECK_ARG(cdiv(k.Ntot, 128) <= 65535, "pc_conv_wgrad: too many column tiles");
     static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic: no tile fetch in the K loop (wrong results)
-    if (abl) {
-        if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, k);
-        else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, k);
-    } else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, k);
+    // rows of D's channels [m_lo, m_hi) with 64- or 128-row tiles
+    auto launch = [&](int m_lo, int m_hi, bool small_m) {
+        const int bm = small_m ? 64 : 128, bn = 128;
+        const int mt = cdiv(m_hi - m_lo, bm), ntl = cdiv(k.Ntot, bn);
+        int splitk = d->splitk;
+        if (splitk <= 0) {
+            // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill two full rounds of
+            // slots and never spill a few blocks into a third (1026 blocks ran ~25 % slower than 1022); at least
+            // 8 chunks (256 positions) per slice
+            const int64_t tiles = (int64_t)mt * ntl;
+            const int slots = small_m ? 768 : 512;
+            splitk = (int)(2 * slots / tiles);
+            const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
+            if (splitk > maxsplit) splitk = maxsplit;
+            if (splitk < 1) splitk = 1;
+        }
+        if (splitk > 65535) splitk = 65535;
+        WgK kk = k;
+        kk.mbase = m_lo; kk.mend = m_hi;
+        kk.chunks_per_split = cdiv(k.nchunks, splitk);
+        splitk = cdiv(k.nchunks, kk.chunks_per_split);
+        dim3 grid(mt, ntl, splitk);
+        if (abl) {
+            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
+            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
+        } else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
+        else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);
+    };
+    // 128-row tiles for the bulk.  When the grid is many rounds deep without split-K (PrimaryCaps: 544 = 4*128 + 32
+    // rows x 527 column tiles), a remainder of at most 64 channels gets its own launch with 64-row tiles instead
+    // of a padded 128-row tile (4.98 vs 5.23 ms); small problems lose more to the second launch than they save
+    const int full = d->Cd / 128 * 128, rem = d->Cd - full;
+    const bool deep = (int64_t)(full / 128) * cdiv(k.Ntot, 128) >= 1024;
+    if (d->Cd <= 64) launch(0, d->Cd, true);
+    else if (rem == 0 || rem > 64 || !deep) launch(0, d->Cd, false);
+    else { launch(0, full, false); launch(full, d->Cd, true); }
     PC_CHECK_LAUNCH("wgrad_kernel");
     return PC_OK;
 }

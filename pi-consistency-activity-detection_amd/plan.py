@@ -82,7 +82,11 @@ class Plan:
             self.roff[pre + ".bn.running_mean"] = o; o += co
             self.roff[pre + ".bn.running_var"] = o; o += co
         self.nrunning = o
-        self.kg_ranges = []       # (ref, nfloats) of kernel-layout grad buffers to zero each step
+        # kernel-layout weight-gradient buffers (wgrad accumulates into them with atomics) live in ONE region so a
+        # single fill zeroes them all each step; their total size is the parameter count plus channel padding
+        self.kg_cap = 4 * (self.nparams + (1 << 20))
+        self.kg_base = self.alloc(self.kg_cap // 4)
+        self.kg_used = 0
         self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
         self.alg_flops = {}       # list name -> algorithmic conv FLOPs (all taps, as the reference's convs count them)
 
@@ -91,6 +95,13 @@ class Plan:
         o = self.arena_bytes
         self.arena_bytes = (o + 4 * int(nfloats) + ALIGN - 1) // ALIGN * ALIGN
         return ("A", o)
+
+    def alloc_kg(self, nfloats):
+        o = self.kg_used
+        self.kg_used = (o + 4 * int(nfloats) + ALIGN - 1) // ALIGN * ALIGN
+        if self.kg_used > self.kg_cap:
+            raise RuntimeError("kernel-layout gradient region overflow")
+        return off(self.kg_base, o // 4)
 
     def tensor(self, N, thw, C, name):
         t = TR(self.alloc(N * thw[0] * thw[1] * thw[2] * C), N, tuple(thw), C, C, name)
@@ -107,8 +118,9 @@ class Plan:
         return ("R", 4 * self.roff[name])
 
     # ------------------------------------------------------------------ op emission
-    def emit(self, kind, i=(), f=(), p=(), l=(), lst=None):
-        lane = self.lane if lst in (None, self.cur) else 0
+    def emit(self, kind, i=(), f=(), p=(), l=(), lst=None, lane=None):
+        if lane is None:
+            lane = self.lane if lst in (None, self.cur) else 0
         self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l), lane))
 
     def fork(self):
@@ -147,19 +159,19 @@ class Plan:
         Ipad = Ipad or I
         O = sum(O_list)
         key = names[0]
-        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc(O * taps * Ipad), unprep=[])
+        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc_kg(O * taps * Ipad), unprep=[])
+        pl = self.next_prep_lane()
         if Ipad != I:
-            self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst="prep")
-        self.kg_ranges.append((w["kg"], O * taps * Ipad))
+            self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst="prep", lane=pl)
         if need_tr:
             w["tr"] = self.alloc(I * taps * O)
         o0 = 0
         for nm, Oi in zip(names, O_list):
             src = self.P(nm)
             self.emit(capi.OP_TRANSPOSE, i=[Oi, I, taps, taps, Ipad, 0], l=[I * taps, taps * Ipad],
-                      p=[src, off(w["fwd"], o0 * taps * Ipad)], lst="prep")
+                      p=[src, off(w["fwd"], o0 * taps * Ipad)], lst="prep", lane=pl)
             if need_tr:
-                self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst="prep")
+                self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst="prep", lane=pl)
             # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]  (flushed right after the wgrad, see flush_grad)
             w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, self.acc], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
             o0 += Oi
@@ -170,14 +182,20 @@ class Plan:
         """Reference IO(T)HW master -> fwd-type layout [O][taps][I] (ConvTranspose forward) and
         [I][taps][O] (its dgrad, a strided conv); grads come back as [I][taps][O]."""
         taps = k[0] * k[1] * k[2]
-        w = dict(O=O, I=I, taps=taps, fwd=self.alloc(O * taps * I), tr=self.alloc(I * taps * O), kg=self.alloc(I * taps * O), unprep=[])
-        self.kg_ranges.append((w["kg"], I * taps * O))
+        w = dict(O=O, I=I, taps=taps, fwd=self.alloc(O * taps * I), tr=self.alloc(I * taps * O), kg=self.alloc_kg(I * taps * O), unprep=[])
         src = self.P(name)
-        self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst="prep")
-        self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst="prep")
+        pl = self.next_prep_lane()
+        self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst="prep", lane=pl)
+        self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst="prep", lane=pl)
         w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, self.acc], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
         self.kw[name] = w
         return w
+
+    def next_prep_lane(self):
+        """Weight-layout prep (one or two tiny transposes per parameter, ~160 launches a step) is spread round-robin
+        over the lanes; ops of one weight stay on one lane, in order."""
+        self._prep_rr = (getattr(self, "_prep_rr", -1) + 1) % self.lanes
+        return self._prep_rr
 
     def alg_dgrad(self, fwd_flops):
         self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + fwd_flops
@@ -578,8 +596,7 @@ class Plan:
 
     def build_backward(self):
         self.cur = "bwd"
-        for rng, nfl in self.kg_ranges:
-            self.emit(capi.OP_FILL, p=[rng], l=[nfl], f=[0.0])
+        self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
         for fn in reversed(self.tape):
             fn()
 
@@ -619,8 +636,21 @@ class Plan:
         self.emit(capi.OP_ADAM, i=[1], f=[1e-4, 0.9, 0.999, 1e-6, 1.0], l=[self.nparams], p=[("P", 0), ("G", 0), ("M", 0), ("V", 0)], lst="adam")
 
     # ------------------------------------------------------------------ finalisation
+    def finalize(self):
+        """Multi-lane plans: wrap the weight-layout prep in one FORK..JOIN (idempotent).  Ops that read master
+        parameters are independent across weights; second-level layouts (made from a prepared buffer) run on
+        lane 0 after the join."""
+        lst = self.lists["prep"]
+        if self.lanes > 1 and lst and lst[0][0] != capi.OP_FORK:
+            first = lambda op: op[0] == capi.OP_FILL or op[3][0][0] == "P"
+            lvl0 = [op for op in lst if first(op)]
+            lvl1 = [op[:5] + (0,) for op in lst if not first(op)]
+            mask = [(1 << self.lanes) - 2]
+            lst[:] = [(capi.OP_FORK, mask, [], [], [], 0)] + lvl0 + [(capi.OP_JOIN, mask, [], [], [], 0)] + lvl1
+
     def resolve(self, bases):
         """-> dict list-name -> numpy array of capi.OP_DTYPE with absolute device pointers."""
+        self.finalize()
         out = {}
         for name, lst in self.lists.items():
             arr = np.zeros(len(lst), dtype=capi.OP_DTYPE)

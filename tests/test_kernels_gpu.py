@@ -81,6 +81,28 @@ def test_conv_same_fwd_dgrad_wgrad(Ci, Co, k, s, thw, N):
     close(gw.cpu(), w.grad.reshape(Co, Ci, taps).permute(0, 2, 1), what="wgrad")
 
 
+def test_wgrad_primarycaps_shape_remainder_rows():
+    """PrimaryCaps weight gradient at its real channel counts (544 = 4*128 + 32 rows, 81*832 columns): the grid is
+    deep enough that the last 32 rows go to a second launch with 64-row tiles; both row ranges are checked
+    against torch on their own scale."""
+    g = torch.Generator().manual_seed(11)
+    N, Ci, Co, hw, k = 2, 832, 544, 28, 9
+    x = torch.randn(N, Ci, hw, hw, generator=g)
+    w = (torch.randn(Co, Ci, k, k, generator=g) * 0.01).requires_grad_(True)
+    y = F.conv2d(x, w)
+    dy = torch.randn(y.shape, generator=g)
+    dy[:, 512:] *= 1e-3                                    # the activation-capsule rows carry much smaller gradients
+    y.backward(dy)
+    o = y.shape[-1]
+    xg = x.permute(0, 2, 3, 1).contiguous().view(N, 1, hw, hw, Ci).to(DEV)
+    dyg = dy.permute(0, 2, 3, 1).contiguous().view(N, 1, o, o, Co).to(DEV)
+    gw = torch.zeros(Co, k * k, Ci, device=DEV)
+    ops.conv_wgrad(desc.wgrad(N, (1, o, o), Co, Co, (1, hw, hw), Ci, Ci, (1, k, k), (1, 1, 1), (0, 0, 0)), dyg, xg, gw)
+    ref = w.grad.reshape(Co, Ci, k * k).permute(0, 2, 1)
+    close(gw[:512].cpu(), ref[:512], what="rows 0..511 (128-row tiles)")
+    close(gw[512:].cpu(), ref[512:], what="rows 512..543 (64-row remainder launch)")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)

@@ -20,6 +20,7 @@ def _plan(lanes, bs=1, hw=112):
     args = pstep.default_args(bv=True, n_frames=5)
     p = Plan(24, hw, n=bs, groups=2, lanes=lanes)
     p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    p.finalize()
     return p
 
 
@@ -48,6 +49,8 @@ def test_regions_balanced_and_private(lanes):
         regs = _regions(lst)
         if name in ("fwd", "bwd"):
             assert len(regs) == 7, "one region per Inception module (Mixed_3b..4f)"
+        elif name == "prep":
+            assert len(regs) == 1, "weight-layout prep: one region"
         else:
             assert not regs
         for a, b in regs:
@@ -86,3 +89,28 @@ def test_buckets_ready_only_at_joined_points():
     spans = sorted((a, e) for _r, a, e in b)
     assert spans[0][0] == 0 and spans[-1][1] == p.nparams
     assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+
+
+def test_prep_list_is_spread_over_lanes_at_resolve():
+    """resolve() wraps the weight-layout prep in one FORK..JOIN: ops reading master parameters round-robin over
+    the lanes (all ops of one weight on one lane), second-level layouts after the join on lane 0."""
+    p = _plan(2)
+    arrs = p.resolve({"A": 1 << 20, "P": 1 << 30, "G": 1 << 31, "M": 1 << 32, "V": 1 << 33, "R": 1 << 34})
+    lst = p.lists["prep"]
+    regs = _regions(lst)
+    assert len(regs) == 1 and regs[0][0] == 0
+    f, j = regs[0]
+    lanes_used = {op[5] for op in lst[f + 1:j]}
+    assert lanes_used == {0, 1}
+    dest_lane = {}
+    for op in lst[f + 1:j]:
+        kind, ptrs, lane = op[0], op[3], op[5]
+        dst = ptrs[0] if kind == capi.OP_FILL else ptrs[1]
+        assert kind == capi.OP_FILL or ptrs[0][0] == "P"            # sources inside the region: master parameters only
+        assert dest_lane.setdefault(dst, lane) == lane               # FILL + transposes of one buffer: same lane
+    for op in lst[j + 1:]:
+        assert op[5] == 0 and op[3][0][0] == "A"                     # second-level layouts read prepared buffers
+    assert len(arrs["prep"]) == len(lst) and int(arrs["prep"][0]["kind"]) == capi.OP_FORK
+    # idempotent
+    p.resolve({"A": 1 << 20, "P": 1 << 30, "G": 1 << 31, "M": 1 << 32, "V": 1 << 33, "R": 1 << 34})
+    assert len(p.lists["prep"]) == len(lst)

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Per-launch GEMM efficiency table: pairs the conv / wgrad ops of a single-lane plan (bench.py workload)
+with the kernels of one step of a `rocprofv3 --kernel-trace` CSV taken with PICONS_LANES=1, and prints
+issued TFLOP/s and the time each launch loses against the fp32 MFMA peak.
+
+    python tools/launch_table.py gpurun_out/prof_l1/l1_kernel_trace.csv [top_n]
+"""
+import csv
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import picons_amd  # noqa: F401,E402
+from picons_amd import capi, desc as D, step as pstep  # noqa: E402
+from picons_amd.plan import Plan  # noqa: E402
+
+PEAK = 157.3e9      # FLOP per ms
+
+VEC = ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")
+
+
+def unflat(i, fields):
+    d, k = {}, 0
+    for f in fields:
+        if f in VEC:
+            d[f] = i[k:k + 3]; k += 3
+        else:
+            d[f] = i[k]; k += 1
+    return d
+
+
+def main():
+    path = sys.argv[1]
+    top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    p = Plan(24, 224, n=8, groups=2, lanes=1)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    ops = [(name, op) for name in ("prep", "fwd", "loss", "bwd") for op in p.lists[name] if op[0] in (capi.OP_CONV, capi.OP_WGRAD)]
+    rows = list(csv.DictReader(open(path)))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
+    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
+    if len(st) != len(ops):
+        raise SystemExit("trace has %d GEMM launches per step, plan has %d ops (lanes / version mismatch?)" % (len(st), len(ops)))
+    out = []
+    for (name, op), r in zip(ops, st):
+        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+        blocks = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_X"])
+        if op[0] == capi.OP_CONV:
+            if "wgrad" in kn:
+                raise SystemExit("order mismatch: conv op paired with " + kn)
+            d = unflat(op[1], D.CONV_FIELDS)
+            M = d["N"] * d["Tq"] * d["Hq"] * d["Wq"]
+            taps = d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
+            fl = 2 * M * d["Co"] * d["Ci"] * taps
+            what = "conv  M=%-7d Co=%-5d Ci=%-4d taps=%s" % (M, d["Co"], d["Ci"], "x".join(map(str, d["ntap"])))
+        else:
+            if "wgrad" not in kn:
+                raise SystemExit("order mismatch: wgrad op paired with " + kn)
+            d = unflat(op[1], D.WGRAD_FIELDS)
+            M = d["N"] * d["Tq"] * d["Hq"] * d["Wq"]
+            taps = d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
+            fl = 2 * M * d["Cd"] * d["Cs"] * taps
+            what = "wgrad K=%-7d Cd=%-5d Cs=%-4d taps=%s" % (M, d["Cd"], d["Cs"], "x".join(map(str, d["ntap"])))
+        out.append((dur, fl, name, kn, blocks, what))
+    print("%7s %7s %7s %-4s %6s %-34s %s" % ("ms", "TF/s", "lost", "list", "blocks", "kernel", "launch (issued shape, trimmed taps)"))
+    for dur, fl, name, kn, blocks, what in sorted(out, key=lambda x: -(x[0] - x[1] / PEAK))[:top]:
+        print("%7.3f %7.1f %7.3f %-4s %6d %-34s %s" % (dur, fl / dur / 1e9, dur - fl / PEAK, name, blocks, kn[:34], what))
+    tot = sum(d for d, *_ in out)
+    print("GEMM launches: %d, %.2f ms/step, %.2f ms above the fp32 MFMA peak time of the issued FLOPs" %
+          (len(out), tot, sum(d - f / PEAK for d, f, *_ in out)))
+
+
+if __name__ == "__main__":
+    main()
