@@ -89,7 +89,8 @@ typedef struct pc_wgrad_desc {
     int32_t istr[3], ntap[3], ioff0[3], istep[3];
     int32_t wk0[3];                 /* first weight tap per dim (taps that only ever see padding are trimmed by the host) */
     int32_t KT, KH, KW;             /* full weight tap extents: g is [Cd][KT*KH*KW][Cs] */
-    int32_t splitk;                 /* 0 = choose */
+    int32_t splitk;                 /* 0 = choose; -1 = one slice written with plain stores (g need not be initialised;
+                                     * only valid when no tap is trimmed: ntap == (KT,KH,KW)) */
 } pc_wgrad_desc;
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
 
@@ -234,6 +235,31 @@ int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
                  float b2, float eps, int step, float gscale, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
+ * Row-spectral PrimaryCaps (capsules_ucf101.py:43-49: Conv2d 832 -> 512+32, 9x9, stride 1).  A real DFT
+ * of length P = image width along the rows turns the kx taps into a product per frequency; what is left
+ * is a 9x1 conv with complex channels per frequency, run in real form by pc_conv_fwd / pc_conv_wgrad as a
+ * grouped conv (group = frequency, 2*Ci -> 2*Co channels): 3x fewer multiply-adds than the direct form,
+ * identical in exact arithmetic.  These three HBM-bound helpers are the rest of it. */
+/* out[r][o][c] = sum_i M[o][i] * in[r][i][c] (+ bias[c]; activation on channels >= act_c0; accum adds
+ * the old value first): a small dense matrix along one tensor axis.  Element offsets (floats):
+ * in:  r*in_sr  + (i / in_split)*in_hi   + (i % in_split)*in_lo  + c
+ * out: r*out_sr + (o / out_split)*out_hi + (o % out_split)*out_lo + c */
+typedef struct pc_axis_desc {
+    int32_t R, I, O, C;
+    int32_t in_split, out_split, act, act_c0, accum;
+    int32_t in_sr, in_hi, in_lo, out_sr, out_hi, out_lo;
+} pc_axis_desc;
+int pc_axis_linear(const pc_axis_desc* d, const float* in, const float* M, const float* bias, float* out, pc_stream s);
+/* weights in a kernel layout in[A][KY*KX][B] -> their row spectrum in real form out[U][2A][KY][2B] with
+ * Wr = sum_kx in*tw[u][kx][0], Wi = sum_kx in*tw[u][kx][1] (tw = cos, -sin of 2*pi*u*kx/P):
+ * out[(0,a)][(0,b)] = Wr, [(0,a)][(1,b)] = sgn*Wi, [(1,a)][(0,b)] = -sgn*Wi, [(1,a)][(1,b)] = Wr.
+ * sgn = +1 with in = [Co][taps][Ci] gives the forward GEMM weights of Y = X * conj(W); sgn = -1 with
+ * in = [Ci][taps][Co] gives the dgrad GEMM weights. */
+int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* out, pc_stream s);
+/* adjoint of pc_wspec_fwd: kg[a][ky*KX+kx][b] = sum_u tw[u][kx][0]*(d00+d11) + tw[u][kx][1]*sgn*(d01-d10) */
+int pc_wspec_bwd(const float* dWg, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* kg, pc_stream s);
+
+/* ------------------------------------------------------------------------------------------
  * Op-list runner: the host builds the step as a flat list of POD ops once (shape inference and
  * arena planning in Python) and the library replays it with no per-op host round trip. */
 typedef struct pc_op {
@@ -250,6 +276,9 @@ enum {
     PC_OP_TRANSPOSE, PC_OP_FILL, PC_OP_AXPY, PC_OP_EM_FWD, PC_OP_EM_BWD, PC_OP_CMASK_FWD,
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
     PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS, PC_OP_COL2IM,
+    PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
+    PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U, sgn; p = in, tw, out */
+    PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U, sgn; p = dWg, tw, kg */
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP__COUNT

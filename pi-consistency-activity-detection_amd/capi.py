@@ -23,6 +23,13 @@ class WgradDesc(C.Structure):
                [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk")]
 
 
+AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "accum", "in_sr", "in_hi", "in_lo", "out_sr", "out_hi", "out_lo"]
+
+
+class AxisDesc(C.Structure):
+    _fields_ = [(n, i32) for n in AXIS_FIELDS]
+
+
 class PoolDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo")] + \
                [(n, i32 * 3) for n in ("k", "s", "padf")]
@@ -40,7 +47,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
- OP_FORK, OP_JOIN) = range(1, 31)
+ OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_FORK, OP_JOIN) = range(1, 34)
 MAX_LANES = 8
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
@@ -84,6 +91,9 @@ _SIGS = {
     "pc_tail_combine": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
     "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "pc_axis_linear": (i32, [vp, vp, vp, vp, vp, vp]),
+    "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),
     "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp, i32]),

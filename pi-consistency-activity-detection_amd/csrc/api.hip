@@ -103,6 +103,15 @@ static int run_one(const pc_op& op, pc_stream s) {
                                  op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), op.i[6], s);
         case PC_OP_COL2IM:
             return pc_col2im(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 1), op.i[6], op.i[7], s);
+        case PC_OP_AXIS: {
+            pc_axis_desc d;
+            memcpy(&d, op.i, sizeof(d));
+            return pc_axis_linear(&d, P(const float*, 0), P(const float*, 1), P(const float*, 2), P(float*, 3), s);
+        }
+        case PC_OP_WSPEC_FWD:
+            return pc_wspec_fwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 2), s);
+        case PC_OP_WSPEC_BWD:
+            return pc_wspec_bwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 2), s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

@@ -585,6 +585,7 @@ struct WgK {
     int KH, KW, NtotFull;
     int P, Ntot, chunks_per_split, nchunks;
     int mbase, mend;                 // rows [mbase, mend) of D's channels handled by this launch
+    int store;                       // one K slice: plain stores instead of atomics
 };
 
 template <int BM, int BN, int ABL = 0>
@@ -730,7 +731,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
                     const int tl = n / p.Cs, cc = n - tl * p.Cs;
                     const int ta = tl / tapHW, tr = tl - ta * tapHW, tb = tr / p.ntap[2], tc = tr - tb * p.ntap[2];
                     const int full = ((p.wk0[0] + ta) * p.KH + p.wk0[1] + tb) * p.KW + p.wk0[2] + tc;
-                    atomicAdd(p.g + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc, acc[i][j][r]);
+                    float* dst = p.g + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc;
+                    if (p.store) *dst = acc[i][j][r];
+                    else atomicAdd(dst, acc[i][j][r]);
                 }
             }
         }
@@ -749,6 +752,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
     k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
     for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; }
+    PC_CHECK_ARG(d->splitk != -1 || (d->ntap[0] == d->KT && d->ntap[1] == d->KH && d->ntap[2] == d->KW), "pc_conv_wgrad: splitk = -1 (plain stores) needs every tap present");
     PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
     k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
@@ -763,7 +767,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         const int bm = small_m ? 64 : 128, bn = 128;
         const int mt = cdiv(m_hi - m_lo, bm), ntl = cdiv(k.Ntot, bn);
         int splitk = d->splitk;
-        if (splitk <= 0) {
+        if (splitk == -1) splitk = 1;
+        else if (splitk <= 0) {
             // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill two full rounds of
             // slots and never spill a few blocks into a third (1026 blocks ran ~25 % slower than 1022); at least
             // 8 chunks (256 positions) per slice
@@ -777,6 +782,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         if (splitk > 65535) splitk = 65535;
         WgK kk = k;
         kk.mbase = m_lo; kk.mend = m_hi;
+        kk.store = d->splitk == -1;
         kk.chunks_per_split = cdiv(k.nchunks, splitk);
         splitk = cdiv(k.nchunks, kk.chunks_per_split);
         dim3 grid(mt, ntl, splitk);

@@ -1,0 +1,179 @@
+// Row-spectral form of PrimaryCaps (capsules_ucf101.py:43-49, a 9x9 stride-1 Conv2d 832 -> 512+32 on 28x28):
+// a length-P real DFT along the image rows turns the kx taps into a per-frequency product, leaving a 9-tap
+// conv along y with complex channels per frequency u = 0..P/2.  In real form that is one grouped conv
+// (group = frequency, 2*Ci -> 2*Co channels, 9x1 taps) run by the ordinary gather-GEMM kernels: 3x fewer
+// multiply-adds than the 81-tap direct form, exact in exact arithmetic.  This file holds the three small
+// HBM-bound kernels around those GEMMs: a dense matrix applied along one tensor axis (DFT, inverse DFT and
+// their transposes), the weight spectrum in the GEMM layouts, and its adjoint.
+#include "common.h"
+
+namespace {
+
+struct AxK {
+    const float* in; const float* M; const float* bias; float* out;
+    int R, I, O, C4;
+    int in_split, out_split, act, act_c0, accum;
+    int in_sr, in_hi, in_lo, out_sr, out_hi, out_lo;
+};
+
+constexpr int AX_OC = 8;        // outputs accumulated per pass over the input axis
+
+__global__ __launch_bounds__(256) void axis_linear_kernel(const AxK p) {
+    extern __shared__ float Ms[];                       // [O][I]
+    for (int k = threadIdx.x; k < p.O * p.I; k += 256) Ms[k] = p.M[k];
+    __syncthreads();
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)p.R * p.C4) return;
+    const int r = (int)(idx / p.C4), c = (int)(idx - (int64_t)r * p.C4) * 4;
+    const float* ip = p.in + (int64_t)r * p.in_sr + c;
+    float* op = p.out + (int64_t)r * p.out_sr + c;
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) b = *(const float4*)(p.bias + c);
+    for (int o0 = 0; o0 < p.O; o0 += AX_OC) {
+        float4 acc[AX_OC];
+#pragma unroll
+        for (int q = 0; q < AX_OC; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i = 0; i < p.I; ++i) {
+            const float4 v = *(const float4*)(ip + (int64_t)(i / p.in_split) * p.in_hi + (int64_t)(i % p.in_split) * p.in_lo);
+#pragma unroll
+            for (int q = 0; q < AX_OC; ++q) {
+                const float m = (o0 + q < p.O) ? Ms[(o0 + q) * p.I + i] : 0.f;
+                acc[q].x += m * v.x; acc[q].y += m * v.y; acc[q].z += m * v.z; acc[q].w += m * v.w;
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < AX_OC; ++q) {
+            const int o = o0 + q;
+            if (o >= p.O) break;
+            float* dst = op + (int64_t)(o / p.out_split) * p.out_hi + (int64_t)(o % p.out_split) * p.out_lo;
+            float4 y = acc[q];
+            y.x += b.x; y.y += b.y; y.z += b.z; y.w += b.w;
+            if (p.accum) {
+                const float4 old = *(const float4*)dst;
+                y.x += old.x; y.y += old.y; y.z += old.z; y.w += old.w;
+            }
+            if (p.act == PC_ACT_SIGMOID && c >= p.act_c0) {
+                y.x = 1.f / (1.f + expf(-y.x)); y.y = 1.f / (1.f + expf(-y.y));
+                y.z = 1.f / (1.f + expf(-y.z)); y.w = 1.f / (1.f + expf(-y.w));
+            } else if (p.act == PC_ACT_RELU && c >= p.act_c0) {
+                y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f);
+            }
+            *(float4*)dst = y;
+        }
+    }
+}
+
+constexpr int WS_MAXK = 16;
+
+// in [A][KY*KX][B] -> out [U][2A][KY][2B]
+__global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict__ in, const float* __restrict__ tw, int A, int B4, int KY,
+                                                         int KX, int U, float sgn, float* __restrict__ out) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)A * KY * B4) return;
+    const int b = (int)(idx % B4) * 4;
+    const int ky = (int)((idx / B4) % KY);
+    const int a = (int)(idx / ((int64_t)B4 * KY));
+    const int B = B4 * 4;
+    float4 v[WS_MAXK];
+#pragma unroll
+    for (int kx = 0; kx < WS_MAXK; ++kx)
+        v[kx] = kx < KX ? *(const float4*)(in + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = (int64_t)KY * 2 * B;                 // floats per output channel row [KY][2B]
+    for (int u = 0; u < U; ++u) {
+        float4 wr = make_float4(0.f, 0.f, 0.f, 0.f), wi = wr;
+#pragma unroll
+        for (int kx = 0; kx < WS_MAXK; ++kx) {
+            if (kx >= KX) break;
+            const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
+            wr.x += c * v[kx].x; wr.y += c * v[kx].y; wr.z += c * v[kx].z; wr.w += c * v[kx].w;
+            wi.x += s * v[kx].x; wi.y += s * v[kx].y; wi.z += s * v[kx].z; wi.w += s * v[kx].w;
+        }
+        const float4 pwi = make_float4(sgn * wi.x, sgn * wi.y, sgn * wi.z, sgn * wi.w);
+        const float4 nwi = make_float4(-pwi.x, -pwi.y, -pwi.z, -pwi.w);
+        float* o0 = out + ((int64_t)u * 2 * A + a) * row + (int64_t)ky * 2 * B + b;          // (0, a)
+        float* o1 = o0 + (int64_t)A * row;                                                      // (1, a)
+        *(float4*)o0 = wr; *(float4*)(o0 + B) = pwi;
+        *(float4*)o1 = nwi; *(float4*)(o1 + B) = wr;
+    }
+}
+
+// dWg [U][2A][KY][2B] -> kg [A][KY*KX][B]
+__global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict__ dWg, const float* __restrict__ tw, int A, int B4, int KY,
+                                                         int KX, int U, float sgn, float* __restrict__ kg) {
+    const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (int64_t)A * KY * B4) return;
+    const int b = (int)(idx % B4) * 4;
+    const int ky = (int)((idx / B4) % KY);
+    const int a = (int)(idx / ((int64_t)B4 * KY));
+    const int B = B4 * 4;
+    float4 acc[WS_MAXK];
+#pragma unroll
+    for (int kx = 0; kx < WS_MAXK; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t row = (int64_t)KY * 2 * B;
+    for (int u = 0; u < U; ++u) {
+        const float* d0 = dWg + ((int64_t)u * 2 * A + a) * row + (int64_t)ky * 2 * B + b;
+        const float* d1 = d0 + (int64_t)A * row;
+        const float4 d00 = *(const float4*)d0, d01 = *(const float4*)(d0 + B), d10 = *(const float4*)d1, d11 = *(const float4*)(d1 + B);
+        const float4 gr = make_float4(d00.x + d11.x, d00.y + d11.y, d00.z + d11.z, d00.w + d11.w);
+        const float4 gi = make_float4(sgn * (d01.x - d10.x), sgn * (d01.y - d10.y), sgn * (d01.z - d10.z), sgn * (d01.w - d10.w));
+#pragma unroll
+        for (int kx = 0; kx < WS_MAXK; ++kx) {
+            if (kx >= KX) break;
+            const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
+            acc[kx].x += c * gr.x + s * gi.x; acc[kx].y += c * gr.y + s * gi.y;
+            acc[kx].z += c * gr.z + s * gi.z; acc[kx].w += c * gr.w + s * gi.w;
+        }
+    }
+#pragma unroll
+    for (int kx = 0; kx < WS_MAXK; ++kx) {
+        if (kx >= KX) break;
+        *(float4*)(kg + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) = acc[kx];
+    }
+}
+
+}  // namespace
+
+extern "C" int pc_axis_linear(const pc_axis_desc* d, const float* in, const float* M, const float* bias, float* out, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(d && in && M && out, "pc_axis_linear: null pointer");
+    PC_CHECK_ARG(d->R > 0 && d->I > 0 && d->O > 0 && d->C > 0 && d->C % 4 == 0, "pc_axis_linear: bad extents (R=%d I=%d O=%d C=%d)", d->R, d->I, d->O, d->C);
+    PC_CHECK_ARG(d->in_split >= 1 && d->out_split >= 1, "pc_axis_linear: split < 1");
+    PC_CHECK_ARG(d->O * d->I * 4 <= 48 * 1024, "pc_axis_linear: matrix too large for LDS");
+    PC_CHECK_ARG((d->in_sr | d->in_hi | d->in_lo | d->out_sr | d->out_hi | d->out_lo) % 4 == 0, "pc_axis_linear: strides must be multiples of 4 floats");
+    PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)out % 16 == 0) && (!bias || (uintptr_t)bias % 16 == 0), "pc_axis_linear: 16-byte alignment");
+    AxK k;
+    k.in = in; k.M = M; k.bias = bias; k.out = out;
+    k.R = d->R; k.I = d->I; k.O = d->O; k.C4 = d->C / 4;
+    k.in_split = d->in_split; k.out_split = d->out_split; k.act = d->act; k.act_c0 = d->act_c0; k.accum = d->accum;
+    k.in_sr = d->in_sr; k.in_hi = d->in_hi; k.in_lo = d->in_lo; k.out_sr = d->out_sr; k.out_hi = d->out_hi; k.out_lo = d->out_lo;
+    const int64_t n = (int64_t)k.R * k.C4;
+    hipLaunchKernelGGL(axis_linear_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), (size_t)d->O * d->I * 4, s, k);
+    PC_CHECK_LAUNCH("axis_linear_kernel");
+    return PC_OK;
+}
+
+static int wspec_check(const void* a, const void* b, const void* c, int A, int B, int KY, int KX, int U, int sgn, const char* who) {
+    PC_CHECK_ARG(a && b && c, "%s: null pointer", who);
+    PC_CHECK_ARG(A > 0 && B > 0 && B % 4 == 0 && KY > 0 && KX > 0 && KX <= WS_MAXK && U > 0, "%s: bad extents (A=%d B=%d KY=%d KX=%d U=%d)", who, A, B, KY, KX, U);
+    PC_CHECK_ARG(sgn == 1 || sgn == -1, "%s: sgn must be +-1", who);
+    PC_CHECK_ARG(((uintptr_t)a % 16 == 0) && ((uintptr_t)c % 16 == 0), "%s: 16-byte alignment", who);
+    return PC_OK;
+}
+
+extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* out, pc_stream s_) {
+    const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, sgn, "pc_wspec_fwd");
+    if (rc != PC_OK) return rc;
+    const int64_t n = (int64_t)A * KY * (B / 4);
+    hipLaunchKernelGGL(wspec_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
+    PC_CHECK_LAUNCH("wspec_fwd_kernel");
+    return PC_OK;
+}
+
+extern "C" int pc_wspec_bwd(const float* dWg, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* kg, pc_stream s_) {
+    const int rc = wspec_check(dWg, tw, kg, A, B, KY, KX, U, sgn, "pc_wspec_bwd");
+    if (rc != PC_OK) return rc;
+    const int64_t n = (int64_t)A * KY * (B / 4);
+    hipLaunchKernelGGL(wspec_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
+    PC_CHECK_LAUNCH("wspec_bwd_kernel");
+    return PC_OK;
+}

@@ -34,6 +34,7 @@ class _Slot:
         self.a0 = base - self.arena.data_ptr()
         self.ops = p.resolve(dict(A=base, P=owner._P.data_ptr(), G=owner._G.data_ptr(), M=0, V=0, R=owner._R.data_ptr()))
         self.busy = False
+        p.upload_consts(self.view)
 
     def view(self, ref, nfloats, dtype=torch.float32):
         o = self.a0 + ref[1]

@@ -207,6 +207,23 @@ def adam_step(p, g, m, v, lr, step, b1=0.9, b2=0.999, eps=1e-6, gscale=1.0):
     capi.call("pc_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, b1, b2, eps, step, gscale, stream())
 
 
+def axis_linear(d, x, M, out, bias=None):
+    """d: dict with capi.AXIS_FIELDS (see include/picons.h pc_axis_desc)."""
+    st = capi.AxisDesc(*[int(d[k]) for k in capi.AXIS_FIELDS])
+    capi.call("pc_axis_linear", C.byref(st), ptr(x), ptr(M), ptr(bias), ptr(out), stream())
+    return out
+
+
+def wspec_fwd(w, tw, A, B, KY, KX, U, sgn, out):
+    capi.call("pc_wspec_fwd", ptr(w), ptr(tw), A, B, KY, KX, U, sgn, ptr(out), stream())
+    return out
+
+
+def wspec_bwd(dWg, tw, A, B, KY, KX, U, sgn, kg):
+    capi.call("pc_wspec_bwd", ptr(dWg), ptr(tw), A, B, KY, KX, U, sgn, ptr(kg), stream())
+    return kg
+
+
 def _lane_array(side):
     """(c_void_p array, n): torch's current stream as lane 0 + the caller's side streams."""
     hs = [torch.cuda.current_stream().cuda_stream] + [st.cuda_stream for st in (side or ())]

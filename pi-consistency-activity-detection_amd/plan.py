@@ -12,9 +12,11 @@ Memory spaces (pointer = base[space] + byte offset, resolved by Plan.resolve):
 """
 from dataclasses import dataclass, field
 
+import os
+
 import numpy as np
 
-from . import capi, desc as D, spec
+from . import capi, desc as D, spec, spectral
 
 ALIGN = 256
 
@@ -42,7 +44,7 @@ def off(ref, nfloats):
 
 
 class Plan:
-    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1):
+    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1, spectral_pc=None):
         """n = clips per forward pass; the batch the kernels see is N = groups*n.
         accum_grads: backward adds into the flat G buffer instead of overwriting it (drop-in nn.Module path,
         where the reference's two forward passes are two separate autograd graphs).
@@ -53,6 +55,9 @@ class Plan:
             raise ValueError("lanes must be 1..%d" % capi.MAX_LANES)
         self.lanes = lanes
         self.lane = 0
+        # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
+        self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
+        self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -95,6 +100,19 @@ class Plan:
         o = self.arena_bytes
         self.arena_bytes = (o + 4 * int(nfloats) + ALIGN - 1) // ALIGN * ALIGN
         return ("A", o)
+
+    def const(self, arr):
+        """Constant table in the arena (uploaded once by the owner of the arena)."""
+        arr = np.ascontiguousarray(arr, dtype=np.float32)
+        ref = self.alloc(arr.size)
+        self.consts.append((ref, arr))
+        return ref
+
+    def upload_consts(self, view):
+        """view(ref, nfloats) -> float32 device tensor over the arena."""
+        import torch
+        for ref, arr in self.consts:
+            view(ref, arr.size).copy_(torch.from_numpy(arr.reshape(-1)))
 
     def alloc_kg(self, nfloats):
         o = self.kg_used
@@ -450,15 +468,33 @@ class Plan:
         npose = spec.IN_CAPS * spec.POSE
         caps_in = self.tensor(N, (1, s20, s20), npose + spec.IN_CAPS, "caps_in")
         wpc = self.prep_conv_weight(["primary_caps.pose.weight", "primary_caps.a.weight"], [npose, spec.IN_CAPS], xd.C, (1, KP, KP), True)
-        wpc["tio"] = self.alloc(KP * KP * xd.C * (npose + spec.IN_CAPS))       # [tap][ci][co]: GEMM weights of the col2im dgrad
-        self.emit(capi.OP_TRANSPOSE, i=[1, npose + spec.IN_CAPS, KP * KP * xd.C, KP * KP * xd.C, npose + spec.IN_CAPS, 0], l=[0, 0],
-                  p=[wpc["fwd"], wpc["tio"]], lst="prep")
+        spectral_pc = self.spectral_pc and xd.thw[0] == 1
+        Cpc = npose + spec.IN_CAPS
+        if spectral_pc:
+            # row-spectral form: DFT along x, one grouped 9x1 conv over the frequencies, inverse DFT (spectral.py)
+            SL = spectral.Layout(N, xd.thw[1], xd.thw[2], xd.C, xd.ld, Cpc, caps_in.ld, KP, KP)
+            sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
+            wpc["wg"] = self.alloc(SL.nu * SL.wg_u)             # [u][2Co][ky][2Ci]  forward GEMM weights
+            wpc["wgt"] = self.alloc(SL.nu * SL.wg_u)            # [u][2Ci][ky][2Co]  dgrad GEMM weights
+            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu, 1], p=[wpc["fwd"], sm["tw"], wpc["wg"]], lst="prep")
+            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu, -1], p=[wpc["tr"], sm["tw"], wpc["wgt"]], lst="prep")
+        else:
+            wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
+            self.emit(capi.OP_TRANSPOSE, i=[1, Cpc, KP * KP * xd.C, KP * KP * xd.C, Cpc, 0], l=[0, 0],
+                      p=[wpc["fwd"], wpc["tio"]], lst="prep")
         pc_bias = self.alloc(npose + spec.IN_CAPS)
         self.emit(capi.OP_TRANSPOSE, i=[1, 1, npose, npose, 1, 0], l=[0, 0], p=[self.P("primary_caps.pose.bias"), pc_bias], lst="prep")
         self.emit(capi.OP_TRANSPOSE, i=[1, 1, spec.IN_CAPS, spec.IN_CAPS, 1, 0], l=[0, 0], p=[self.P("primary_caps.a.bias"), off(pc_bias, npose)], lst="prep")
         pc_dbias = self.alloc(npose + spec.IN_CAPS)
-        self.conv_bias_act("", xd, npose + spec.IN_CAPS, (1, KP, KP), (0, 0, 0), capi.ACT_SIGMOID, caps_in, act_c0=npose,
-                           bias_ref=pc_bias, wkey="primary_caps.pose.weight")
+        if spectral_pc:
+            xhat = self.alloc(SL.nu * SL.xhat_u)
+            yhat = self.alloc(SL.nu * SL.yhat_u)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_xhat(), capi.AXIS_FIELDS), p=[xd.ref, sm["F"], None, xhat])
+            self.conv_op(SL.conv(), xhat, wpc["wg"], yhat)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.yhat_to_y(capi.ACT_SIGMOID, npose), capi.AXIS_FIELDS), p=[yhat, sm["G"], pc_bias, caps_in.ref])
+        else:
+            self.conv_bias_act("", xd, Cpc, (1, KP, KP), (0, 0, 0), capi.ACT_SIGMOID, caps_in, act_c0=npose,
+                               bias_ref=pc_bias, wkey="primary_caps.pose.weight")
         # ConvCaps EM routing (capsules_ucf101.py:290-331)
         npos = N * s20 * s20
         comb = self.tensor(N, (1, s20, s20), C * 17, "comb")
@@ -489,13 +525,28 @@ class Plan:
                       p=[da_sl.ref, a_sl.ref, da_sl.ref, self.G("primary_caps.a.bias"), ws2])
             self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_NONE, npose, dcaps.ld, self.acc], l=[caps_in.rows],
                       p=[dcaps.ref, caps_in.ref, None, self.G("primary_caps.pose.bias"), ws2])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
-                      p=[dcaps.ref, xd.ref, wpc["kg"]])
+            if spectral_pc:
+                dyhat = self.alloc(SL.nu * SL.yhat_u)
+                dwg = self.alloc(SL.nu * SL.wg_u)
+                self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_dyhat(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dyhat])
+                wd = D.flatten(SL.wgrad_u(), D.WGRAD_FIELDS)
+                for u in range(SL.nu):        # one frequency per launch: dWg[u] = dY^[u]^T . X^[u], plain stores
+                    self.emit(capi.OP_WGRAD, i=wd, p=[off(dyhat, u * SL.yhat_u), off(xhat, u * SL.xhat_u), off(dwg, u * SL.wg_u)])
+                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu, 1], p=[dwg, sm["tw"], wpc["kg"]])
+            else:
+                self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
+                          p=[dcaps.ref, xd.ref, wpc["kg"]])
             self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
             dx, acc = self.grad_for_write(xd)
             F_pc = 2 * caps_in.rows * caps_in.C * xd.C * KP * KP
-            if xd.thw[0] == 1 and caps_in.thw[1] + KP - 1 == xd.thw[1]:
+            if spectral_pc:
+                dxhat = self.alloc(SL.nu * SL.xhat_u)
+                self.alg_dgrad(SL.flops())
+                for dd in SL.dgrad():
+                    self.conv_op(dd, dyhat, wpc["wgt"], dxhat, alg=0)
+                self.emit(capi.OP_AXIS, i=D.flatten(SL.dxhat_to_dx(dx.ld, acc), capi.AXIS_FIELDS), p=[dxhat, sm["Ft"], None, dx.ref])
+            elif xd.thw[0] == 1 and caps_in.thw[1] + KP - 1 == xd.thw[1]:
                 # exact 'full' correlation as GEMM + col2im: cols[o][(tap, ci)] = dcaps[o][:] . W[:, tap, ci] over the
                 # 20x20 real output positions only (the gather form multiplies 28x28 positions x 81 taps: 2x the FLOPs)
                 cols = self.alloc(caps_in.rows * KP * KP * xd.C)

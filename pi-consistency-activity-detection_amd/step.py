@@ -65,6 +65,7 @@ class StepEngine:
         self.R = torch.zeros(p.nrunning, **f32)
         base_a = (self.arena.data_ptr() + 255) // 256 * 256
         self._a0 = base_a - self.arena.data_ptr()
+        p.upload_consts(self.aview)
         self.bases = dict(A=base_a, P=self.P.data_ptr(), G=self.G.data_ptr(), M=self.M.data_ptr(), V=self.V.data_ptr(), R=self.R.data_ptr())
         self.ops = p.resolve(self.bases)
         self.step_count = 0

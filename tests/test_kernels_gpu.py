@@ -103,6 +103,29 @@ def test_wgrad_primarycaps_shape_remainder_rows():
     close(gw[512:].cpu(), ref[512:], what="rows 512..543 (64-row remainder launch)")
 
 
+@pytest.mark.parametrize("N,HW,Ci,Co,K", [(3, 14, 32, 40, 5), (2, 13, 16, 24, 3), (2, 28, 832, 544, 9)])
+def test_primary_caps_row_spectral_form_vs_torch(N, HW, Ci, Co, K):
+    """PrimaryCaps as DFT along the rows + grouped 9x1 complex conv + inverse DFT (spectral.py, csrc/spectral.hip):
+    output (bias, sigmoid on the activation channels), input gradient and weight gradient against F.conv2d + autograd;
+    even and odd widths, and the real layer size."""
+    from picons_amd import spectral
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(N, Ci, HW, HW, generator=g, requires_grad=True)
+    w = (torch.randn(Co, Ci, K, K, generator=g) / np.sqrt(Ci * K * K)).requires_grad_(True)
+    b = torch.randn(Co, generator=g) * 0.1
+    c0 = Co - 8
+    z = F.conv2d(x, w, b)
+    y = torch.cat([z[:, :c0], torch.sigmoid(z[:, c0:])], 1)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dzg = dz.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yg, dxg, dwg = spectral.primary_caps_fwd_bwd(xg, w.detach().to(DEV), b.to(DEV), dzg, act_c0=c0)
+    close(yg.permute(0, 3, 1, 2), y, rtol=2e-5, what="output")
+    close(dxg.permute(0, 3, 1, 2), x.grad, what="dgrad")
+    close(dwg, w.grad, what="wgrad")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)
