@@ -555,6 +555,11 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
     k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
     TileCfg c = choose_tile(k.Mg, groups, d->Co);
+    static const char* force = getenv("PICONS_CONV_TILE");      // diagnostic: "bm,bn" for grouped launches without BN partials
+    if (force && groups > 2 && !(d->flags & PC_F_BNPART)) {
+        int bm = 0, bn = 0;
+        if (sscanf(force, "%d,%d", &bm, &bn) == 2) { c.bm = bm; c.bn = bn; c.wm = (bm == 64 && bn == 128) ? 1 : (bn == 32 ? 4 : 2); }
+    }
     if (d->flags & PC_F_NFAST) {
         // n-fastest rows: a tile should hold whole groups of N samples of consecutive w so its tap box is tight;
         // when Wq*N is not a multiple of 128 use 64-row tiles (28 w x 16 samples = 7 tiles of 64, none straddles a row)
@@ -586,6 +591,7 @@ struct WgK {
     int P, Ntot, chunks_per_split, nchunks;
     int mbase, mend;                 // rows [mbase, mend) of D's channels handled by this launch
     int store;                       // one K slice: plain stores instead of atomics
+    int nbatch, dbs, sbs, gbs;       // > 1: blockIdx.z is a problem index (no split-K), pointers advance by these strides
 };
 
 template <int BM, int BN, int ABL = 0>
@@ -599,9 +605,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = p.mbase + blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int c_begin = blockIdx.z * p.chunks_per_split;
-    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    const bool batched = p.nbatch > 1;
+    const int c_begin = batched ? 0 : blockIdx.z * p.chunks_per_split;
+    const int c_end = batched ? p.nchunks : min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
+    const float* Dp = p.D + (batched ? (size_t)blockIdx.z * p.dbs : 0);
+    const float* Sp = p.S + (batched ? (size_t)blockIdx.z * p.sbs : 0);
+    float* gp = p.g + (batched ? (size_t)blockIdx.z * p.gbs : 0);
 
     // column decode for the S tile (constant over the K loop)
     constexpr int SC4 = BN / 4, DC4 = BM / 4;          // float4 columns per row
@@ -644,7 +654,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
             const int r = drow0 + DRP * j;
             const int pos = c * BK + r;
             const bool v = mval && pos < p.P;
-            const float* src = v ? p.D + (size_t)pos * p.ldd + m0 + dcol : g_zero16;
+            const float* src = v ? Dp + (size_t)pos * p.ldd + m0 + dcol : g_zero16;
             glds16(src, ld + j * 1024);
         }
 #pragma unroll
@@ -655,7 +665,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
             const bool v = nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
                            (unsigned)w < (unsigned)p.Ws;
             const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
-            const float* src = v ? p.S + ps * p.lds + cs : g_zero16;
+            const float* src = v ? Sp + ps * p.lds + cs : g_zero16;
             glds16(src, ls + j * 1024);
         }
     };
@@ -731,7 +741,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
                     const int tl = n / p.Cs, cc = n - tl * p.Cs;
                     const int ta = tl / tapHW, tr = tl - ta * tapHW, tb = tr / p.ntap[2], tc = tr - tb * p.ntap[2];
                     const int full = ((p.wk0[0] + ta) * p.KH + p.wk0[1] + tb) * p.KW + p.wk0[2] + tc;
-                    float* dst = p.g + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc;
+                    float* dst = gp + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc;
                     if (p.store) *dst = acc[i][j][r];
                     else atomicAdd(dst, acc[i][j][r]);
                 }
@@ -752,6 +762,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
     k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
     for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; }
+    PC_CHECK_ARG(d->nbatch <= 1 || (d->splitk == -1 && d->nbatch <= 65535), "pc_conv_wgrad: nbatch > 1 needs splitk = -1");
     PC_CHECK_ARG(d->splitk != -1 || (d->ntap[0] == d->KT && d->ntap[1] == d->KH && d->ntap[2] == d->KW), "pc_conv_wgrad: splitk = -1 (plain stores) needs every tap present");
     PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
     k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
@@ -767,6 +778,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         const int bm = small_m ? 64 : 128, bn = 128;
         const int mt = cdiv(m_hi - m_lo, bm), ntl = cdiv(k.Ntot, bn);
         int splitk = d->splitk;
+        const int nb = d->nbatch > 1 ? d->nbatch : 1;
         if (splitk == -1) splitk = 1;
         else if (splitk <= 0) {
             // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill two full rounds of
@@ -783,9 +795,10 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         WgK kk = k;
         kk.mbase = m_lo; kk.mend = m_hi;
         kk.store = d->splitk == -1;
+        kk.nbatch = nb; kk.dbs = d->dbstride; kk.sbs = d->sbstride; kk.gbs = d->gbstride;
         kk.chunks_per_split = cdiv(k.nchunks, splitk);
         splitk = cdiv(k.nchunks, kk.chunks_per_split);
-        dim3 grid(mt, ntl, splitk);
+        dim3 grid(mt, ntl, nb > 1 ? nb : splitk);
         if (abl) {
             if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
@@ -796,7 +809,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // rows x 527 column tiles), a remainder of at most 64 channels gets its own launch with 64-row tiles instead
     // of a padded 128-row tile (4.98 vs 5.23 ms); small problems lose more to the second launch than they save
     const int full = d->Cd / 128 * 128, rem = d->Cd - full;
-    const bool deep = (int64_t)(full / 128) * cdiv(k.Ntot, 128) >= 1024;
+    const bool deep = (int64_t)(full / 128) * cdiv(k.Ntot, 128) * (d->nbatch > 1 ? d->nbatch : 1) >= 1024;
     if (d->Cd <= 64) launch(0, d->Cd, true);
     else if (rem == 0 || rem > 64 || !deep) launch(0, d->Cd, false);
     else { launch(0, full, false); launch(full, d->Cd, true); }

@@ -63,9 +63,10 @@ __global__ __launch_bounds__(256) void axis_linear_kernel(const AxK p) {
     }
 }
 
-constexpr int WS_MAXK = 16;
+constexpr int WS_MAXK = 16;     // generic bound; the 9-tap PrimaryCaps kernel gets its own instantiation
 
 // in [A][KY*KX][B] -> out [U][2A][KY][2B]
+template <int MAXK>
 __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict__ in, const float* __restrict__ tw, int A, int B4, int KY,
                                                          int KX, int U, float sgn, float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -74,15 +75,15 @@ __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict_
     const int ky = (int)((idx / B4) % KY);
     const int a = (int)(idx / ((int64_t)B4 * KY));
     const int B = B4 * 4;
-    float4 v[WS_MAXK];
+    float4 v[MAXK];
 #pragma unroll
-    for (int kx = 0; kx < WS_MAXK; ++kx)
+    for (int kx = 0; kx < MAXK; ++kx)
         v[kx] = kx < KX ? *(const float4*)(in + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) : make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t row = (int64_t)KY * 2 * B;                 // floats per output channel row [KY][2B]
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U; ++u) {       // (one frequency per block instead re-reads the taps U times: 1.3 vs 0.5 ms)
         float4 wr = make_float4(0.f, 0.f, 0.f, 0.f), wi = wr;
 #pragma unroll
-        for (int kx = 0; kx < WS_MAXK; ++kx) {
+        for (int kx = 0; kx < MAXK; ++kx) {
             if (kx >= KX) break;
             const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
             wr.x += c * v[kx].x; wr.y += c * v[kx].y; wr.z += c * v[kx].z; wr.w += c * v[kx].w;
@@ -98,6 +99,7 @@ __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict_
 }
 
 // dWg [U][2A][KY][2B] -> kg [A][KY*KX][B]
+template <int MAXK>
 __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict__ dWg, const float* __restrict__ tw, int A, int B4, int KY,
                                                          int KX, int U, float sgn, float* __restrict__ kg) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -106,10 +108,11 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
     const int ky = (int)((idx / B4) % KY);
     const int a = (int)(idx / ((int64_t)B4 * KY));
     const int B = B4 * 4;
-    float4 acc[WS_MAXK];
+    float4 acc[MAXK];
 #pragma unroll
-    for (int kx = 0; kx < WS_MAXK; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int kx = 0; kx < MAXK; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t row = (int64_t)KY * 2 * B;
+#pragma unroll 5
     for (int u = 0; u < U; ++u) {
         const float* d0 = dWg + ((int64_t)u * 2 * A + a) * row + (int64_t)ky * 2 * B + b;
         const float* d1 = d0 + (int64_t)A * row;
@@ -117,7 +120,7 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
         const float4 gr = make_float4(d00.x + d11.x, d00.y + d11.y, d00.z + d11.z, d00.w + d11.w);
         const float4 gi = make_float4(sgn * (d01.x - d10.x), sgn * (d01.y - d10.y), sgn * (d01.z - d10.z), sgn * (d01.w - d10.w));
 #pragma unroll
-        for (int kx = 0; kx < WS_MAXK; ++kx) {
+        for (int kx = 0; kx < MAXK; ++kx) {
             if (kx >= KX) break;
             const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
             acc[kx].x += c * gr.x + s * gi.x; acc[kx].y += c * gr.y + s * gi.y;
@@ -125,7 +128,7 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
         }
     }
 #pragma unroll
-    for (int kx = 0; kx < WS_MAXK; ++kx) {
+    for (int kx = 0; kx < MAXK; ++kx) {
         if (kx >= KX) break;
         *(float4*)(kg + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) = acc[kx];
     }
@@ -164,7 +167,8 @@ extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int 
     const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, sgn, "pc_wspec_fwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
-    hipLaunchKernelGGL(wspec_fwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
+    if (KX <= 9) hipLaunchKernelGGL(wspec_fwd_kernel<9>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
+    else hipLaunchKernelGGL(wspec_fwd_kernel<WS_MAXK>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
     PC_CHECK_LAUNCH("wspec_fwd_kernel");
     return PC_OK;
 }
@@ -173,7 +177,8 @@ extern "C" int pc_wspec_bwd(const float* dWg, const float* tw, int A, int B, int
     const int rc = wspec_check(dWg, tw, kg, A, B, KY, KX, U, sgn, "pc_wspec_bwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
-    hipLaunchKernelGGL(wspec_bwd_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
+    if (KX <= 9) hipLaunchKernelGGL(wspec_bwd_kernel<9>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
+    else hipLaunchKernelGGL(wspec_bwd_kernel<WS_MAXK>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
     PC_CHECK_LAUNCH("wspec_bwd_kernel");
     return PC_OK;
 }

@@ -529,9 +529,7 @@ class Plan:
                 dyhat = self.alloc(SL.nu * SL.yhat_u)
                 dwg = self.alloc(SL.nu * SL.wg_u)
                 self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_dyhat(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dyhat])
-                wd = D.flatten(SL.wgrad_u(), D.WGRAD_FIELDS)
-                for u in range(SL.nu):        # one frequency per launch: dWg[u] = dY^[u]^T . X^[u], plain stores
-                    self.emit(capi.OP_WGRAD, i=wd, p=[off(dyhat, u * SL.yhat_u), off(xhat, u * SL.xhat_u), off(dwg, u * SL.wg_u)])
+                self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dyhat, xhat, dwg])
                 self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu, 1], p=[dwg, sm["tw"], wpc["kg"]])
             else:
                 self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
@@ -733,7 +731,8 @@ class Plan:
                 elif kind == capi.OP_WGRAD:
                     N, Tq, Hq, Wq, Cd, Cs = i[0], i[1], i[2], i[3], i[4], i[9]
                     nt = i[14] * i[15] * i[16]
-                    s += 2 * N * Tq * Hq * Wq * (27 if (Cd == 32 and Cs == 128 and nt == 1) else Cd) * (3 if Cs == 4 else Cs) * nt
+                    nb = max(1, i[30]) if len(i) > 30 else 1          # problems batched in one launch (spectral PrimaryCaps)
+                    s += 2 * N * Tq * Hq * Wq * (27 if (Cd == 32 and Cs == 128 and nt == 1) else Cd) * (3 if Cs == 4 else Cs) * nt * nb
             tot[name] = s
         return tot
 

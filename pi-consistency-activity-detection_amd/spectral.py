@@ -106,10 +106,13 @@ class Layout:
             d["wgstride"] = self.wg_u
         return out
 
-    def wgrad_u(self):
-        """One frequency: dWg[u] [2Co][KY][2Ci] = dY^[u]^T . X^[u]; 10 K-chunks at bs=8, so one slice, plain stores."""
-        return D.wgrad(self.N, (1, self.OH, 1), self.Co2, self.Co2, (1, self.H, 1), self.Ci2, self.Ci2, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
-                       splitk=-1)
+    def wgrad(self):
+        """dWg[u] [2Co][KY][2Ci] = dY^[u]^T . X^[u] for every frequency in ONE launch (blockIdx.z = u): K is only the
+        N*OH rows of one frequency (10 chunks at bs=8), so one slice each, plain stores, no zero-fill."""
+        d = D.wgrad(self.N, (1, self.OH, 1), self.Co2, self.Co2, (1, self.H, 1), self.Ci2, self.Ci2, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+                    splitk=-1)
+        d.update(nbatch=self.nu, dbstride=self.yhat_u, sbstride=self.xhat_u, gbstride=self.wg_u)
+        return d
 
     def flops(self):
         """Issued-algorithmic FLOPs of the forward grouped conv (= dgrad = wgrad): 2 * rows * 2Co * 9 * 2Ci per frequency."""
@@ -141,9 +144,7 @@ def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):
     dyhat = torch.empty(L.nu * L.yhat_u, **f32)
     ops.axis_linear(L.dy_to_dyhat(Co), dy, m["Gt"], dyhat)
     dwg = torch.empty(L.nu * L.wg_u, **f32)
-    wd = L.wgrad_u()
-    for u in range(L.nu):
-        ops.conv_wgrad(wd, dyhat[u * L.yhat_u:], xhat[u * L.xhat_u:], dwg[u * L.wg_u:])
+    ops.conv_wgrad(L.wgrad(), dyhat, xhat, dwg)
     kg = torch.empty(Co, KY * KX, Ci, **f32)
     ops.wspec_bwd(dwg, m["tw"], Co, Ci, KY, KX, L.nu, 1, kg)
     dw = kg.permute(0, 2, 1).reshape(Co, Ci, KY, KX)

@@ -18,12 +18,8 @@ bias = torch.zeros(Co, **f32); dy = torch.randn(N, L.OH, L.OW, Co, **f32)
 xhat = torch.empty(L.nu * L.xhat_u, **f32); wg = torch.empty(L.nu * L.wg_u, **f32); yhat = torch.empty(L.nu * L.yhat_u, **f32)
 y = torch.empty(N, L.OH, L.OW, Co, **f32); dyhat = torch.empty_like(yhat); dwg = torch.empty_like(wg); kg = torch.empty(Co, K * K, Ci, **f32)
 wgt = torch.empty_like(wg); dxhat = torch.empty_like(xhat); dx = torch.empty_like(x)
-wd = L.wgrad_u()
-
-
 def wgrad_all():
-    for u in range(L.nu):
-        ops.conv_wgrad(wd, dyhat[u * L.yhat_u:], xhat[u * L.xhat_u:], dwg[u * L.wg_u:])
+    ops.conv_wgrad(L.wgrad(), dyhat, xhat, dwg)
 
 
 def dgrad_all():
@@ -37,7 +33,7 @@ stages = [
     ("grouped conv 9x1, 15 freqs", lambda: ops.conv_fwd(L.conv(), xhat, wg, yhat)),
     ("Y^ -> y (+bias, sigmoid)", lambda: ops.axis_linear(L.yhat_to_y(capi.ACT_SIGMOID, 512), yhat, m["G"], y, bias=bias)),
     ("dy -> dY^", lambda: ops.axis_linear(L.dy_to_dyhat(Co), dy, m["Gt"], dyhat)),
-    ("wgrad x15", wgrad_all),
+    ("wgrad, 15 freqs in one launch", wgrad_all),
     ("weight-spectrum adjoint", lambda: ops.wspec_bwd(dwg, m["tw"], Co, Ci, K, K, L.nu, 1, kg)),
     ("weight spectrum (dgrad layout)", lambda: ops.wspec_fwd(wt, m["tw"], Ci, Co, K, K, L.nu, -1, wgt)),
     ("grouped dgrad", dgrad_all),

@@ -61,7 +61,7 @@ def main():
             d = unflat(op[1], D.WGRAD_FIELDS)
             M = d["N"] * d["Tq"] * d["Hq"] * d["Wq"]
             taps = d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
-            fl = 2 * M * d["Cd"] * d["Cs"] * taps
+            fl = 2 * M * d["Cd"] * d["Cs"] * taps * max(1, d.get("nbatch", 0))
             what = "wgrad K=%-7d Cd=%-5d Cs=%-4d taps=%s" % (M, d["Cd"], d["Cs"], "x".join(map(str, d["ntap"])))
         out.append((dur, fl, name, kn, blocks, what))
     print("%7s %7s %7s %-4s %6s %-34s %s" % ("ms", "TF/s", "lost", "list", "blocks", "kernel", "launch (issued shape, trimmed taps)"))
