@@ -91,8 +91,8 @@ typedef struct pc_wgrad_desc {
     int32_t KT, KH, KW;             /* full weight tap extents: g is [Cd][KT*KH*KW][Cs] */
     int32_t splitk;                 /* 0 = choose; -1 = one slice written with plain stores (g need not be initialised;
                                      * only valid when no tap is trimmed: ntap == (KT,KH,KW)) */
-    int32_t nbatch;                 /* 0/1 = one problem; > 1: that many independent problems in ONE launch (blockIdx.z),
-                                     * D, S and g advanced by the strides below (floats) per problem; requires splitk = -1 */
+    int32_t nbatch;                 /* 0/1 = one problem; > 1: that many independent problems in ONE launch (blockIdx.z =
+                                     * problem * slices + slice), D, S and g advanced by the strides below (floats) */
     int32_t dbstride, sbstride, gbstride;
 } pc_wgrad_desc;
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);

@@ -591,7 +591,7 @@ struct WgK {
     int P, Ntot, chunks_per_split, nchunks;
     int mbase, mend;                 // rows [mbase, mend) of D's channels handled by this launch
     int store;                       // one K slice: plain stores instead of atomics
-    int nbatch, dbs, sbs, gbs;       // > 1: blockIdx.z is a problem index (no split-K), pointers advance by these strides
+    int nsplit, dbs, sbs, gbs;       // blockIdx.z = problem * nsplit + K slice; pointers advance by these strides per problem
 };
 
 template <int BM, int BN, int ABL = 0>
@@ -605,13 +605,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = p.mbase + blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const bool batched = p.nbatch > 1;
-    const int c_begin = batched ? 0 : blockIdx.z * p.chunks_per_split;
-    const int c_end = batched ? p.nchunks : min(p.nchunks, c_begin + p.chunks_per_split);
+    // blockIdx.z = problem * nsplit + K slice
+    const int prob = blockIdx.z / p.nsplit, slice = blockIdx.z - prob * p.nsplit;
+    const int c_begin = slice * p.chunks_per_split;
+    const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
-    const float* Dp = p.D + (batched ? (size_t)blockIdx.z * p.dbs : 0);
-    const float* Sp = p.S + (batched ? (size_t)blockIdx.z * p.sbs : 0);
-    float* gp = p.g + (batched ? (size_t)blockIdx.z * p.gbs : 0);
+    const float* Dp = p.D + (size_t)prob * p.dbs;
+    const float* Sp = p.S + (size_t)prob * p.sbs;
+    float* gp = p.g + (size_t)prob * p.gbs;
 
     // column decode for the S tile (constant over the K loop)
     constexpr int SC4 = BN / 4, DC4 = BM / 4;          // float4 columns per row
@@ -688,41 +689,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
         const int buf = ABL ? 0 : ((c - c_begin) & 1);
         if (!ABL) ptab_fill(c + 2);
         if (!ABL && c + 1 < c_end) gload(c + 1, buf ^ 1);
-        // a wave's two 32-row MFMA tiles are the even / odd rows of its 64-row slab (same for columns): one
-        // ds_read_b64 feeds both tiles.  Fragments are double-buffered in registers: the reads of k-step ks+1
-        // are issued before the MFMAs of k-step ks, so no MFMA group waits on an LDS round trip.
-        float af[2][TM], bf[2][TN];
-        auto fread = [&](int ks, float (&a)[TM], float (&b)[TN]) {
-            if (TM == 2) {
-                const float2 v = *(const float2*)&Ds[buf][ks * 2 + kh][wm * 64 + 2 * (lane & 31)];
-                a[0] = v.x; a[TM - 1] = v.y;
-            } else {
-                a[0] = Ds[buf][ks * 2 + kh][ml];
-            }
-            if (TN == 2) {
-                const float2 v = *(const float2*)&Ss[buf][ks * 2 + kh][wn * 64 + 2 * (lane & 31)];
-                b[0] = v.x; b[TN - 1] = v.y;
-            } else {
-                b[0] = Ss[buf][ks * 2 + kh][nl];
-            }
-        };
-        fread(0, af[0], bf[0]);
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
-            if (ks + 1 < BK / 2) fread(ks + 1, af[(ks + 1) & 1], bf[(ks + 1) & 1]);
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][ks * 2 + kh][ml + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][ks * 2 + kh][nl + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-        }
-        // pin the software pipeline: hipcc pairs two k-steps per ds_read2st64, i.e. one A + one B read per group of
-        // 2*TM*TN MFMAs; keep the reads of group g+1 in flight while group g's MFMAs issue
-        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-#pragma unroll
-        for (int g = 0; g < BK / 4; ++g) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * TM * TN, 0);
-            if (g + 2 < BK / 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
     }
@@ -730,12 +708,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int rho = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            const int m = m0 + wm * (BM / 2) + (TM == 2 ? 2 * rho + i : rho);
+            const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.mend) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * (BN / 2) + (TN == 2 ? 2 * (lane & 31) + j : (lane & 31));
+                const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
                 if (n < p.Ntot) {
                     // trimmed column (tap_local, cs) -> column of the full [KT*KH*KW][Cs] layout
                     const int tl = n / p.Cs, cc = n - tl * p.Cs;
@@ -762,7 +739,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
     k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
     for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; }
-    PC_CHECK_ARG(d->nbatch <= 1 || (d->splitk == -1 && d->nbatch <= 65535), "pc_conv_wgrad: nbatch > 1 needs splitk = -1");
+    PC_CHECK_ARG(d->nbatch <= 4096, "pc_conv_wgrad: nbatch too large");
     PC_CHECK_ARG(d->splitk != -1 || (d->ntap[0] == d->KT && d->ntap[1] == d->KH && d->ntap[2] == d->KW), "pc_conv_wgrad: splitk = -1 (plain stores) needs every tap present");
     PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
     k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
@@ -784,21 +761,22 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill two full rounds of
             // slots and never spill a few blocks into a third (1026 blocks ran ~25 % slower than 1022); at least
             // 8 chunks (256 positions) per slice
-            const int64_t tiles = (int64_t)mt * ntl;
+            const int64_t tiles = (int64_t)mt * ntl * nb;
             const int slots = small_m ? 768 : 512;
             splitk = (int)(2 * slots / tiles);
             const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
             if (splitk > maxsplit) splitk = maxsplit;
             if (splitk < 1) splitk = 1;
         }
-        if (splitk > 65535) splitk = 65535;
+        if ((int64_t)splitk * nb > 65535) splitk = 65535 / nb;
         WgK kk = k;
         kk.mbase = m_lo; kk.mend = m_hi;
         kk.store = d->splitk == -1;
-        kk.nbatch = nb; kk.dbs = d->dbstride; kk.sbs = d->sbstride; kk.gbs = d->gbstride;
+        kk.dbs = nb > 1 ? d->dbstride : 0; kk.sbs = nb > 1 ? d->sbstride : 0; kk.gbs = nb > 1 ? d->gbstride : 0;
         kk.chunks_per_split = cdiv(k.nchunks, splitk);
         splitk = cdiv(k.nchunks, kk.chunks_per_split);
-        dim3 grid(mt, ntl, nb > 1 ? nb : splitk);
+        kk.nsplit = splitk;
+        dim3 grid(mt, ntl, nb * splitk);
         if (abl) {
             if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);

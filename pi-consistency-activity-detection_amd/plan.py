@@ -599,10 +599,10 @@ class Plan:
             Gc = self.alloc(N * 128 * 27 * 32)
             self.emit(capi.OP_FILL, p=[Gc], l=[N * 128 * 27 * 32], f=[0.0])
             xin_per = cat112.thw[0] * cat112.thw[1] * cat112.thw[2] * cat112.ld
-            for n in range(N):        # per-sample dWc[n][ci][tap][j] = sum_i x[n,i,ci] * dproj[n, 2i-1+k, j]
-                wd = D.trim_wgrad(D.wgrad(1, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1))
-                self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS),
-                          p=[off(cat112.ref, n * xin_per), off(dproj.ref, n * per_n * 32), off(Gc, n * 128 * 27 * 32)])
+            # per-sample dWc[n][ci][tap][j] = sum_i x[n,i,ci] * dproj[n, 2i-1+k, j]: N problems in one launch
+            wd = D.trim_wgrad(D.wgrad(1, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1))
+            wd.update(nbatch=N, dbstride=xin_per, sbstride=per_n * 32, gbstride=128 * 27 * 32)
+            self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS), p=[cat112.ref, dproj.ref, Gc])
             self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
                       p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
             self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")

@@ -40,11 +40,24 @@ def main():
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
     st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"]]
-    if len(st) != len(ops):
-        raise SystemExit("trace has %d GEMM launches per step, plan has %d ops (lanes / version mismatch?)" % (len(st), len(ops)))
+    def n_kernels(op):
+        """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (csrc/conv.hip)."""
+        if op[0] != capi.OP_WGRAD:
+            return 1
+        d = unflat(op[1], D.WGRAD_FIELDS)
+        full, rem = d["Cd"] // 128 * 128, d["Cd"] % 128
+        ntot = d["ntap"][0] * d["ntap"][1] * d["ntap"][2] * d["Cs"]
+        deep = (full // 128) * -(-ntot // 128) * max(1, d.get("nbatch", 0)) >= 1024
+        return 2 if (d["Cd"] > 64 and 0 < rem <= 64 and deep) else 1
+    if len(st) != sum(n_kernels(op) for _n, op in ops):
+        raise SystemExit("trace has %d GEMM launches per step, plan expects %d (lanes / version mismatch?)" %
+                         (len(st), sum(n_kernels(op) for _n, op in ops)))
     out = []
-    for (name, op), r in zip(ops, st):
-        dur = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    it = iter(st)
+    for name, op in ops:
+        rs = [next(it) for _ in range(n_kernels(op))]
+        r = rs[0]
+        dur = sum((int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6 for q in rs)
         kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         blocks = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_X"])
         if op[0] == capi.OP_CONV:
