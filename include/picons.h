@@ -240,9 +240,13 @@ int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
 /* ------------------------------------------------------------------------------------------
  * Row-spectral PrimaryCaps (capsules_ucf101.py:43-49: Conv2d 832 -> 512+32, 9x9, stride 1).  A real DFT
  * of length P = image width along the rows turns the kx taps into a product per frequency; what is left
- * is a 9x1 conv with complex channels per frequency, run in real form by pc_conv_fwd / pc_conv_wgrad as a
- * grouped conv (group = frequency, 2*Ci -> 2*Co channels): 3x fewer multiply-adds than the direct form,
- * identical in exact arithmetic.  These three HBM-bound helpers are the rest of it. */
+ * is a 9x1 conv with complex channels per frequency u = 0..P/2.  The complex product is taken in its
+ * three-multiplication form (X = Xr + i Xi, conj(W) = Wr - i Wi):
+ *     t0 = (Xr + Xi) Wr,  t1 = Xi (Wr - Wi),  t2 = Xr (Wr + Wi);   Re = t0 - t1,  Im = t0 - t2,
+ * so the whole layer is ONE grouped real conv for pc_conv_fwd / pc_conv_wgrad (3 groups per frequency,
+ * Ci -> Co, 9x1 taps): a quarter of the direct form's multiply-adds, equal to it in exact arithmetic.
+ * The sums/differences of the operands and results are folded into the DFT matrices.  These three
+ * HBM-bound helpers are the rest of it. */
 /* out[r][o][c] = sum_i M[o][i] * in[r][i][c] (+ bias[c]; activation on channels >= act_c0; accum adds
  * the old value first): a small dense matrix along one tensor axis.  Element offsets (floats):
  * in:  r*in_sr  + (i / in_split)*in_hi   + (i % in_split)*in_lo  + c
@@ -253,14 +257,13 @@ typedef struct pc_axis_desc {
     int32_t in_sr, in_hi, in_lo, out_sr, out_hi, out_lo;
 } pc_axis_desc;
 int pc_axis_linear(const pc_axis_desc* d, const float* in, const float* M, const float* bias, float* out, pc_stream s);
-/* weights in a kernel layout in[A][KY*KX][B] -> their row spectrum in real form out[U][2A][KY][2B] with
- * Wr = sum_kx in*tw[u][kx][0], Wi = sum_kx in*tw[u][kx][1] (tw = cos, -sin of 2*pi*u*kx/P):
- * out[(0,a)][(0,b)] = Wr, [(0,a)][(1,b)] = sgn*Wi, [(1,a)][(0,b)] = -sgn*Wi, [(1,a)][(1,b)] = Wr.
- * sgn = +1 with in = [Co][taps][Ci] gives the forward GEMM weights of Y = X * conj(W); sgn = -1 with
- * in = [Ci][taps][Co] gives the dgrad GEMM weights. */
-int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* out, pc_stream s);
-/* adjoint of pc_wspec_fwd: kg[a][ky*KX+kx][b] = sum_u tw[u][kx][0]*(d00+d11) + tw[u][kx][1]*sgn*(d01-d10) */
-int pc_wspec_bwd(const float* dWg, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* kg, pc_stream s);
+/* weights in a kernel layout in[A][KY*KX][B] -> the three weight planes per frequency out[U][3][A][KY][B]:
+ *   V0 = Wr, V1 = Wr - Wi, V2 = Wr + Wi,  Wr = sum_kx in*tw[u][kx][0], Wi = sum_kx in*tw[u][kx][1]
+ * (tw = cos, -sin of 2*pi*u*kx/P).  in = [Co][taps][Ci] gives the forward GEMM weights, in = [Ci][taps][Co]
+ * the dgrad GEMM weights. */
+int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, float* out, pc_stream s);
+/* adjoint: kg[a][ky*KX+kx][b] = sum_u tw[u][kx][0]*(d0+d1+d2) + tw[u][kx][1]*(d2-d1), dV = [U][3][A][KY][B] */
+int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, float* kg, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * Op-list runner: the host builds the step as a flat list of POD ops once (shape inference and
@@ -280,8 +283,8 @@ enum {
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
     PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS, PC_OP_COL2IM,
     PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
-    PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U, sgn; p = in, tw, out */
-    PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U, sgn; p = dWg, tw, kg */
+    PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U; p = in, tw, out */
+    PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U; p = dV, tw, kg */
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP__COUNT

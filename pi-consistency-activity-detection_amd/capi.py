@@ -92,8 +92,8 @@ _SIGS = {
     "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
     "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "pc_axis_linear": (i32, [vp, vp, vp, vp, vp, vp]),
-    "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
-    "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),
     "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp, i32]),

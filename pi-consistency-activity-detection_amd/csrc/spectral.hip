@@ -1,8 +1,9 @@
 // Row-spectral form of PrimaryCaps (capsules_ucf101.py:43-49, a 9x9 stride-1 Conv2d 832 -> 512+32 on 28x28):
 // a length-P real DFT along the image rows turns the kx taps into a per-frequency product, leaving a 9-tap
-// conv along y with complex channels per frequency u = 0..P/2.  In real form that is one grouped conv
-// (group = frequency, 2*Ci -> 2*Co channels, 9x1 taps) run by the ordinary gather-GEMM kernels: 3x fewer
-// multiply-adds than the 81-tap direct form, exact in exact arithmetic.  This file holds the three small
+// conv along y with complex channels per frequency u = 0..P/2.  With the three-multiplication form of the
+// complex product that is one grouped REAL conv (3 groups per frequency, Ci -> Co channels, 9x1 taps) run by
+// the ordinary gather-GEMM kernels: 4x fewer multiply-adds than the 81-tap direct form, equal to it in exact
+// arithmetic.  This file holds the three small
 // HBM-bound kernels around those GEMMs: a dense matrix applied along one tensor axis (DFT, inverse DFT and
 // their transposes), the weight spectrum in the GEMM layouts, and its adjoint.
 #include "common.h"
@@ -63,73 +64,68 @@ __global__ __launch_bounds__(256) void axis_linear_kernel(const AxK p) {
     }
 }
 
-constexpr int WS_MAXK = 16;     // generic bound; the 9-tap PrimaryCaps kernel gets its own instantiation
+constexpr int WS_MAXK = 16;     // tap counts 1..16 are instantiated (the tap arrays must stay in registers)
 
-// in [A][KY*KX][B] -> out [U][2A][KY][2B]
-template <int MAXK>
+// in [A][KY*KX][B] -> out [U][3][A][KY][B]: V0 = Wr, V1 = Wr - Wi, V2 = Wr + Wi
+template <int KX>
 __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict__ in, const float* __restrict__ tw, int A, int B4, int KY,
-                                                         int KX, int U, float sgn, float* __restrict__ out) {
+                                                         int U, float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)A * KY * B4) return;
     const int b = (int)(idx % B4) * 4;
     const int ky = (int)((idx / B4) % KY);
     const int a = (int)(idx / ((int64_t)B4 * KY));
     const int B = B4 * 4;
-    float4 v[MAXK];
+    float4 v[KX];
 #pragma unroll
-    for (int kx = 0; kx < MAXK; ++kx)
-        v[kx] = kx < KX ? *(const float4*)(in + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) : make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t row = (int64_t)KY * 2 * B;                 // floats per output channel row [KY][2B]
+    for (int kx = 0; kx < KX; ++kx) v[kx] = *(const float4*)(in + ((int64_t)a * KY * KX + ky * KX + kx) * B + b);
+    const int64_t plane = (int64_t)A * KY * B;               // floats per (u, j) plane [A][KY][B]
+    float* o = out + ((int64_t)a * KY + ky) * B + b;
     for (int u = 0; u < U; ++u) {       // (one frequency per block instead re-reads the taps U times: 1.3 vs 0.5 ms)
         float4 wr = make_float4(0.f, 0.f, 0.f, 0.f), wi = wr;
 #pragma unroll
-        for (int kx = 0; kx < MAXK; ++kx) {
-            if (kx >= KX) break;
+        for (int kx = 0; kx < KX; ++kx) {
             const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
             wr.x += c * v[kx].x; wr.y += c * v[kx].y; wr.z += c * v[kx].z; wr.w += c * v[kx].w;
             wi.x += s * v[kx].x; wi.y += s * v[kx].y; wi.z += s * v[kx].z; wi.w += s * v[kx].w;
         }
-        const float4 pwi = make_float4(sgn * wi.x, sgn * wi.y, sgn * wi.z, sgn * wi.w);
-        const float4 nwi = make_float4(-pwi.x, -pwi.y, -pwi.z, -pwi.w);
-        float* o0 = out + ((int64_t)u * 2 * A + a) * row + (int64_t)ky * 2 * B + b;          // (0, a)
-        float* o1 = o0 + (int64_t)A * row;                                                      // (1, a)
-        *(float4*)o0 = wr; *(float4*)(o0 + B) = pwi;
-        *(float4*)o1 = nwi; *(float4*)(o1 + B) = wr;
+        float* ou = o + (int64_t)u * 3 * plane;
+        *(float4*)ou = wr;
+        *(float4*)(ou + plane) = make_float4(wr.x - wi.x, wr.y - wi.y, wr.z - wi.z, wr.w - wi.w);
+        *(float4*)(ou + 2 * plane) = make_float4(wr.x + wi.x, wr.y + wi.y, wr.z + wi.z, wr.w + wi.w);
     }
 }
 
-// dWg [U][2A][KY][2B] -> kg [A][KY*KX][B]
-template <int MAXK>
-__global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict__ dWg, const float* __restrict__ tw, int A, int B4, int KY,
-                                                         int KX, int U, float sgn, float* __restrict__ kg) {
+// dV [U][3][A][KY][B] -> kg [A][KY*KX][B]:  dWr = d0 + d1 + d2, dWi = d2 - d1
+template <int KX>
+__global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ tw, int A, int B4, int KY,
+                                                         int U, float* __restrict__ kg) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)A * KY * B4) return;
     const int b = (int)(idx % B4) * 4;
     const int ky = (int)((idx / B4) % KY);
     const int a = (int)(idx / ((int64_t)B4 * KY));
     const int B = B4 * 4;
-    float4 acc[MAXK];
+    float4 acc[KX];
 #pragma unroll
-    for (int kx = 0; kx < MAXK; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int64_t row = (int64_t)KY * 2 * B;
+    for (int kx = 0; kx < KX; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t plane = (int64_t)A * KY * B;
+    const float* d = dV + ((int64_t)a * KY + ky) * B + b;
 #pragma unroll 5
     for (int u = 0; u < U; ++u) {
-        const float* d0 = dWg + ((int64_t)u * 2 * A + a) * row + (int64_t)ky * 2 * B + b;
-        const float* d1 = d0 + (int64_t)A * row;
-        const float4 d00 = *(const float4*)d0, d01 = *(const float4*)(d0 + B), d10 = *(const float4*)d1, d11 = *(const float4*)(d1 + B);
-        const float4 gr = make_float4(d00.x + d11.x, d00.y + d11.y, d00.z + d11.z, d00.w + d11.w);
-        const float4 gi = make_float4(sgn * (d01.x - d10.x), sgn * (d01.y - d10.y), sgn * (d01.z - d10.z), sgn * (d01.w - d10.w));
+        const float* du = d + (int64_t)u * 3 * plane;
+        const float4 d0 = *(const float4*)du, d1 = *(const float4*)(du + plane), d2 = *(const float4*)(du + 2 * plane);
+        const float4 gr = make_float4(d0.x + d1.x + d2.x, d0.y + d1.y + d2.y, d0.z + d1.z + d2.z, d0.w + d1.w + d2.w);
+        const float4 gi = make_float4(d2.x - d1.x, d2.y - d1.y, d2.z - d1.z, d2.w - d1.w);
 #pragma unroll
-        for (int kx = 0; kx < MAXK; ++kx) {
-            if (kx >= KX) break;
+        for (int kx = 0; kx < KX; ++kx) {
             const float c = tw[(u * KX + kx) * 2], s = tw[(u * KX + kx) * 2 + 1];
             acc[kx].x += c * gr.x + s * gi.x; acc[kx].y += c * gr.y + s * gi.y;
             acc[kx].z += c * gr.z + s * gi.z; acc[kx].w += c * gr.w + s * gi.w;
         }
     }
 #pragma unroll
-    for (int kx = 0; kx < MAXK; ++kx) {
-        if (kx >= KX) break;
+    for (int kx = 0; kx < KX; ++kx) {
         *(float4*)(kg + ((int64_t)a * KY * KX + ky * KX + kx) * B + b) = acc[kx];
     }
 }
@@ -155,30 +151,35 @@ extern "C" int pc_axis_linear(const pc_axis_desc* d, const float* in, const floa
     return PC_OK;
 }
 
-static int wspec_check(const void* a, const void* b, const void* c, int A, int B, int KY, int KX, int U, int sgn, const char* who) {
+static int wspec_check(const void* a, const void* b, const void* c, int A, int B, int KY, int KX, int U, const char* who) {
     PC_CHECK_ARG(a && b && c, "%s: null pointer", who);
     PC_CHECK_ARG(A > 0 && B > 0 && B % 4 == 0 && KY > 0 && KX > 0 && KX <= WS_MAXK && U > 0, "%s: bad extents (A=%d B=%d KY=%d KX=%d U=%d)", who, A, B, KY, KX, U);
-    PC_CHECK_ARG(sgn == 1 || sgn == -1, "%s: sgn must be +-1", who);
     PC_CHECK_ARG(((uintptr_t)a % 16 == 0) && ((uintptr_t)c % 16 == 0), "%s: 16-byte alignment", who);
     return PC_OK;
 }
 
-extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* out, pc_stream s_) {
-    const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, sgn, "pc_wspec_fwd");
+extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, float* out, pc_stream s_) {
+    const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, "pc_wspec_fwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
-    if (KX <= 9) hipLaunchKernelGGL(wspec_fwd_kernel<9>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
-    else hipLaunchKernelGGL(wspec_fwd_kernel<WS_MAXK>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, KX, U, (float)sgn, out);
+    const dim3 grid((unsigned)cdiv(n, 256));
+#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_fwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, U, out); break;
+    switch (KX) { WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11)
+                  WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(15) WS_CASE(16) }
+#undef WS_CASE
     PC_CHECK_LAUNCH("wspec_fwd_kernel");
     return PC_OK;
 }
 
-extern "C" int pc_wspec_bwd(const float* dWg, const float* tw, int A, int B, int KY, int KX, int U, int sgn, float* kg, pc_stream s_) {
-    const int rc = wspec_check(dWg, tw, kg, A, B, KY, KX, U, sgn, "pc_wspec_bwd");
+extern "C" int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, float* kg, pc_stream s_) {
+    const int rc = wspec_check(dV, tw, kg, A, B, KY, KX, U, "pc_wspec_bwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
-    if (KX <= 9) hipLaunchKernelGGL(wspec_bwd_kernel<9>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
-    else hipLaunchKernelGGL(wspec_bwd_kernel<WS_MAXK>, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, (hipStream_t)s_, dWg, tw, A, B / 4, KY, KX, U, (float)sgn, kg);
+    const dim3 grid((unsigned)cdiv(n, 256));
+#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_bwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, dV, tw, A, B / 4, KY, U, kg); break;
+    switch (KX) { WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11)
+                  WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(15) WS_CASE(16) }
+#undef WS_CASE
     PC_CHECK_LAUNCH("wspec_bwd_kernel");
     return PC_OK;
 }

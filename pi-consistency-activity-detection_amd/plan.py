@@ -471,13 +471,13 @@ class Plan:
         spectral_pc = self.spectral_pc and xd.thw[0] == 1
         Cpc = npose + spec.IN_CAPS
         if spectral_pc:
-            # row-spectral form: DFT along x, one grouped 9x1 conv over the frequencies, inverse DFT (spectral.py)
+            # row-spectral form: DFT along x, one grouped 9x1 conv (3 real groups per frequency), inverse DFT (spectral.py)
             SL = spectral.Layout(N, xd.thw[1], xd.thw[2], xd.C, xd.ld, Cpc, caps_in.ld, KP, KP)
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
-            wpc["wg"] = self.alloc(SL.nu * SL.wg_u)             # [u][2Co][ky][2Ci]  forward GEMM weights
-            wpc["wgt"] = self.alloc(SL.nu * SL.wg_u)            # [u][2Ci][ky][2Co]  dgrad GEMM weights
-            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu, 1], p=[wpc["fwd"], sm["tw"], wpc["wg"]], lst="prep")
-            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu, -1], p=[wpc["tr"], sm["tw"], wpc["wgt"]], lst="prep")
+            wpc["wv"] = self.alloc(SL.G * SL.w_g)               # [g][Co][ky][Ci]  forward GEMM weight planes
+            wpc["wvt"] = self.alloc(SL.G * SL.w_g)              # [g][Ci][ky][Co]  dgrad GEMM weight planes
+            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu], p=[wpc["fwd"], sm["tw"], wpc["wv"]], lst="prep")
+            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu], p=[wpc["tr"], sm["tw"], wpc["wvt"]], lst="prep")
         else:
             wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
             self.emit(capi.OP_TRANSPOSE, i=[1, Cpc, KP * KP * xd.C, KP * KP * xd.C, Cpc, 0], l=[0, 0],
@@ -487,11 +487,11 @@ class Plan:
         self.emit(capi.OP_TRANSPOSE, i=[1, 1, spec.IN_CAPS, spec.IN_CAPS, 1, 0], l=[0, 0], p=[self.P("primary_caps.a.bias"), off(pc_bias, npose)], lst="prep")
         pc_dbias = self.alloc(npose + spec.IN_CAPS)
         if spectral_pc:
-            xhat = self.alloc(SL.nu * SL.xhat_u)
-            yhat = self.alloc(SL.nu * SL.yhat_u)
-            self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_xhat(), capi.AXIS_FIELDS), p=[xd.ref, sm["F"], None, xhat])
-            self.conv_op(SL.conv(), xhat, wpc["wg"], yhat)
-            self.emit(capi.OP_AXIS, i=D.flatten(SL.yhat_to_y(capi.ACT_SIGMOID, npose), capi.AXIS_FIELDS), p=[yhat, sm["G"], pc_bias, caps_in.ref])
+            xpl = self.alloc(SL.G * SL.x_g)
+            tpl = self.alloc(SL.G * SL.t_g)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_planes(), capi.AXIS_FIELDS), p=[xd.ref, sm["F"], None, xpl])
+            self.conv_op(SL.conv(), xpl, wpc["wv"], tpl)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.planes_to_y(capi.ACT_SIGMOID, npose), capi.AXIS_FIELDS), p=[tpl, sm["G"], pc_bias, caps_in.ref])
         else:
             self.conv_bias_act("", xd, Cpc, (1, KP, KP), (0, 0, 0), capi.ACT_SIGMOID, caps_in, act_c0=npose,
                                bias_ref=pc_bias, wkey="primary_caps.pose.weight")
@@ -526,11 +526,11 @@ class Plan:
             self.emit(capi.OP_ACT_BWD, i=[dcaps.ld, caps_in.ld, capi.ACT_NONE, npose, dcaps.ld, self.acc], l=[caps_in.rows],
                       p=[dcaps.ref, caps_in.ref, None, self.G("primary_caps.pose.bias"), ws2])
             if spectral_pc:
-                dyhat = self.alloc(SL.nu * SL.yhat_u)
-                dwg = self.alloc(SL.nu * SL.wg_u)
-                self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_dyhat(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dyhat])
-                self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dyhat, xhat, dwg])
-                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu, 1], p=[dwg, sm["tw"], wpc["kg"]])
+                dtpl = self.alloc(SL.G * SL.t_g)
+                dwv = self.alloc(SL.G * SL.w_g)
+                self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dtpl])
+                self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dtpl, xpl, dwv])
+                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu], p=[dwv, sm["tw"], wpc["kg"]])
             else:
                 self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
                           p=[dcaps.ref, xd.ref, wpc["kg"]])
@@ -539,11 +539,11 @@ class Plan:
             dx, acc = self.grad_for_write(xd)
             F_pc = 2 * caps_in.rows * caps_in.C * xd.C * KP * KP
             if spectral_pc:
-                dxhat = self.alloc(SL.nu * SL.xhat_u)
+                dxpl = self.alloc(SL.G * SL.x_g)
                 self.alg_dgrad(SL.flops())
                 for dd in SL.dgrad():
-                    self.conv_op(dd, dyhat, wpc["wgt"], dxhat, alg=0)
-                self.emit(capi.OP_AXIS, i=D.flatten(SL.dxhat_to_dx(dx.ld, acc), capi.AXIS_FIELDS), p=[dxhat, sm["Ft"], None, dx.ref])
+                    self.conv_op(dd, dtpl, wpc["wvt"], dxpl, alg=0)
+                self.emit(capi.OP_AXIS, i=D.flatten(SL.planes_to_dx(dx.ld, acc), capi.AXIS_FIELDS), p=[dxpl, sm["Ft"], None, dx.ref])
             elif xd.thw[0] == 1 and caps_in.thw[1] + KP - 1 == xd.thw[1]:
                 # exact 'full' correlation as GEMM + col2im: cols[o][(tap, ci)] = dcaps[o][:] . W[:, tap, ci] over the
                 # 20x20 real output positions only (the gather form multiplies 28x28 positions x 81 taps: 2x the FLOPs)

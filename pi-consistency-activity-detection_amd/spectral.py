@@ -1,12 +1,17 @@
 """Row-spectral form of PrimaryCaps (capsules_ucf101.py:43-49: Conv2d(832, 32*16 + 32, kernel 9, stride 1)).
 
 y[n,oy,ox,co] = sum_{ci,ky,kx} w[co,ci,ky,kx] x[n,oy+ky,ox+kx,ci] is a correlation along x, so with a length-P
-(P = input width) DFT along the rows   Y^[u] = X^[u] * conj(W^[u])   per frequency u, and what is left is a 9-tap
-conv along y with complex channels.  No wrap-around reaches the valid outputs (ox + kx <= P-1).  In real form
-(channels [re | im]) it is ONE grouped conv, group = frequency u = 0..P/2, 2*Ci -> 2*Co channels, 9x1 taps:
-15*9*2*2 = 540 real multiply-adds per (ci, co, output row) instead of 81*20 = 1620 -- a third of the direct form's
-FLOPs, equal to it in exact arithmetic.  The GEMMs are the ordinary conv / wgrad kernels; the DFTs, the weight
-spectrum and its adjoint are the three small kernels of csrc/spectral.hip.
+(P = input width) DFT along the rows   Y^[u] = X^[u] * conj(W^[u])   per frequency u = 0..P/2, and what is left is a
+9-tap conv along y with complex channels.  No wrap-around reaches the valid outputs (ox + kx <= P-1).  The complex
+product is taken with three real multiplications (X = Xr + i Xi, conj(W) = Wr - i Wi):
+
+    t0 = (Xr + Xi) Wr,   t1 = Xi (Wr - Wi),   t2 = Xr (Wr + Wi);     Re Y = t0 - t1,   Im Y = t0 - t2
+
+so the layer is ONE grouped real conv, 3 groups per frequency, Ci -> Co channels, 9x1 taps: 15*3*9 = 405 real
+multiply-adds per (ci, co, output row) instead of 81*20 = 1620 -- a quarter of the direct form's FLOPs, equal to it in
+exact arithmetic.  The operand sums (Xr + Xi) and the result differences are folded into the DFT / inverse-DFT
+matrices, so backward needs nothing but their transposes.  The GEMMs are the ordinary conv / wgrad kernels; the DFTs,
+the weight planes and their adjoint are the three small kernels of csrc/spectral.hip.
 
 This module builds the constant matrices and lays out the descriptors; `primary_caps_fwd_bwd` runs the whole
 thing on torch tensors for the kernel-level parity test (tests/test_kernels_gpu.py)."""
@@ -53,9 +58,19 @@ def idft_matrix(P, OW):
 
 
 def matrices(P, KX):
-    """-> dict of float32 arrays: F (x -> X^), Ft (dX^ -> dx), G (Y^ -> y), Gt (dy -> dY^), tw."""
+    """-> dict of float32 arrays for the three-multiplication form (planes j = 0,1,2 per frequency):
+    F  [3nu][P]  x -> (Xr + Xi, Xi, Xr);      Ft = F^T   (dX planes -> dx)
+    G  [OW][3nu] (t0, t1, t2) -> y = Gr (t0 - t1) + Gi (t0 - t2);      Gt = G^T   (dy -> dt planes)
+    tw [nu][KX][2]."""
     OW = P - KX + 1
-    F, G = dft_matrix(P), idft_matrix(P, OW)
+    nu = n_freq(P)
+    F2, G2 = dft_matrix(P), idft_matrix(P, OW)
+    Fr, Fi = F2[0::2], F2[1::2]
+    F = np.empty((3 * nu, P))
+    F[0::3], F[1::3], F[2::3] = Fr + Fi, Fi, Fr
+    Gr, Gi = G2[:, 0::2], G2[:, 1::2]
+    G = np.empty((OW, 3 * nu))
+    G[:, 0::3], G[:, 1::3], G[:, 2::3] = Gr + Gi, -Gr, -Gi
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
     return dict(F=f32(F), Ft=f32(F.T), G=f32(G), Gt=f32(G.T), tw=twiddles(P, KX))
 
@@ -67,56 +82,57 @@ def axis(R, I, O, C, in_sr, in_hi, in_lo, in_split, out_sr, out_hi, out_lo, out_
 
 class Layout:
     """Extents and descriptors of one spectral PrimaryCaps instance: x [N][H][W][Ci] (row stride ldx) ->
-    y [N][OH][OW][Co] (row stride ldy), kernel KY x KX, W = P."""
+    y [N][OH][OW][Co] (row stride ldy), kernel KY x KX, W = P.  Groups g = 3*u + j; operand planes X [g][n][iy][Ci],
+    result planes T [g][n][oy][Co], weight planes [g][Co][KY][Ci] (forward) / [g][Ci][KY][Co] (dgrad)."""
 
     def __init__(self, N, H, W, Ci, ldx, Co, ldy, KY, KX):
         self.N, self.H, self.W, self.Ci, self.ldx, self.Co, self.ldy, self.KY, self.KX = N, H, W, Ci, ldx, Co, ldy, KY, KX
         self.OH, self.OW = H - KY + 1, W - KX + 1
         self.nu = n_freq(W)
-        self.Ci2, self.Co2 = 2 * Ci, 2 * Co
-        self.xhat_u = N * H * self.Ci2            # floats per frequency of X^ [u][n][iy][2Ci]
-        self.yhat_u = N * self.OH * self.Co2      # floats per frequency of Y^ [u][n][oy][2Co]
-        self.wg_u = self.Co2 * KY * self.Ci2      # floats per frequency of the real-form weights (either layout)
+        self.G = 3 * self.nu
+        self.x_g = N * H * Ci                     # floats per operand plane
+        self.t_g = N * self.OH * Co               # floats per result plane
+        self.w_g = Co * KY * Ci                   # floats per weight plane (either layout)
 
-    # --- the four axis transforms
-    def x_to_xhat(self):
-        return axis(self.N * self.H, self.W, 2 * self.nu, self.Ci, self.W * self.ldx, self.ldx, 0, 1, self.Ci2, self.xhat_u, self.Ci, 2)
+    # --- the four axis transforms (index o or i = 3*u + j: offset = g * plane)
+    def x_to_planes(self):
+        return axis(self.N * self.H, self.W, self.G, self.Ci, self.W * self.ldx, self.ldx, 0, 1, self.Ci, self.x_g, 0, 1)
 
-    def yhat_to_y(self, act, act_c0):
-        return axis(self.N * self.OH, 2 * self.nu, self.OW, self.Co, self.Co2, self.yhat_u, self.Co, 2, self.OW * self.ldy, self.ldy, 0, 1,
+    def planes_to_y(self, act, act_c0):
+        return axis(self.N * self.OH, self.G, self.OW, self.Co, self.Co, self.t_g, 0, 1, self.OW * self.ldy, self.ldy, 0, 1,
                     act=act, act_c0=act_c0)
 
-    def dy_to_dyhat(self, lddy):
-        return axis(self.N * self.OH, self.OW, 2 * self.nu, self.Co, self.OW * lddy, lddy, 0, 1, self.Co2, self.yhat_u, self.Co, 2)
+    def dy_to_planes(self, lddy):
+        return axis(self.N * self.OH, self.OW, self.G, self.Co, self.OW * lddy, lddy, 0, 1, self.Co, self.t_g, 0, 1)
 
-    def dxhat_to_dx(self, lddx, accum):
-        return axis(self.N * self.H, 2 * self.nu, self.W, self.Ci, self.Ci2, self.xhat_u, self.Ci, 2, self.W * lddx, lddx, 0, 1, accum=int(accum))
+    def planes_to_dx(self, lddx, accum):
+        return axis(self.N * self.H, self.G, self.W, self.Ci, self.Ci, self.x_g, 0, 1, self.W * lddx, lddx, 0, 1, accum=int(accum))
 
     # --- the GEMMs
     def conv(self):
-        d = D.conv_fwd(self.nu * self.N, (1, self.H, 1), self.Ci2, self.Ci2, self.Co2, self.Co2, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
-                       (1, self.OH, 1), groups=self.nu)
-        d["wgstride"] = self.wg_u
+        d = D.conv_fwd(self.G * self.N, (1, self.H, 1), self.Ci, self.Ci, self.Co, self.Co, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+                       (1, self.OH, 1), groups=self.G)
+        d["wgstride"] = self.w_g
         return d
 
     def dgrad(self):
-        out = D.transposed_classes(self.nu * self.N, (1, self.OH, 1), self.Co2, self.Co2, (1, self.H, 1), self.Ci2, self.Ci2,
-                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.nu, ldw=self.Co2)
+        out = D.transposed_classes(self.G * self.N, (1, self.OH, 1), self.Co, self.Co, (1, self.H, 1), self.Ci, self.Ci,
+                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G, ldw=self.Co)
         for d in out:
-            d["wgstride"] = self.wg_u
+            d["wgstride"] = self.w_g
         return out
 
     def wgrad(self):
-        """dWg[u] [2Co][KY][2Ci] = dY^[u]^T . X^[u] for every frequency in ONE launch (blockIdx.z = u): K is only the
-        N*OH rows of one frequency (10 chunks at bs=8), so one slice each, plain stores, no zero-fill."""
-        d = D.wgrad(self.N, (1, self.OH, 1), self.Co2, self.Co2, (1, self.H, 1), self.Ci2, self.Ci2, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+        """dV[g] [Co][KY][Ci] = dT[g]^T . X[g] for every group in ONE launch (blockIdx.z = g): K is only the N*OH rows
+        of one plane (10 chunks at bs=8), so one slice each, plain stores, no zero-fill."""
+        d = D.wgrad(self.N, (1, self.OH, 1), self.Co, self.Co, (1, self.H, 1), self.Ci, self.Ci, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
                     splitk=-1)
-        d.update(nbatch=self.nu, dbstride=self.yhat_u, sbstride=self.xhat_u, gbstride=self.wg_u)
+        d.update(nbatch=self.G, dbstride=self.t_g, sbstride=self.x_g, gbstride=self.w_g)
         return d
 
     def flops(self):
-        """Issued-algorithmic FLOPs of the forward grouped conv (= dgrad = wgrad): 2 * rows * 2Co * 9 * 2Ci per frequency."""
-        return 2 * self.nu * self.N * self.OH * self.Co2 * self.KY * self.Ci2
+        """Issued-algorithmic FLOPs of the forward grouped conv (= dgrad = wgrad): 2 * rows * Co * 9 * Ci per group."""
+        return 2 * self.G * self.N * self.OH * self.Co * self.KY * self.Ci
 
 
 def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):
@@ -132,27 +148,27 @@ def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):
     wf = w.reshape(Co, Ci, KY * KX).permute(0, 2, 1).contiguous()          # [Co][taps][Ci]
     wt = w.reshape(Co, Ci, KY * KX).permute(1, 2, 0).contiguous()          # [Ci][taps][Co]
     f32 = dict(device=dev, dtype=torch.float32)
-    xhat = torch.empty(L.nu * L.xhat_u, **f32)
-    ops.axis_linear(L.x_to_xhat(), x, m["F"], xhat)
-    wg = torch.empty(L.nu * L.wg_u, **f32)
-    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, 1, wg)
-    yhat = torch.empty(L.nu * L.yhat_u, **f32)
-    ops.conv_fwd(L.conv(), xhat, wg, yhat)
+    xp = torch.empty(L.G * L.x_g, **f32)
+    ops.axis_linear(L.x_to_planes(), x, m["F"], xp)
+    wv = torch.empty(L.G * L.w_g, **f32)
+    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, wv)
+    tp = torch.empty(L.G * L.t_g, **f32)
+    ops.conv_fwd(L.conv(), xp, wv, tp)
     y = torch.empty(N, L.OH, L.OW, Co, **f32)
-    ops.axis_linear(L.yhat_to_y(capi.ACT_SIGMOID if act_c0 is not None else capi.ACT_NONE, act_c0 or 0), yhat, m["G"], y, bias=bias)
+    ops.axis_linear(L.planes_to_y(capi.ACT_SIGMOID if act_c0 is not None else capi.ACT_NONE, act_c0 or 0), tp, m["G"], y, bias=bias)
     # backward
-    dyhat = torch.empty(L.nu * L.yhat_u, **f32)
-    ops.axis_linear(L.dy_to_dyhat(Co), dy, m["Gt"], dyhat)
-    dwg = torch.empty(L.nu * L.wg_u, **f32)
-    ops.conv_wgrad(L.wgrad(), dyhat, xhat, dwg)
+    dtp = torch.empty(L.G * L.t_g, **f32)
+    ops.axis_linear(L.dy_to_planes(Co), dy, m["Gt"], dtp)
+    dv = torch.empty(L.G * L.w_g, **f32)
+    ops.conv_wgrad(L.wgrad(), dtp, xp, dv)
     kg = torch.empty(Co, KY * KX, Ci, **f32)
-    ops.wspec_bwd(dwg, m["tw"], Co, Ci, KY, KX, L.nu, 1, kg)
+    ops.wspec_bwd(dv, m["tw"], Co, Ci, KY, KX, L.nu, kg)
     dw = kg.permute(0, 2, 1).reshape(Co, Ci, KY, KX)
-    wgt = torch.empty(L.nu * L.wg_u, **f32)
-    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, -1, wgt)
-    dxhat = torch.empty(L.nu * L.xhat_u, **f32)
+    wvt = torch.empty(L.G * L.w_g, **f32)
+    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, wvt)
+    dxp = torch.empty(L.G * L.x_g, **f32)
     for dd in L.dgrad():
-        ops.conv_fwd(dd, dyhat, wgt, dxhat)
+        ops.conv_fwd(dd, dtp, wvt, dxp)
     dx = torch.empty(N, H, W, Ci, **f32)
-    ops.axis_linear(L.dxhat_to_dx(Ci, False), dxhat, m["Ft"], dx)
+    ops.axis_linear(L.planes_to_dx(Ci, False), dxp, m["Ft"], dx)
     return y, dx, dw

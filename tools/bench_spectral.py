@@ -15,29 +15,27 @@ m = {k: torch.from_numpy(v).to(dev) for k, v in spectral.matrices(W, K).items()}
 f32 = dict(device=dev, dtype=torch.float32)
 x = torch.randn(N, H, W, Ci, **f32); wf = torch.randn(Co, K * K, Ci, **f32) * 0.01; wt = torch.randn(Ci, K * K, Co, **f32) * 0.01
 bias = torch.zeros(Co, **f32); dy = torch.randn(N, L.OH, L.OW, Co, **f32)
-xhat = torch.empty(L.nu * L.xhat_u, **f32); wg = torch.empty(L.nu * L.wg_u, **f32); yhat = torch.empty(L.nu * L.yhat_u, **f32)
-y = torch.empty(N, L.OH, L.OW, Co, **f32); dyhat = torch.empty_like(yhat); dwg = torch.empty_like(wg); kg = torch.empty(Co, K * K, Ci, **f32)
-wgt = torch.empty_like(wg); dxhat = torch.empty_like(xhat); dx = torch.empty_like(x)
-def wgrad_all():
-    ops.conv_wgrad(L.wgrad(), dyhat, xhat, dwg)
+xp = torch.empty(L.G * L.x_g, **f32); wv = torch.empty(L.G * L.w_g, **f32); tp = torch.empty(L.G * L.t_g, **f32)
+y = torch.empty(N, L.OH, L.OW, Co, **f32); dtp = torch.empty_like(tp); dv = torch.empty_like(wv); kg = torch.empty(Co, K * K, Ci, **f32)
+wvt = torch.empty_like(wv); dxp = torch.empty_like(xp); dx = torch.empty_like(x)
 
 
 def dgrad_all():
     for dd in L.dgrad():
-        ops.conv_fwd(dd, dyhat, wgt, dxhat)
+        ops.conv_fwd(dd, dtp, wvt, dxp)
 
 
 stages = [
-    ("x -> X^ (row DFT)", lambda: ops.axis_linear(L.x_to_xhat(), x, m["F"], xhat)),
-    ("weight spectrum (fwd layout)", lambda: ops.wspec_fwd(wf, m["tw"], Co, Ci, K, K, L.nu, 1, wg)),
-    ("grouped conv 9x1, 15 freqs", lambda: ops.conv_fwd(L.conv(), xhat, wg, yhat)),
-    ("Y^ -> y (+bias, sigmoid)", lambda: ops.axis_linear(L.yhat_to_y(capi.ACT_SIGMOID, 512), yhat, m["G"], y, bias=bias)),
-    ("dy -> dY^", lambda: ops.axis_linear(L.dy_to_dyhat(Co), dy, m["Gt"], dyhat)),
-    ("wgrad, 15 freqs in one launch", wgrad_all),
-    ("weight-spectrum adjoint", lambda: ops.wspec_bwd(dwg, m["tw"], Co, Ci, K, K, L.nu, 1, kg)),
-    ("weight spectrum (dgrad layout)", lambda: ops.wspec_fwd(wt, m["tw"], Ci, Co, K, K, L.nu, -1, wgt)),
+    ("x -> operand planes (row DFT)", lambda: ops.axis_linear(L.x_to_planes(), x, m["F"], xp)),
+    ("weight planes (fwd layout)", lambda: ops.wspec_fwd(wf, m["tw"], Co, Ci, K, K, L.nu, wv)),
+    ("grouped conv 9x1, 45 groups", lambda: ops.conv_fwd(L.conv(), xp, wv, tp)),
+    ("result planes -> y (+bias, sigmoid)", lambda: ops.axis_linear(L.planes_to_y(capi.ACT_SIGMOID, 512), tp, m["G"], y, bias=bias)),
+    ("dy -> result-plane grads", lambda: ops.axis_linear(L.dy_to_planes(Co), dy, m["Gt"], dtp)),
+    ("wgrad, 45 groups in one launch", lambda: ops.conv_wgrad(L.wgrad(), dtp, xp, dv)),
+    ("weight-plane adjoint", lambda: ops.wspec_bwd(dv, m["tw"], Co, Ci, K, K, L.nu, kg)),
+    ("weight planes (dgrad layout)", lambda: ops.wspec_fwd(wt, m["tw"], Ci, Co, K, K, L.nu, wvt)),
     ("grouped dgrad", dgrad_all),
-    ("dX^ -> dx", lambda: ops.axis_linear(L.dxhat_to_dx(Ci, False), dxhat, m["Ft"], dx)),
+    ("operand-plane grads -> dx", lambda: ops.axis_linear(L.planes_to_dx(Ci, False), dxp, m["Ft"], dx)),
 ]
 tot = 0.0
 for name, fn in stages:
@@ -52,6 +50,6 @@ for name, fn in stages:
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / R
     tot += ms
-    print("%-34s %7.3f ms" % (name, ms), flush=True)
+    print("%-36s %7.3f ms" % (name, ms), flush=True)
 print("%-34s %7.3f ms   (direct form: fwd 4.66 + dgrad 4.36+0.40 + wgrad 4.98 = 14.4 ms)" % ("total", tot))
 print("GEMM FLOPs each: %.1f G (direct 469 G)" % (L.flops() / 1e9))
