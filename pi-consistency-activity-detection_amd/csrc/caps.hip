@@ -35,7 +35,9 @@ __device__ __forceinline__ float sum_cg(float v) {  // over cg (lane bits 4,5)
     return v;
 }
 
-// forward state of one position (floats)
+// forward state of one position (floats).  The backward kernel replays the forward and needs every iteration's
+// intermediates (FwdState); the forward kernel only needs the current one (FwdLite: 8.7 KB instead of 21.6 KB per
+// wave, so ten waves instead of four share one copy of W^T in LDS).
 struct FwdState {
     float P[NB][16];
     float a[NB];
@@ -47,6 +49,26 @@ struct FwdState {
     float s2[3][MAXC][16];
     float aout[3][MAXC];
     float D[4];                // stdv + eps per iteration
+    static __device__ __forceinline__ int ti(int t) { return t; }
+    __device__ __forceinline__ float& r_prev(int t, int i, int c) { return R[t - 1][i][c]; }
+    __device__ __forceinline__ float& r_next(int t, int i, int c) { return R[t][i][c]; }
+    __device__ __forceinline__ float& rnorm(int i, int c) { return rn[i][c]; }
+};
+
+struct FwdLite {
+    float P[NB][16];
+    float a[NB];
+    float R1[NB][MAXC];        // assignment of the current iteration, normalised in place
+    float invS[1][NB];
+    float rs[1][MAXC];
+    float mu[1][MAXC][16];
+    float s2[1][MAXC][16];
+    float aout[1][MAXC];
+    float D[4];
+    static __device__ __forceinline__ int ti(int) { return 0; }
+    __device__ __forceinline__ float& r_prev(int, int i, int c) { return R1[i][c]; }
+    __device__ __forceinline__ float& r_next(int, int i, int c) { return R1[i][c]; }
+    __device__ __forceinline__ float& rnorm(int i, int c) { return R1[i][c]; }
 };
 
 struct BwdState {
@@ -84,7 +106,8 @@ template <int NW>
 __device__ __forceinline__ void SYNC() {
     if (NW == 1) WSYNC(); else __syncthreads();
 }
-__device__ __forceinline__ float Rt(const FwdState* st, int t, int i, int c, int C) { return t == 0 ? 1.0f / C : st->R[t - 1][i][c]; }
+template <class ST>
+__device__ __forceinline__ float Rt(ST* st, int t, int i, int c, int C) { return t == 0 ? 1.0f / C : st->r_prev(t, i, c); }
 
 template <int NW>
 __device__ __forceinline__ void xwave_sum(float (&v)[CJ], float* red, int wv, int lane) {
@@ -104,14 +127,15 @@ __device__ __forceinline__ void xwave_sum(float (&v)[CJ], float* red, int wv, in
 }
 
 // Forward EM for the position held in st->P / st->a.  Leaves every iteration's state in *st.
-template <int NW>
-__device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, const float* beta_a, int C, int tid, float* red) {
+template <int NW, class ST>
+__device__ void em_forward(ST* st, const float* WT, const float* beta_u, const float* beta_a, int C, int tid, float* red) {
     const int lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
     const int i0 = wv * (NB / NW), i1 = i0 + NB / NW;
     constexpr int RP = 64 * NW / NB;           // lanes per input capsule in the row-parallel sections (2 or 8)
     constexpr int CPT = NW == 1 ? 2 : 8;       // lanes per output capsule in the column-parallel sections
     for (int t = 0; t < 3; ++t) {
+        const int tt = ST::ti(t);
         // ---- M-step (capsules_ucf101.py:127-152)
         {   // S_i = sum_c r[i][c]*a_i : RP lanes per input capsule
             const int i = tid / RP, part = tid % RP;
@@ -119,31 +143,31 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             float S = 0.f;
             for (int c = part; c < C; c += RP) S += Rt(st, t, i, c, C) * ai;
             S = seg_sum<RP>(S);
-            if (part == 0) st->invS[t][i] = 1.0f / (S + EPS);
+            if (part == 0) st->invS[tt][i] = 1.0f / (S + EPS);
         }
         SYNC<NW>();
         for (int e = tid; e < NB * C; e += 64 * NW) {
             const int i = e / C, c = e - i * C;
-            st->rn[i][c] = Rt(st, t, i, c, C) * st->a[i] * st->invS[t][i];
+            st->rnorm(i, c) = Rt(st, t, i, c, C) * st->a[i] * st->invS[tt][i];
         }
         SYNC<NW>();
         if (tid < C * CPT) {   // r_sum[c] = sum_i rn[i][c] : CPT lanes per output capsule
             const int c = tid / CPT, part = tid % CPT;
             float s = 0.f;
-            for (int i = part; i < NB; i += CPT) s += st->rn[i][c];
+            for (int i = part; i < NB; i += CPT) s += st->rnorm(i, c);
             s = seg_sum<CPT>(s);
-            if (part == 0) st->rs[t][c] = s;
+            if (part == 0) st->rs[tt][c] = s;
         }
         SYNC<NW>();
         float m[CJ], sg[CJ], irs[CJ];
 #pragma unroll
-        for (int j = 0; j < CJ; ++j) { m[j] = 0.f; sg[j] = 0.f; const int c = cg + 4 * j; irs[j] = c < C ? 1.0f / (st->rs[t][c] + EPS) : 0.f; }
+        for (int j = 0; j < CJ; ++j) { m[j] = 0.f; sg[j] = 0.f; const int c = cg + 4 * j; irs[j] = c < C ? 1.0f / (st->rs[tt][c] + EPS) : 0.f; }
         for (int i = i0; i < i1; ++i) {
             const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const int c = cg + 4 * j;
-                if (c < C) m[j] += st->rn[i][c] * irs[j] * vote(WT, prow, i, c, q, C);
+                if (c < C) m[j] += st->rnorm(i, c) * irs[j] * vote(WT, prow, i, c, q, C);
             }
         }
         xwave_sum<NW>(m, red, wv, lane);
@@ -152,7 +176,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const int c = cg + 4 * j;
-                if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rn[i][c] * irs[j] * d * d; }
+                if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rnorm(i, c) * irs[j] * d * d; }
             }
         }
         xwave_sum<NW>(sg, red, wv, lane);
@@ -163,8 +187,8 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             cost[j] = 0.f;
             if (c < C) {
                 sg[j] += EPS;
-                if (wv == 0) { st->mu[t][c][h] = m[j]; st->s2[t][c][h] = sg[j]; }
-                cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[t][c]);
+                if (wv == 0) { st->mu[tt][c][h] = m[j]; st->s2[tt][c][h] = sg[j]; }
+                cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[tt][c]);
                 csum += (double)cost[j];
             }
         }
@@ -187,7 +211,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
             ao[j] = 0.f;
             if (c < C) {
                 ao[j] = 1.0f / (1.0f + expf(-LAMBDA * (beta_a[c] - (mean - cost[j]) / D)));
-                if (h == 0 && wv == 0) st->aout[t][c] = ao[j];
+                if (h == 0 && wv == 0) st->aout[tt][c] = ao[j];
             }
         }
         if (tid == 0) st->D[t] = D;
@@ -209,7 +233,7 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
                 if (c < C) {
                     const float d = vote(WT, prow, i, c, q, C) - m[j];
                     const float lp = sum16(-d * d * is2[j] - hl[j]);
-                    if (h == 0) st->R[t][i][c] = lp + la[j];
+                    if (h == 0) st->r_next(t, i, c) = lp + la[j];
                 }
             }
         }
@@ -217,13 +241,13 @@ __device__ void em_forward(FwdState* st, const float* WT, const float* beta_u, c
         {   // softmax over c, RP lanes per input capsule
             const int i = tid / RP, part = tid % RP;
             float mx = -INFINITY;
-            for (int c = part; c < C; c += RP) mx = fmaxf(mx, st->R[t][i][c]);
+            for (int c = part; c < C; c += RP) mx = fmaxf(mx, st->r_next(t, i, c));
             mx = seg_max<RP>(mx);
             float s = 0.f;
-            for (int c = part; c < C; c += RP) { const float e = expf(st->R[t][i][c] - mx); st->R[t][i][c] = e; s += e; }
+            for (int c = part; c < C; c += RP) { const float e = expf(st->r_next(t, i, c) - mx); st->r_next(t, i, c) = e; s += e; }
             s = seg_sum<RP>(s);
             const float inv = 1.0f / s;
-            for (int c = part; c < C; c += RP) st->R[t][i][c] *= inv;
+            for (int c = part; c < C; c += RP) st->r_next(t, i, c) *= inv;
         }
         SYNC<NW>();
     }
@@ -237,34 +261,37 @@ __device__ __forceinline__ void load_WT(float* WT, const float* W, int C, int ti
     }
 }
 
-__device__ __forceinline__ void load_pos(FwdState* st, const float* x, int64_t pos, int tid, int nthr) {
+template <class ST>
+__device__ __forceinline__ void load_pos(ST* st, const float* x, int64_t pos, int tid, int nthr) {
     const float* xp = x + pos * (NB * 17);
     for (int e = tid; e < NB * 16 / 4; e += nthr) ((f32x4*)&st->P[0][0])[e] = ((const f32x4*)xp)[e];
     if (tid < NB) st->a[tid] = xp[NB * 16 + tid];
 }
 
-constexpr int FWD_WAVES = 4;
+constexpr int FWD_WAVES = 10;
 
-// Forward: one wave per position, FWD_WAVES independent waves per block sharing W^T in LDS.  (A cooperative
-// 4-waves-per-position variant with 2 blocks/CU was measured slower: 1.78 vs 1.27 ms per step - more barriers.)
+// Forward: one wave per position, FWD_WAVES independent waves per block sharing W^T in LDS.  The kernel is a chain
+// of dependent reductions, so it lives on waves per SIMD: 4 waves/block (full FwdState) ran 1.38 ms, 8 with the
+// compact state 0.74 ms, 10 0.57 ms, 12 0.59 ms (25 positions per CU: 12 leaves a nearly empty third round).
+// (A cooperative 4-waves-per-position variant was measured slower: more barriers.)
 __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ beta_u, const float* __restrict__ beta_a,
                                                                  int npos, int C, float* __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* WT = smem;
-    FwdState* sts = (FwdState*)(smem + NB * MAXC * 16);
+    FwdLite* sts = (FwdLite*)(smem + NB * MAXC * 16);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     load_WT(WT, W, C, threadIdx.x, blockDim.x);
     __syncthreads();
-    FwdState* st = sts + wave;
+    FwdLite* st = sts + wave;
     for (int64_t pos = (int64_t)blockIdx.x * FWD_WAVES + wave; pos < npos; pos += (int64_t)gridDim.x * FWD_WAVES) {
         WSYNC();
         load_pos(st, x, pos, lane, 64);
         WSYNC();
         em_forward<1>(st, WT, beta_u, beta_a, C, lane, nullptr);
         float* o = out + pos * (C * 17);
-        for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[2][0][0])[e];
-        if (lane < C) o[C * 16 + lane] = st->aout[2][lane];
+        for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[0][0][0])[e];
+        if (lane < C) o[C * 16 + lane] = st->aout[0][lane];
     }
 }
 
@@ -659,11 +686,11 @@ extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* be
     PC_CHECK_ARG(x && W && beta_u && beta_a && out, "pc_em_routing_fwd: null");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_fwd: B must be 32 and C <= 24 (B=%d C=%d)", B, C);
     PC_CHECK_ARG((uintptr_t)x % 16 == 0, "pc_em_routing_fwd: x alignment");
-    const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdState) * FWD_WAVES;
+    const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdLite) * FWD_WAVES;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)em_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     int grid = cdiv(npos, FWD_WAVES);
-    if (grid > 512) grid = 512;
+    if (grid > 256) grid = 256;            // one block (10 waves, 136 KB of LDS) per CU, positions strided over the grid
     hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out);
     PC_CHECK_LAUNCH("em_fwd");
     return PC_OK;
