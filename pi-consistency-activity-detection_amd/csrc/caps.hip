@@ -295,31 +295,46 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __r
     }
 }
 
-// Backward: BWD_WAVES waves per block cooperate on one position at a time; forward recomputed into LDS, then reversed.
-constexpr int BWD_WAVES = 4;   // 8 waves spill (256 VGPR cap at 2 waves/SIMD)
+// Backward: BWD_WAVES waves cooperate on one position at a time (forward recomputed into LDS, then reversed); a block
+// holds BWD_GROUPS such teams, each with its own state, sharing one copy of W^T.  The kernel is latency-bound chains of
+// reductions, so the second team is what gives every SIMD two waves; dW goes to the team's global partial with
+// no-return float atomics (each element has one owner thread, so there is no contention) instead of 49 KB of LDS.
+constexpr int BWD_WAVES = 4;   // 8 cooperating waves spill (256 VGPR cap at 2 waves/SIMD)
 constexpr int BW = BWD_WAVES;
+constexpr int BWD_GROUPS = 2;
+constexpr int EM_SMALL = MAXC * 16 + 32;          // dbeta_u [C][16] + dbeta_a [C] accumulators
 
-__global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
+__global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ beta_u, const float* __restrict__ beta_a,
                                                                  const float* __restrict__ dout, int npos, int C, float* __restrict__ dx,
                                                                  float* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* WT = smem;                              // [NB][C][4(q)][4(k)]
-    float* dWacc = smem + NB * MAXC * 16;          // [i][c][k][q]
-    float* dbu = dWacc + NB * MAXC * 16;           // [C][16]
+    constexpr int NT = 64 * BW;
+    constexpr int GRP_FLOATS = EM_SMALL + (sizeof(FwdState) + sizeof(BwdState)) / 4 + BW * MAXC * 16;
+    const int grp = threadIdx.x / NT, tid = threadIdx.x % NT;
+    float* WT = smem;                              // [NB][C][4(q)][4(k)]  shared by the teams
+    float* gbase = smem + NB * MAXC * 16 + grp * GRP_FLOATS;
+    float* dbu = gbase;                            // [C][16]
     float* dba = dbu + MAXC * 16;                  // [C]
     FwdState* st = (FwdState*)(dba + 32);
     BwdState* bs = (BwdState*)(st + 1);
     float* red = (float*)(bs + 1);                 // [BW][MAXC*16]
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
     const int i0 = wv * (NB / BW), i1 = i0 + NB / BW;
-    constexpr int NT = 64 * BW;
     constexpr int RP = NT / NB, CPT = 8;
-    load_WT(WT, W, C, tid, NT);
-    for (int e = tid; e < NB * MAXC * 16 + MAXC * 16 + 32; e += NT) dWacc[e] = 0.f;
+    const int team = blockIdx.x * BWD_GROUPS + grp, nteams = gridDim.x * BWD_GROUPS;
+    float* pp = part + (size_t)team * (NB * MAXC * 16 + EM_SMALL);
+    load_WT(WT, W, C, threadIdx.x, blockDim.x);
+    for (int e = tid; e < EM_SMALL; e += NT) dbu[e] = 0.f;
+    for (int e = tid; e < NB * MAXC * 16; e += NT) pp[e] = 0.f;
     __syncthreads();
-    for (int64_t pos = blockIdx.x; pos < npos; pos += gridDim.x) {
+    // both teams run the same number of rounds (the barriers are block-wide); a team without a position left
+    // replays the last one and keeps its results to itself
+    const int rounds = (npos + nteams - 1) / nteams;
+    for (int rd = 0; rd < rounds; ++rd) {
+        const bool live = (int64_t)team + (int64_t)rd * nteams < npos;
+        const int64_t pos = live ? (int64_t)team + (int64_t)rd * nteams : npos - 1;
         __syncthreads();
         load_pos(st, x, pos, tid, NT);
         __syncthreads();
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
                     // d sigma^2 / d mu through sum_i co (v-mu)^2 :  -2 ds * mu * eps/(rs+eps)
                     dmu_add[j] = bs->dmu[t][c][h] - 2.f * ds * st->mu[t][c][h] * (EPS / (rsv + EPS));
                     drs_new[j] = dcost * G;
-                    if (wv == 0) { dbu[c * 16 + h] += dcost * rsv; if (h == 0) dba[c] += LAMBDA * du[j]; }
+                    if (wv == 0 && live) { dbu[c * 16 + h] += dcost * rsv; if (h == 0) dba[c] += LAMBDA * du[j]; }
                 }
             }
             __syncthreads();                  // all reads of ds2/dmu/da_out done before wave 0 overwrites them
@@ -515,7 +530,7 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
 #pragma unroll
                     for (int k = 0; k < 4; ++k) { tk[k] += __shfl_xor(tk[k], 4, 64); tk[k] += __shfl_xor(tk[k], 8, 64); }
                     const float mine = p == 0 ? tk[0] : (p == 1 ? tk[1] : (p == 2 ? tk[2] : tk[3]));
-                    dWacc[((i * C + c) * 4 + p) * 4 + q] += mine;
+                    if (live) atomicAdd(pp + ((i * C + c) * 4 + p) * 4 + q, mine);
                 }
                 // dP[p][k]: reduce over q (lane bits 0,1) and cg (bits 4,5)
 #pragma unroll
@@ -524,14 +539,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES) void em_bwd_kernel(const float* __r
                     s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
                     dP[k] = s;
                 }
-                if (q == 0 && cg == 0) *(f32x4*)(dxp + i * 16 + p * 4) = dP;
+                if (q == 0 && cg == 0 && live) *(f32x4*)(dxp + i * 16 + p * 4) = dP;
             }
-            if (tid < NB) dxp[NB * 16 + tid] = bs->da_in[tid];
+            if (tid < NB && live) dxp[NB * 16 + tid] = bs->da_in[tid];
         }
     }
     __syncthreads();
-    float* pp = part + (size_t)blockIdx.x * (NB * MAXC * 16 + MAXC * 16 + 32);
-    for (int e = tid; e < NB * MAXC * 16 + MAXC * 16 + 32; e += NT) pp[e] = dWacc[e];
+    for (int e = tid; e < EM_SMALL; e += NT) pp[NB * MAXC * 16 + e] = dbu[e];
 }
 
 // part [nblk][NB*MAXC*16 + MAXC*16 + 32] -> dW [NB][C][4][4], dbeta_u [C][16], dbeta_a [C]  (+=)
@@ -671,14 +685,14 @@ __global__ __launch_bounds__(256) void tapsum_bwd_kernel(const float* __restrict
     }
 }
 
-inline int em_bwd_blocks(int npos) { return npos < 256 ? npos : 256; }
+inline int em_bwd_blocks(int npos) { const int b = (npos + BWD_GROUPS - 1) / BWD_GROUPS; return b < 256 ? b : 256; }
 constexpr size_t EM_PART = NB * MAXC * 16 + MAXC * 16 + 32;
 
 }  // namespace
 
 extern "C" int64_t pc_em_ws_floats(int npos, int B, int C) {
     (void)B; (void)C;
-    return (int64_t)em_bwd_blocks(npos) * (int64_t)EM_PART + 64;
+    return (int64_t)em_bwd_blocks(npos) * BWD_GROUPS * (int64_t)EM_PART + 64;
 }
 
 extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* beta_u, const float* beta_a, int npos, int B, int C,
@@ -701,13 +715,13 @@ extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* be
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(x && W && beta_u && beta_a && dout && dx && dW && dbeta_u && dbeta_a && ws, "pc_em_routing_bwd: null");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_bwd: B must be 32 and C <= 24");
-    const size_t lds = (2 * (size_t)NB * MAXC * 16 + MAXC * 16 + 32) * 4 + sizeof(FwdState) + sizeof(BwdState) + BWD_WAVES * MAXC * 16 * 4;
+    const size_t lds = (size_t)NB * MAXC * 16 * 4 + BWD_GROUPS * ((size_t)EM_SMALL * 4 + sizeof(FwdState) + sizeof(BwdState) + BWD_WAVES * MAXC * 16 * 4);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)em_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     const int nblk = em_bwd_blocks(npos);
-    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64 * BWD_WAVES), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
+    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64 * BWD_WAVES * BWD_GROUPS), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
     PC_CHECK_LAUNCH("em_bwd");
-    hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, 256)), dim3(256), 0, s, ws, nblk, C, dW, dbeta_u, dbeta_a);
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, 256)), dim3(256), 0, s, ws, nblk * BWD_GROUPS, C, dW, dbeta_u, dbeta_a);
     PC_CHECK_LAUNCH("em_reduce");
     return PC_OK;
 }
