@@ -151,6 +151,13 @@ int pc_ndhwc_to_ncdhw(const float* src, int ld, int N, int C, int64_t thw, float
 int pc_transpose_batched(const float* src, int batch, int R, int Cc, int64_t src_batch_stride,
                          int src_ld, float* dst, int64_t dst_batch_stride, int dst_ld, int accum,
                          pc_stream s);
+/* the same for many independent jobs in one launch (the per-step weight re-layouts); `jobs` is HOST memory */
+typedef struct pc_transpose_job {
+    uint64_t src, dst;              /* device pointers */
+    int64_t  src_batch_stride, dst_batch_stride;
+    int32_t  batch, R, C, src_ld, dst_ld, accum;
+} pc_transpose_job;
+int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_stream s);
 /* dx[n,h,w,c] (+)= sum over valid taps of cols[n, h-b, w-c'][(b*KW+c')*C + c]: gather half of an exact stride-1 'full'
  * correlation (PrimaryCaps dgrad, capsules_ucf101.py:44-45 backward) computed as GEMM + col2im, so only the
  * Ho*Wo real output positions are multiplied instead of the (Ho+KH-1)*(Wo+KW-1) gathered ones. */
@@ -285,6 +292,7 @@ enum {
     PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
     PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U; p = in, tw, out */
     PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U; p = dV, tw, kg */
+    PC_OP_TRANSPOSE_MULTI,          /* p[0] = HOST pointer to pc_transpose_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP__COUNT

@@ -112,6 +112,8 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_wspec_fwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], P(float*, 2), s);
         case PC_OP_WSPEC_BWD:
             return pc_wspec_bwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], P(float*, 2), s);
+        case PC_OP_TRANSPOSE_MULTI:
+            return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

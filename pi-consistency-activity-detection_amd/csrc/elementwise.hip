@@ -354,6 +354,35 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// Many independent transposes in one launch (the ~160 weight re-layouts at the start of every step): the jobs travel
+// by value in the kernel arguments, a block finds its job from the tile prefix sums.
+constexpr int TM_JOBS = 40;
+struct TJobK { const float* src; float* dst; long long sbs, dbs; int R, Cc, sld, dld, accum, tiles_c, tiles_rc, pad_; };
+struct TPack { TJobK j[TM_JOBS]; int first[TM_JOBS + 1]; int n; };
+
+__global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
+    __shared__ float tile[32][33];
+    int k = 0;
+    while (k + 1 < pk.n && (int)blockIdx.x >= pk.first[k + 1]) ++k;
+    const TJobK& J = pk.j[k];
+    const int t = blockIdx.x - pk.first[k];
+    const int b = t / J.tiles_rc, rem = t - b * J.tiles_rc;
+    const int r0 = (rem / J.tiles_c) * 32, c0 = (rem % J.tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < J.R && c < J.Cc) ? J.src[(size_t)b * J.sbs + (size_t)r * J.sld + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < J.Cc && r < J.R) {
+            float* o = J.dst + (size_t)b * J.dbs + (size_t)c * J.dld + r;
+            *o = (J.accum ? *o : 0.f) + tile[tx][i];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* p, int64_t n, float v) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = v;
 }
@@ -546,6 +575,29 @@ extern "C" int pc_transpose_batched(const float* src, int batch, int R, int Cc, 
     hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(Cc, 32), cdiv(R, 32), batch), dim3(256), 0, (hipStream_t)s, src, R, Cc, src_batch_stride,
                        src_ld, dst, dst_batch_stride, dst_ld, accum);
     PC_CHECK_LAUNCH("transpose");
+    return PC_OK;
+}
+
+extern "C" int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_stream s) {
+    PC_CHECK_ARG(jobs && njobs >= 1, "pc_transpose_multi: bad args");
+    for (int j0 = 0; j0 < njobs; j0 += TM_JOBS) {
+        TPack pk;
+        pk.n = njobs - j0 < TM_JOBS ? njobs - j0 : TM_JOBS;
+        int tiles = 0;
+        for (int q = 0; q < pk.n; ++q) {
+            const pc_transpose_job& a = jobs[j0 + q];
+            PC_CHECK_ARG(a.src && a.dst && a.batch >= 1 && a.R >= 1 && a.C >= 1, "pc_transpose_multi: bad job %d", j0 + q);
+            TJobK& k = pk.j[q];
+            k.src = (const float*)(uintptr_t)a.src; k.dst = (float*)(uintptr_t)a.dst; k.sbs = a.src_batch_stride; k.dbs = a.dst_batch_stride;
+            k.R = a.R; k.Cc = a.C; k.sld = a.src_ld; k.dld = a.dst_ld; k.accum = a.accum; k.pad_ = 0;
+            k.tiles_c = cdiv(a.C, 32); k.tiles_rc = k.tiles_c * cdiv(a.R, 32);
+            pk.first[q] = tiles;
+            tiles += a.batch * k.tiles_rc;
+        }
+        pk.first[pk.n] = tiles;
+        hipLaunchKernelGGL(transpose_multi_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)s, pk);
+        PC_CHECK_LAUNCH("transpose_multi");
+    }
     return PC_OK;
 }
 

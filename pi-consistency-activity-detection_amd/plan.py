@@ -701,7 +701,10 @@ class Plan:
         """-> dict list-name -> numpy array of capi.OP_DTYPE with absolute device pointers."""
         self.finalize()
         out = {}
+        keep = out["_tjobs"] = []          # host job tables of the TRANSPOSE_MULTI ops (the list's owner keeps `out` alive)
         for name, lst in self.lists.items():
+            if name == "prep":
+                lst = self._merge_prep_transposes(lst, bases, keep)
             arr = np.zeros(len(lst), dtype=capi.OP_DTYPE)
             for j, (kind, i, f, p, l, lane) in enumerate(lst):
                 arr[j]["kind"] = kind
@@ -710,9 +713,34 @@ class Plan:
                 arr[j]["f"][:len(f)] = f
                 arr[j]["l"][:len(l)] = l
                 for q, r in enumerate(p):
-                    arr[j]["p"][q] = 0 if r is None else bases[r[0]] + r[1]
+                    arr[j]["p"][q] = 0 if r is None else (r[1] if r[0] == "HOST" else bases[r[0]] + r[1])
             out[name] = arr
         return out
+
+    def _merge_prep_transposes(self, lst, bases, keep):
+        """The weight re-layouts that read master parameters are independent of each other: all of them on one lane
+        become ONE launch (pc_transpose_multi, jobs passed by value) instead of ~80 seven-microsecond launches."""
+        res, pending = [], {}
+
+        def flush():
+            for lane in sorted(pending):
+                jobs = pending[lane]
+                tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
+                for q, (kind, i, f, p, l, _ln) in enumerate(jobs):
+                    tab[q] = (bases[p[0][0]] + p[0][1], bases[p[1][0]] + p[1][1], l[0], l[1], i[0], i[1], i[2], i[3], i[4], i[5])
+                keep.append(tab)
+                res.append((capi.OP_TRANSPOSE_MULTI, [len(jobs)], [], [("HOST", tab.ctypes.data)], [], lane))
+            pending.clear()
+        for op in lst:
+            if op[0] == capi.OP_TRANSPOSE and op[3][0][0] == "P":
+                pending.setdefault(op[5], []).append(op)
+            elif op[0] == capi.OP_FILL or op[0] == capi.OP_FORK:
+                res.append(op)           # fills precede the transposes into their buffer; the fork opens the region
+            else:
+                flush()
+                res.append(op)
+        flush()
+        return res
 
     def flops(self, only_kind=None):
         """Algorithmic FLOPs (2*M*N*K, real channel counts) of the conv / wgrad ops per list."""

@@ -110,7 +110,14 @@ def test_prep_list_is_spread_over_lanes_at_resolve():
         assert dest_lane.setdefault(dst, lane) == lane               # FILL + transposes of one buffer: same lane
     for op in lst[j + 1:]:
         assert op[5] == 0 and op[3][0][0] == "A"                     # second-level layouts read prepared buffers
-    assert len(arrs["prep"]) == len(lst) and int(arrs["prep"][0]["kind"]) == capi.OP_FORK
+    # in the resolved array every lane's parameter re-layouts are one multi-job launch inside the region
+    kinds = [int(k) for k in arrs["prep"]["kind"]]
+    assert kinds[0] == capi.OP_FORK and kinds.count(capi.OP_TRANSPOSE_MULTI) == 2 and capi.OP_TRANSPOSE not in kinds[:kinds.index(capi.OP_JOIN)]
+    multi = arrs["prep"][[k == capi.OP_TRANSPOSE_MULTI for k in kinds]]
+    assert sorted(int(x) for x in multi["lane"]) == [0, 1]
+    n_par = sum(1 for op in lst[f + 1:j] if op[0] == capi.OP_TRANSPOSE)
+    assert int(multi["i"][:, 0].sum()) == n_par and sum(len(t) for t in arrs["_tjobs"]) == n_par
+    assert {int(multi["p"][q, 0]) for q in range(2)} == {t.ctypes.data for t in arrs["_tjobs"]}
     # idempotent
     p.resolve({"A": 1 << 20, "P": 1 << 30, "G": 1 << 31, "M": 1 << 32, "V": 1 << 33, "R": 1 << 34})
     assert len(p.lists["prep"]) == len(lst)
