@@ -382,6 +382,9 @@ class Plan:
         othw = tuple((x.thw[i] - 1) * stride[i] - 2 * pad[i] + k[i] + opad[i] for i in range(3))
         assert othw == tuple(out.thw), (name, othw, out.thw)
         w = self.prep_convT_weight(name + ".weight", Ci, cout, k)
+        if (self.spectral_pc and cscale is None and x.thw[0] == 1 and k[0] == 1 and k[2] >= 7 and tuple(stride) == (1, 1, 1)
+                and tuple(pad) == (0, 0, 0) and tuple(opad) == (0, 0, 0)):
+            return self._convT_spectral(name, x, cout, k, act, out, w)
         flags = capi.F_BIAS | (capi.F_CSCALE if cscale is not None else 0)
         if cscale is None and max(k) >= 7 and tuple(stride) == (1, 1, 1) and self.groups * self.n == x.N:
             flags |= capi.F_NFAST          # 9x9 'full' conv (upsample1): most taps of a border patch are padding
@@ -412,6 +415,44 @@ class Plan:
             dx, acc = self.grad_for_write(x)
             dd = D.conv_fwd(x.N, othw, cout, dz.ld, Ci, dx.ld, k, stride, pad, x.thw, flags=capi.F_ACCUM if acc else 0, ldw=cout)
             self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=F_fwd)
+        self.tape.append(bwd)
+
+    def _convT_spectral(self, name, x, cout, k, act, out, w):
+        """Stride-1 9x9 ConvTranspose2d (upsample1) in row-spectral form (spectral.LayoutT): a full convolution along x is
+        a product per frequency, what is left is one grouped transposed conv along y (a quarter of the direct FLOPs)."""
+        Ci, KY, KX = x.C, k[1], k[2]
+        SL = spectral.LayoutT(x.N, x.thw[1], x.thw[2], Ci, x.ld, cout, out.ld, KY, KX)
+        sm = {kk: self.const(v) for kk, v in SL.matrices().items()}
+        w["wv"] = self.alloc(SL.G * SL.w_g)                  # [g][Co][ky][Ci]  forward (transposed-form) GEMM weight planes
+        w["wvt"] = self.alloc(SL.G * SL.w_g)                 # [g][Ci][ky][Co]  dgrad GEMM weight planes
+        self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu], p=[w["fwd"], sm["tw"], w["wv"]], lst="prep")
+        self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu], p=[w["tr"], sm["tw"], w["wvt"]], lst="prep")
+        xpl = self.alloc(SL.G * SL.x_g)
+        tpl = self.alloc(SL.G * SL.t_g)
+        self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_planes(), capi.AXIS_FIELDS), p=[x.ref, sm["F"], None, xpl])
+        for dd in SL.convT():
+            self.conv_op(dd, xpl, w["wv"], tpl)
+        self.emit(capi.OP_AXIS, i=D.flatten(SL.planes_to_y(act, 0), capi.AXIS_FIELDS), p=[tpl, sm["G"], self.P(name + ".bias"), out.ref])
+        othw = tuple(out.thw)
+
+        def bwd():
+            dy = self.grad_of(out)
+            dz = self.tensor(x.N, othw, cout, name + ".dz") if act != capi.ACT_NONE else dy
+            ws = self.alloc(_act_bwd_ws(out.rows, cout))
+            self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
+                      p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
+            dtpl = self.alloc(SL.G * SL.t_g)
+            dwv = self.alloc(SL.G * SL.w_g)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dz.ld), capi.AXIS_FIELDS), p=[dz.ref, sm["Gt"], None, dtpl])
+            self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[xpl, dtpl, dwv])
+            self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu], p=[dwv, sm["tw"], w["kg"]])
+            self.flush_grad(w)
+            self.mark_final(name + ".bias")
+            dx, acc = self.grad_for_write(x)
+            dxpl = self.alloc(SL.G * SL.x_g)
+            self.alg_dgrad(SL.flops())
+            self.conv_op(SL.dgrad(), dtpl, w["wvt"], dxpl, alg=0)
+            self.emit(capi.OP_AXIS, i=D.flatten(SL.planes_to_dx(dx.ld, acc), capi.AXIS_FIELDS), p=[dxpl, sm["Ft"], None, dx.ref])
         self.tape.append(bwd)
 
     # ------------------------------------------------------------------ whole model

@@ -75,6 +75,19 @@ def matrices(P, KX):
     return dict(F=f32(F), Ft=f32(F.T), G=f32(G), Gt=f32(G.T), tw=twiddles(P, KX))
 
 
+def matrices_full(P, W, KX):
+    """The same for a FULL convolution along x (stride-1 ConvTranspose: y = x * w, W + KX - 1 = P outputs from W inputs):
+    Y^ = X^ W^ without the conjugate.  With the conjugate twiddle table (cos, +sin) the weight-plane kernels produce
+    V1 = Wr + Wi and V2 = -(Wi - Wr), for which Re = t0 - t1, Im = t0 - t2 again, so F (restricted to the W input columns)
+    and G (all P outputs) keep their form."""
+    assert W + KX - 1 == P
+    m = matrices(P, 1)                       # OW = P: every output column
+    F = np.ascontiguousarray(m["F"][:, :W])
+    tw = twiddles(P, KX).copy()
+    tw[..., 1] = -tw[..., 1]
+    return dict(F=F, Ft=np.ascontiguousarray(F.T), G=m["G"], Gt=m["Gt"], tw=tw)
+
+
 def axis(R, I, O, C, in_sr, in_hi, in_lo, in_split, out_sr, out_hi, out_lo, out_split, act=0, act_c0=0, accum=0):
     return dict(R=R, I=I, O=O, C=C, in_split=in_split, out_split=out_split, act=act, act_c0=act_c0, accum=accum,
                 in_sr=in_sr, in_hi=in_hi, in_lo=in_lo, out_sr=out_sr, out_hi=out_hi, out_lo=out_lo)
@@ -133,6 +146,100 @@ class Layout:
     def flops(self):
         """Issued-algorithmic FLOPs of the forward grouped conv (= dgrad = wgrad): 2 * rows * Co * 9 * Ci per group."""
         return 2 * self.G * self.N * self.OH * self.Co * self.KY * self.Ci
+
+
+class LayoutT:
+    """Stride-1 ConvTranspose2d with a KY x KX kernel (upsample1, capsules_ucf101.py:375,488): x [N][H][W][Ci] (row stride
+    ldx) -> y [N][H+KY-1][W+KX-1][Co] (row stride ldy).  Same planes as Layout; along y the grouped GEMM is the
+    transposed (scatter-adjoint) form, its dgrad an ordinary grouped conv, the weight gradient in ConvTranspose
+    convention dV[g] [Ci][KY][Co] = X[g]^T . dT[g]."""
+
+    def __init__(self, N, H, W, Ci, ldx, Co, ldy, KY, KX):
+        self.N, self.H, self.W, self.Ci, self.ldx, self.Co, self.ldy, self.KY, self.KX = N, H, W, Ci, ldx, Co, ldy, KY, KX
+        self.OH, self.OW = H + KY - 1, W + KX - 1
+        self.P = self.OW
+        self.nu = n_freq(self.P)
+        self.G = 3 * self.nu
+        self.x_g = N * H * Ci
+        self.t_g = N * self.OH * Co
+        self.w_g = Co * KY * Ci
+
+    def matrices(self):
+        return matrices_full(self.P, self.W, self.KX)
+
+    def x_to_planes(self):
+        return axis(self.N * self.H, self.W, self.G, self.Ci, self.W * self.ldx, self.ldx, 0, 1, self.Ci, self.x_g, 0, 1)
+
+    def planes_to_y(self, act, act_c0):
+        return axis(self.N * self.OH, self.G, self.OW, self.Co, self.Co, self.t_g, 0, 1, self.OW * self.ldy, self.ldy, 0, 1,
+                    act=act, act_c0=act_c0)
+
+    def dy_to_planes(self, lddy):
+        return axis(self.N * self.OH, self.OW, self.G, self.Co, self.OW * lddy, lddy, 0, 1, self.Co, self.t_g, 0, 1)
+
+    def planes_to_dx(self, lddx, accum):
+        return axis(self.N * self.H, self.G, self.W, self.Ci, self.Ci, self.x_g, 0, 1, self.W * lddx, lddx, 0, 1, accum=int(accum))
+
+    def convT(self):
+        out = D.transposed_classes(self.G * self.N, (1, self.H, 1), self.Ci, self.Ci, (1, self.OH, 1), self.Co, self.Co,
+                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G)
+        for d in out:
+            d["wgstride"] = self.w_g
+        return out
+
+    def dgrad(self):
+        d = D.conv_fwd(self.G * self.N, (1, self.OH, 1), self.Co, self.Co, self.Ci, self.Ci, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+                       (1, self.H, 1), groups=self.G, ldw=self.Co)
+        d["wgstride"] = self.w_g
+        return d
+
+    def wgrad(self):
+        d = D.wgrad(self.N, (1, self.H, 1), self.Ci, self.Ci, (1, self.OH, 1), self.Co, self.Co, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+                    splitk=-1)
+        d.update(nbatch=self.G, dbstride=self.x_g, sbstride=self.t_g, gbstride=self.w_g)
+        return d
+
+    def flops(self):
+        """Issued-algorithmic FLOPs of one grouped GEMM: 2 * input rows * Co * KY * Ci per group."""
+        return 2 * self.G * self.N * self.H * self.Co * self.KY * self.Ci
+
+
+def conv_transpose_fwd_bwd(x, w, bias, dy):
+    """Tensor-level runner (tests): x [N][H][W][Ci] cuda, w [Ci][Co][KY][KX] (ConvTranspose2d layout), bias [Co],
+    dy [N][OH][OW][Co] = gradient of the pre-activation output.  -> (relu(y), dx, dw [Ci][Co][KY][KX])."""
+    import torch
+    from . import ops
+    dev = x.device
+    N, H, W, Ci = x.shape
+    _, Co, KY, KX = w.shape
+    L = LayoutT(N, H, W, Ci, Ci, Co, Co, KY, KX)
+    m = {k: torch.from_numpy(v).to(dev) for k, v in L.matrices().items()}
+    wf = w.reshape(Ci, Co, KY * KX).permute(1, 2, 0).contiguous()          # [Co][taps][Ci]
+    wt = w.reshape(Ci, Co, KY * KX).permute(0, 2, 1).contiguous()          # [Ci][taps][Co]
+    f32 = dict(device=dev, dtype=torch.float32)
+    xp = torch.empty(L.G * L.x_g, **f32)
+    ops.axis_linear(L.x_to_planes(), x, m["F"], xp)
+    wv = torch.empty(L.G * L.w_g, **f32)
+    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, wv)
+    tp = torch.zeros(L.G * L.t_g, **f32)
+    for dd in L.convT():
+        ops.conv_fwd(dd, xp, wv, tp)
+    y = torch.empty(N, L.OH, L.OW, Co, **f32)
+    ops.axis_linear(L.planes_to_y(capi.ACT_RELU, 0), tp, m["G"], y, bias=bias)
+    dtp = torch.empty(L.G * L.t_g, **f32)
+    ops.axis_linear(L.dy_to_planes(Co), dy, m["Gt"], dtp)
+    dv = torch.empty(L.G * L.w_g, **f32)
+    ops.conv_wgrad(L.wgrad(), xp, dtp, dv)
+    kg = torch.empty(Ci, KY * KX, Co, **f32)
+    ops.wspec_bwd(dv, m["tw"], Ci, Co, KY, KX, L.nu, kg)
+    dw = kg.permute(0, 2, 1).reshape(Ci, Co, KY, KX)
+    wvt = torch.empty(L.G * L.w_g, **f32)
+    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, wvt)
+    dxp = torch.empty(L.G * L.x_g, **f32)
+    ops.conv_fwd(L.dgrad(), dtp, wvt, dxp)
+    dx = torch.empty(N, H, W, Ci, **f32)
+    ops.axis_linear(L.planes_to_dx(Ci, False), dxp, m["Ft"], dx)
+    return y, dx, dw
 
 
 def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):

@@ -126,6 +126,26 @@ def test_primary_caps_row_spectral_form_vs_torch(N, HW, Ci, Co, K):
     close(dwg, w.grad, what="wgrad")
 
 
+@pytest.mark.parametrize("N,HW,Ci,Co,K", [(3, 10, 24, 16, 5), (2, 9, 8, 12, 3), (2, 20, 384, 64, 9)])
+def test_conv_transpose_row_spectral_form_vs_torch(N, HW, Ci, Co, K):
+    """Stride-1 ConvTranspose2d (upsample1) in the row-spectral form (full convolution along x: conjugate twiddles,
+    grouped transposed conv along y): relu(output), input gradient, weight gradient against torch."""
+    from picons_amd import spectral
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(N, Ci, HW, HW, generator=g, requires_grad=True)
+    w = (torch.randn(Ci, Co, K, K, generator=g) / np.sqrt(Ci * K * K)).requires_grad_(True)
+    b = torch.randn(Co, generator=g) * 0.1
+    z = F.conv_transpose2d(x, w, b)
+    dz = torch.randn(z.shape, generator=g)
+    z.backward(dz)
+    xg = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    dzg = dz.permute(0, 2, 3, 1).contiguous().to(DEV)
+    yg, dxg, dwg = spectral.conv_transpose_fwd_bwd(xg, w.detach().to(DEV), b.to(DEV), dzg)
+    close(yg.permute(0, 3, 1, 2), torch.relu(z), rtol=2e-5, what="output")
+    close(dxg.permute(0, 3, 1, 2), x.grad, what="dgrad")
+    close(dwg, w.grad, what="wgrad")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)
