@@ -788,9 +788,12 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // of a padded 128-row tile (4.98 vs 5.23 ms); small problems lose more to the second launch than they save
     const int full = d->Cd / 128 * 128, rem = d->Cd - full;
     const bool deep = (int64_t)(full / 128) * cdiv(k.Ntot, 128) * (d->nbatch > 1 ? d->nbatch : 1) >= 1024;
+    // 64-row tiles run at ~0.88 of the 128-row tiles' rate: take them when they pad that much less (192 = 3 x 64 vs 2 x 128)
+    const double pad128 = (double)cdiv(d->Cd, 128) * 128, pad64 = (double)cdiv(d->Cd, 64) * 64;
     if (d->Cd <= 64) launch(0, d->Cd, true);
-    else if (rem == 0 || rem > 64 || !deep) launch(0, d->Cd, false);
-    else { launch(0, full, false); launch(full, d->Cd, true); }
+    else if (rem != 0 && rem <= 64 && deep) { launch(0, full, false); launch(full, d->Cd, true); }
+    else if (pad128 > 1.15 * pad64) launch(0, d->Cd, true);
+    else launch(0, d->Cd, false);
     PC_CHECK_LAUNCH("wgrad_kernel");
     return PC_OK;
 }
