@@ -306,8 +306,11 @@ int pc_run_ops(const pc_op* ops, int n, pc_stream s);
 int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes);
 /* same, with a hipEvent pair recorded around every op of `kind` on the stream that op runs on;
  * returns elapsed ms summed over those ops in *ms and their count in *count (bench.py roofline
- * leg).  Synchronises all lanes before returning. */
+ * leg).  Synchronises all lanes before returning (unless ms == NULL, see below). */
 int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes);
+/* With ms == NULL pc_run_ops_timed does not synchronise: the event pairs stay pending (per host thread) until this call
+ * waits for them and returns their summed elapsed ms and their number. */
+int pc_run_ops_timed_collect(float* ms, int* count);
 
 #ifdef __cplusplus
 }

@@ -102,6 +102,7 @@ _SIGS = {
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),
     "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp, i32]),
+    "pc_run_ops_timed_collect": (i32, [C.POINTER(f32), C.POINTER(i32)]),
 }
 EXPORTS = sorted(_SIGS)
 

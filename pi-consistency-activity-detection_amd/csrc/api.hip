@@ -2,6 +2,7 @@
 // host-built plan (pi-consistency-activity-detection_amd/plan.py) with no per-op host round trip.
 #include "common.h"
 #include <string.h>
+#include <vector>
 
 static thread_local char g_err[512] = "";
 
@@ -124,6 +125,10 @@ static int run_one(const pc_op& op, pc_stream s) {
 static thread_local hipEvent_t g_ev[PC_MAX_LANES];
 static thread_local bool g_ev_init = false;
 
+// Deferred kernel timing: event pairs recorded by pc_run_ops_timed(..., ms = NULL) wait here until
+// pc_run_ops_timed_collect reads them, so the timed replay adds no host synchronisation of its own.
+static thread_local std::vector<hipEvent_t> g_pending;
+
 static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes, int kind, float* ms, int* count) {
     if (!ops && n > 0) { pc_set_error("pc_run_ops: null ops"); return PC_E_ARG; }
     if (nlanes < 1 || nlanes > PC_MAX_LANES || !lanes) { pc_set_error("pc_run_ops: nlanes=%d (1..%d)", nlanes, PC_MAX_LANES); return PC_E_ARG; }
@@ -169,7 +174,12 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         snprintf(tmp, sizeof(tmp), "%s", g_err);
         pc_set_error("op %d (kind %d): %s", k - 1, ops[k - 1].kind, tmp);
     }
-    if (kind > 0) {
+    if (kind > 0 && !ms) {              // deferred: keep the recorded pairs for pc_run_ops_timed_collect
+        for (int i = 0; i < 2 * j; ++i) g_pending.push_back(ev[i]);
+        for (int i = 2 * j; i < 2 * cnt; ++i) (void)hipEventDestroy(ev[i]);
+        free(ev);
+        if (count) *count = j;
+    } else if (kind > 0) {
         for (int q = 0; q < nlanes; ++q) (void)hipStreamSynchronize((hipStream_t)lanes[q]);
         float total = 0.f;
         for (int i = 0; i < j; ++i) { float e = 0.f; (void)hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]); total += e; }
@@ -192,4 +202,22 @@ extern "C" int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes,
 extern "C" int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes) {
     if (kind <= 0) { pc_set_error("pc_run_ops_timed: kind=%d", kind); return PC_E_ARG; }
     return run_list(ops, n, lanes, nlanes, kind, ms, count);
+}
+
+extern "C" int pc_run_ops_timed_collect(float* ms, int* count) {
+    float total = 0.f;
+    const int pairs = (int)g_pending.size() / 2;
+    if (pairs) (void)hipEventSynchronize(g_pending.back());
+    for (int i = 0; i < pairs; ++i) {
+        float e = 0.f;
+        (void)hipEventSynchronize(g_pending[2 * i + 1]);
+        (void)hipEventElapsedTime(&e, g_pending[2 * i], g_pending[2 * i + 1]);
+        total += e;
+        (void)hipEventDestroy(g_pending[2 * i]);
+        (void)hipEventDestroy(g_pending[2 * i + 1]);
+    }
+    g_pending.clear();
+    if (ms) *ms = total;
+    if (count) *count = pairs;
+    return PC_OK;
 }

@@ -241,8 +241,15 @@ def run_ops(ops_np, n=None, side=None):
         capi.call("pc_run_ops_lanes", C.c_void_p(ops_np.ctypes.data), n, arr, nl)
 
 
-def run_ops_timed(ops_np, kind, side=None):
+def run_ops_timed(ops_np, kind, side=None, defer=False):
+    """defer: record the event pairs but do not synchronise; timed_collect() reads them later."""
     ms = C.c_float(0); cnt = C.c_int32(0)
     arr, nl = _lane_array(side)
-    capi.call("pc_run_ops_timed", C.c_void_p(ops_np.ctypes.data), len(ops_np), kind, C.byref(ms), C.byref(cnt), arr, nl)
+    capi.call("pc_run_ops_timed", C.c_void_p(ops_np.ctypes.data), len(ops_np), kind, None if defer else C.byref(ms), C.byref(cnt), arr, nl)
+    return ms.value, cnt.value
+
+
+def timed_collect():
+    ms = C.c_float(0); cnt = C.c_int32(0)
+    capi.call("pc_run_ops_timed_collect", C.byref(ms), C.byref(cnt))
     return ms.value, cnt.value

@@ -153,9 +153,7 @@ class StepEngine:
             if timed_kind is None or len(arr) == 0:
                 ops.run_ops(arr, side=self.side)
             else:
-                ms, cnt = ops.run_ops_timed(arr, timed_kind, side=self.side)
-                self.kind_ms += ms
-                self.kind_count += cnt
+                ops.run_ops_timed(arr, timed_kind, side=self.side, defer=True)    # read after the step's own sync
         run(o["prep"])
         run(o["fwd"])
         run(o["loss"])
@@ -211,7 +209,12 @@ class StepEngine:
             reducer.wait()
             gscale = reducer.gscale
         self.adam(self.args.lr if lr is None else lr, gscale)
-        return self.read_scalars()
+        out = self.read_scalars()            # the step's one host sync
+        if timed_kind is not None:
+            ms, cnt = ops.timed_collect()
+            self.kind_ms += ms
+            self.kind_count += cnt
+        return out
 
     def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, reducer=None):
         self.stage(label_mb, unlabel_mb, perm, drops)
