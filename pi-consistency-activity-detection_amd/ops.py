@@ -224,6 +224,18 @@ def wspec_bwd(dV, tw, A, B, KY, KX, U, kg):
     return kg
 
 
+def transpose_multi(jobs):
+    """jobs: list of (src, dst, batch, R, C, src_batch_stride, src_ld, dst_batch_stride, dst_ld, accum) with torch tensors
+    for src / dst: dst[b][c][r] (+)= src[b][r][c] for all of them in one launch."""
+    import numpy as np
+    tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
+    for q, (src, dst, batch, R, Cc, sbs, sld, dbs, dld, accum) in enumerate(jobs):
+        if not (src.is_cuda and dst.is_cuda):
+            raise RuntimeError("picons ops need CUDA/HIP tensors (no CPU fallback)")
+        tab[q] = (src.data_ptr(), dst.data_ptr(), sbs, dbs, batch, R, Cc, sld, dld, int(accum))
+    capi.call("pc_transpose_multi", C.c_void_p(tab.ctypes.data), len(jobs), stream())
+
+
 def _lane_array(side):
     """(c_void_p array, n): torch's current stream as lane 0 + the caller's side streams."""
     hs = [torch.cuda.current_stream().cuda_stream] + [st.cuda_stream for st in (side or ())]

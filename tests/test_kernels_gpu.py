@@ -146,6 +146,43 @@ def test_conv_transpose_row_spectral_form_vs_torch(N, HW, Ci, Co, K):
     close(dwg, w.grad, what="wgrad")
 
 
+def test_transpose_multi_many_jobs():
+    """pc_transpose_multi: 97 independent jobs (more than one argument pack) of ragged sizes, batched and accumulating
+    ones included, against torch."""
+    g = torch.Generator().manual_seed(31)
+    jobs, checks = [], []
+    for q in range(97):
+        B = 1 + q % 3; R = 1 + (q * 7) % 70; Cc = 1 + (q * 13) % 90
+        src = torch.randn(B, R, Cc, generator=g).to(DEV)
+        accum = q % 5 == 0
+        dst = torch.randn(B, Cc, R, generator=g).to(DEV) if accum else torch.full((B, Cc, R), 7.0, device=DEV)
+        want = src.transpose(1, 2) + (dst if accum else 0)
+        jobs.append((src, dst, B, R, Cc, R * Cc, Cc, Cc * R, R, accum))
+        checks.append((dst, want.clone()))
+    ops.transpose_multi(jobs)
+    torch.cuda.synchronize()
+    for dst, want in checks:
+        assert torch.equal(dst, want)
+
+
+def test_axis_linear_general_strides():
+    """pc_axis_linear with two-level input and output indices, bias, ReLU from a channel on, and accumulation."""
+    g = torch.Generator().manual_seed(32)
+    R, I, O, C_ = 5, 6, 4, 8
+    x = torch.randn(3, R, 2, C_, generator=g)            # index i = (i_hi in 0..2, i_lo in 0..1): [i_hi][r][i_lo][c]
+    M = torch.randn(O, I, generator=g)
+    b = torch.randn(C_, generator=g)
+    old = torch.randn(R, 2, 2, C_, generator=g)          # o = (o_hi, o_lo): [r][o_hi][o_lo][c]
+    xi = x.permute(1, 0, 2, 3).reshape(R, I, C_)         # [r][i][c]
+    want = torch.einsum("oi,ric->roc", M, xi) + b + old.reshape(R, O, C_)
+    want[:, :, 4:] = torch.relu(want[:, :, 4:])
+    d = dict(R=R, I=I, O=O, C=C_, in_split=2, out_split=2, act=capi.ACT_RELU, act_c0=4, accum=1,
+             in_sr=2 * C_, in_hi=R * 2 * C_, in_lo=C_, out_sr=4 * C_, out_hi=2 * C_, out_lo=C_)
+    out = old.clone().to(DEV)
+    ops.axis_linear(d, x.to(DEV), M.to(DEV), out, bias=b.to(DEV))
+    close(out.cpu().reshape(R, O, C_), want, rtol=1e-5, what="axis_linear")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)
