@@ -113,6 +113,16 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_wspec_fwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], P(float*, 2), s);
         case PC_OP_WSPEC_BWD:
             return pc_wspec_bwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], P(float*, 2), s);
+        case PC_OP_TAIL6_WEIGHTS:
+            return pc_tail6_weights(P(const float*, 0), op.i[0], op.i[1], P(float*, 1), P(float*, 2), s);
+        case PC_OP_TAIL6_GATHER:
+            return pc_tail6_gather(P(const float*, 0), P(const float*, 1), P(const float*, 2), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 3), s);
+        case PC_OP_TAIL6_SCATTER:
+            return pc_tail6_scatter(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
+        case PC_OP_TAIL6_WGRAD_MAP:
+            return pc_tail6_wgrad_map(P(const float*, 0), op.i[0], op.i[1], P(float*, 1), s);
+        case PC_OP_TAIL6_BIAS_SUMS:
+            return pc_tail6_bias_sums(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         case PC_OP_TRANSPOSE_MULTI:
             return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
         default:

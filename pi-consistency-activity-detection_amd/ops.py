@@ -224,6 +224,30 @@ def wspec_bwd(dV, tw, A, B, KY, KX, U, kg):
     return kg
 
 
+def tail6_weights(wf, N, Ci, W6f, W6t):
+    capi.call("pc_tail6_weights", ptr(wf), N, Ci, ptr(W6f), ptr(W6t), stream())
+
+
+def tail6_gather(cols, bc, bsm, N, It, Ih, Iw, out):
+    capi.call("pc_tail6_gather", ptr(cols), ptr(bc), ptr(bsm), N, It, Ih, Iw, ptr(out), stream())
+    return out
+
+
+def tail6_scatter(dout, N, It, Ih, Iw, dcols):
+    capi.call("pc_tail6_scatter", ptr(dout), N, It, Ih, Iw, ptr(dcols), stream())
+    return dcols
+
+
+def tail6_wgrad_map(dW6, N, Ci, Gc):
+    capi.call("pc_tail6_wgrad_map", ptr(dW6), N, Ci, ptr(Gc), stream())
+    return Gc
+
+
+def tail6_bias_sums(dout, N, It, Ih, Iw, sums):
+    capi.call("pc_tail6_bias_sums", ptr(dout), N, It, Ih, Iw, ptr(sums), stream())
+    return sums
+
+
 def transpose_multi(jobs):
     """jobs: list of (src, dst, batch, R, C, src_batch_stride, src_ld, dst_batch_stride, dst_ld, accum) with torch tensors
     for src / dst: dst[b][c][r] (+)= src[b][r][c] for all of them in one launch."""

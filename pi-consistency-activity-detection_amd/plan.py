@@ -58,6 +58,9 @@ class Plan:
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
         self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
+        # decoder tail as one five-tap transposed conv with a single output channel (csrc/tail6.hip) instead of the
+        # 27-channel form + tap sum
+        self.merged_tail = os.environ.get("PICONS_TAIL6", "1") != "0"
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -620,6 +623,8 @@ class Plan:
         cs_ref = self.in_drop128 if self.training else None
         W4, b4, Wp = self.P("upsample4.weight"), self.P("upsample4.bias"), self.P("smooth.weight")
         self.emit(capi.OP_TAIL_COMBINE, i=[N, 128, 128, 27, J], p=[W4, b4, cs_ref, Wp, wt, wf, bc])
+        if self.merged_tail:
+            return self._merged_tail(cat112, othw, wf, bc, cs_ref, W4, b4, Wp, J)
         proj = self.tensor(N, othw, 32, "proj")
         F_tail = 0
         for dd in D.transposed_classes(N, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1, flags=capi.F_BIAS, groups=N):
@@ -651,6 +656,49 @@ class Plan:
             dd = D.conv_fwd(N, othw, 32, 32, 128, dx.ld, k3, s2, p1, cat112.thw, flags=capi.F_ACCUM if acc else 0, groups=N, ldw=32)
             dd["wgstride"] = 128 * 27 * 32
             self.conv_op(dd, dproj.ref, wt, dx.ref, alg=F_tail)
+        self.tape.append(bwd_smooth)
+        return out
+
+    def _merged_tail(self, cat112, othw, wf, bc, cs_ref, W4, b4, Wp, J):
+        """upsample4 -> Dropout3d -> smooth as ONE five-tap stride-2 transposed conv with a single output channel
+        (csrc/tail6.hip): per clip-pass a 128 -> 216 column GEMM over the 4x112x112 input positions and a gather of the
+        <= 27 column entries that land on each of the 8x224x224 outputs; 44 GFLOP per pass instead of 177."""
+        N = cat112.N
+        It, Ih, Iw = cat112.thw
+        C6, C6P = 216, 224
+        one, zero = (1, 1, 1), (0, 0, 0)
+        w6f = self.alloc(N * C6P * 128)                 # [n][c6][ci]   forward GEMM weights
+        w6t = self.alloc(N * 128 * C6P)                 # [n][ci][c6]   dgrad GEMM weights
+        self.emit(capi.OP_TAIL6_WEIGHTS, i=[N, 128], p=[wf, w6f, w6t])
+        cols = self.alloc(cat112.rows * C6P)
+        F_t6 = 2 * cat112.rows * C6 * 128
+        d = D.conv_fwd(N, cat112.thw, 128, cat112.ld, C6P, C6P, one, one, zero, cat112.thw, groups=N)
+        d["wgstride"] = C6P * 128
+        self.conv_op(d, cat112.ref, w6f, cols, alg=F_t6)
+        out = self.tensor(N, othw, 1, "out")
+        self.emit(capi.OP_TAIL6_GATHER, i=[N, It, Ih, Iw], p=[cols, bc, self.P("smooth.bias"), out.ref])
+        self.out = out
+
+        def bwd_smooth():
+            dcols = self.alloc(cat112.rows * C6P)
+            self.emit(capi.OP_TAIL6_SCATTER, i=[N, It, Ih, Iw], p=[self.dout, dcols])
+            sums = self.alloc(N * 32)
+            self.emit(capi.OP_TAIL6_BIAS_SUMS, i=[N, It, Ih, Iw], p=[self.dout, sums])
+            dW6 = self.alloc(N * 128 * C6P)
+            self.emit(capi.OP_FILL, p=[dW6], l=[N * 128 * C6P], f=[0.0])
+            per_in = It * Ih * Iw
+            wd = D.wgrad(1, cat112.thw, 128, cat112.ld, cat112.thw, C6P, C6P, one, one, zero)
+            wd.update(nbatch=N, dbstride=per_in * cat112.ld, sbstride=per_in * C6P, gbstride=128 * C6P)
+            self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS), p=[cat112.ref, dcols, dW6])
+            Gc = self.alloc(N * 128 * 27 * 32)
+            self.emit(capi.OP_TAIL6_WGRAD_MAP, i=[N, 128], p=[dW6, Gc])
+            self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
+                      p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
+            self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
+            dx, acc = self.grad_for_write(cat112)
+            dd = D.conv_fwd(N, cat112.thw, C6P, C6P, 128, dx.ld, one, one, zero, cat112.thw, flags=capi.F_ACCUM if acc else 0, groups=N)
+            dd["wgstride"] = 128 * C6P
+            self.conv_op(dd, dcols, w6t, dx.ref, alg=F_t6)
         self.tape.append(bwd_smooth)
         return out
 

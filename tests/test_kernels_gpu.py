@@ -590,6 +590,66 @@ def test_collapsed_tail_kernels_vs_torch():
     close(uncl(dx), xr.grad, what="collapsed dgrad")
 
 
+def test_merged_tail_vs_torch():
+    """upsample4 -> Dropout3d -> smooth as ONE five-tap stride-2 transposed conv with a single output channel
+    (csrc/tail6.hip): 216-column GEMM + gather forward; scatter + two GEMMs + the map back onto the combined weights
+    backward; output, input gradient and all four parameter gradients against torch (capsules_ucf101.py:504-509)."""
+    g = torch.Generator().manual_seed(14)
+    N, Ci, Co, taps, J = 3, 8, 12, 27, 27
+    I = (2, 3, 5)
+    W4 = (torch.randn(Ci, Co, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    b4 = torch.randn(Co, generator=g).requires_grad_(True)
+    Wp = (torch.randn(Co, 1, 3, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    bp = torch.randn(1, generator=g).requires_grad_(True)
+    cs = (torch.rand(N, Co, generator=g) < 0.5).float() * 2
+    x = torch.randn(N, Ci, *I, generator=g, requires_grad=True)
+    u = F.conv_transpose3d(x, W4, b4, stride=2, padding=1, output_padding=1) * cs.view(N, Co, 1, 1, 1)
+    out = F.conv_transpose3d(u, Wp, bp, padding=1)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    dev = lambda t: t.detach().contiguous().to(DEV)
+    Wt = torch.empty(N, Ci, taps, 32, device=DEV); Wf = torch.empty(N, 32, taps, Ci, device=DEV); bc = torch.empty(N, 32, device=DEV)
+    W4g, b4g, csg, Wpg, bpg = dev(W4), dev(b4), dev(cs), dev(Wp), dev(bp)
+    capi.call("pc_tail_combine", ops.ptr(W4g), ops.ptr(b4g), ops.ptr(csg), ops.ptr(Wpg), N, Ci, Co, taps, J,
+              ops.ptr(Wt), ops.ptr(Wf), ops.ptr(bc), ops.stream())
+    C6P = 224
+    W6f = torch.empty(N, C6P, Ci, device=DEV); W6t = torch.empty(N, Ci, C6P, device=DEV)
+    ops.tail6_weights(Wf, N, Ci, W6f, W6t)
+    xg = cl(x)
+    cols = torch.empty(N, *I, C6P, device=DEV)
+    d = desc.conv_fwd(N, I, Ci, Ci, C6P, C6P, (1, 1, 1), (1, 1, 1), (0, 0, 0), I, groups=N)
+    d["wgstride"] = C6P * Ci
+    ops.conv_fwd(d, xg, W6f, cols)
+    o = torch.empty(N, *[2 * v for v in I], device=DEV)
+    ops.tail6_gather(cols, bc, bpg, N, *I, o)
+    close(o.cpu(), out[:, 0], what="merged forward")
+    # backward
+    doutg = dev(dout[:, 0])
+    dcols = torch.empty(N, *I, C6P, device=DEV)
+    ops.tail6_scatter(doutg, N, *I, dcols)
+    dx = torch.empty(N, *I, Ci, device=DEV)
+    dd = desc.conv_fwd(N, I, C6P, C6P, Ci, Ci, (1, 1, 1), (1, 1, 1), (0, 0, 0), I, groups=N)
+    dd["wgstride"] = Ci * C6P
+    ops.conv_fwd(dd, dcols, W6t, dx)
+    close(uncl(dx), x.grad, what="merged dgrad")
+    dW6 = torch.zeros(N, Ci, C6P, device=DEV)
+    per = int(np.prod(I))
+    wd = desc.wgrad(1, I, Ci, Ci, I, C6P, C6P, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    wd.update(nbatch=N, dbstride=per * Ci, sbstride=per * C6P, gbstride=Ci * C6P)
+    ops.conv_wgrad(wd, xg, dcols, dW6)
+    Gc = torch.empty(N, Ci, taps, 32, device=DEV)
+    ops.tail6_wgrad_map(dW6, N, Ci, Gc)
+    sums = torch.empty(N, 32, device=DEV)
+    ops.tail6_bias_sums(doutg, N, *I, sums)
+    dproj = ops.tapsum_bwd(doutg)
+    close(sums[:, :27], dproj.reshape(N, -1, 32).sum(1)[:, :27], what="bias sums")
+    dW4 = torch.zeros(Ci, Co, taps, device=DEV); db4 = torch.zeros(Co, device=DEV); dWp = torch.zeros(Co, J, device=DEV); dbp = torch.zeros(1, device=DEV)
+    capi.call("pc_tail_grads", ops.ptr(Gc), ops.ptr(sums), ops.ptr(W4g), ops.ptr(b4g), ops.ptr(csg), ops.ptr(Wpg), N, Ci, Co, taps, J, 13,
+              ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 0, ops.stream())
+    close(dW4.cpu(), W4.grad.reshape(Ci, Co, taps), what="dW4"); close(db4.cpu(), b4.grad, what="db4")
+    close(dWp.cpu(), Wp.grad.reshape(Co, J), what="dWp"); close(dbp.cpu(), bp.grad, what="dbp")
+
+
 def test_full_correlation_as_gemm_plus_col2im():
     """PrimaryCaps dgrad form: cols = dY x W^T (1x1 conv with Co = taps*Ci) then pc_col2im == conv2d dgrad."""
     g = torch.Generator().manual_seed(14)
