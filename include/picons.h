@@ -94,6 +94,8 @@ typedef struct pc_wgrad_desc {
     int32_t nbatch;                 /* 0/1 = one problem; > 1: that many independent problems in ONE launch (blockIdx.z =
                                      * problem * slices + slice), D, S and g advanced by the strides below (floats) */
     int32_t dbstride, sbstride, gbstride;
+    int32_t Td, Hd, Wd, doff[3];    /* Td > 0: D is not dense but the sub-lattice (Tq,Hq,Wq) starting at doff of a
+                                     * [N][Td][Hd][Wd][ldd] tensor (with nbatch > 1: per problem, N = 1 each) */
 } pc_wgrad_desc;
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
 
@@ -274,19 +276,21 @@ int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX,
 
 /* ------------------------------------------------------------------------------------------
  * Merged decoder tail (capsules_ucf101.py:504-509).  upsample4 -> Dropout3d -> smooth composes, per dimension, into one
- * stride-2 transposed conv with five taps k5 = k4 + ks and ONE output channel; the single term that would pass through
- * the cropped position m = -1 of upsample4's output (input index 0, k4 = 0, only in tap k5 = 2) is kept out by a sixth
- * column "2'" used at input index 0.  cols[n][i][c6] = x[n][i][:] . W6[n][:][c6] is one grouped 1x1 GEMM (216 columns,
- * padded to 224) for pc_conv_fwd; these helpers are the rest.  Column index c6 = (ct*6 + ch)*6 + cw. */
-/* wf [N][32][27][Ci] (pc_tail_combine's forward layout) -> W6f [N][224][Ci] (forward GEMM), W6t [N][Ci][224] (dgrad GEMM) */
-int pc_tail6_weights(const float* wf, int N, int Ci, float* W6f, float* W6t, pc_stream s);
-/* out[n][o] = bsm[0] + sum_{ks: o+1-ks in grid} bc[n][ks] + sum of the <= 27 entries of cols [N][It][Ih][Iw][224] that
+ * stride-2 transposed conv with five taps k5 = k4 + ks (o = 2i - 2 + k5) and ONE output channel; the single term that
+ * would pass through the cropped position m = -1 of upsample4's output (input index 0, k4 = 0, only in tap k5 = 2) is
+ * left out of that tap's weight for the positions whose index is 0 in that dimension.  The positions therefore fall into
+ * 8 classes z = 4*(it==0) + 2*(ih==0) + (iw==0), each with its own 128 x 125 weight matrix, and
+ * cols[n][i][slot] = x[n][i][:] . W5[n][z(i)][:][slot], slot = (k5t*5 + k5h)*5 + k5w (125, padded to 128), is one grouped
+ * 1x1 GEMM per class over its sub-lattice for pc_conv_fwd; these helpers are the rest. */
+/* wf [N][32][27][Ci] (pc_tail_combine's forward layout) -> W5f [N][8][128][Ci] (forward GEMM), W5t [N][8][Ci][128] (dgrad GEMM) */
+int pc_tail6_weights(const float* wf, int N, int Ci, float* W5f, float* W5t, pc_stream s);
+/* out[n][o] = bsm[0] + sum_{ks: o+1-ks in grid} bc[n][ks] + sum of the <= 27 entries of cols [N][It][Ih][Iw][128] that
  * land on o = 2i - 2 + k5; out is [N][2It][2Ih][2Iw] */
 int pc_tail6_gather(const float* cols, const float* bc, const float* bsm, int N, int It, int Ih, int Iw, float* out, pc_stream s);
-/* the transpose: dcols[n][i][c6] = dout[n][o(i, c6)] (0 where the column is not in use or o is outside) */
+/* the transpose: dcols[n][i][slot] = dout[n][2i - 2 + k5] (0 where that output does not exist) */
 int pc_tail6_scatter(const float* dout, int N, int It, int Ih, int Iw, float* dcols, pc_stream s);
-/* dW6 [N][Ci][224] -> gradient of the combined weights Gc [N][Ci][27][32] in the layout pc_tail_grads consumes */
-int pc_tail6_wgrad_map(const float* dW6, int N, int Ci, float* Gc, pc_stream s);
+/* dW5 [N][8][Ci][128] -> gradient of the combined weights Gc [N][Ci][27][32] in the layout pc_tail_grads consumes */
+int pc_tail6_wgrad_map(const float* dW5, int N, int Ci, float* Gc, pc_stream s);
 /* sums[n][ks] = sum of dout[n][o] over the outputs whose smooth tap ks reads an in-grid position (what pc_tail_colsum
  * gives on the 27-channel form) */
 int pc_tail6_bias_sums(const float* dout, int N, int It, int Ih, int Iw, float* sums, pc_stream s);
@@ -311,10 +315,10 @@ enum {
     PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
     PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U; p = in, tw, out */
     PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U; p = dV, tw, kg */
-    PC_OP_TAIL6_WEIGHTS,            /* i = N, Ci; p = wf, W6f, W6t */
+    PC_OP_TAIL6_WEIGHTS,            /* i = N, Ci; p = wf, W5f, W5t */
     PC_OP_TAIL6_GATHER,             /* i = N, It, Ih, Iw; p = cols, bc, bsm, out */
     PC_OP_TAIL6_SCATTER,            /* i = N, It, Ih, Iw; p = dout, dcols */
-    PC_OP_TAIL6_WGRAD_MAP,          /* i = N, Ci; p = dW6, Gc */
+    PC_OP_TAIL6_WGRAD_MAP,          /* i = N, Ci; p = dW5, Gc */
     PC_OP_TAIL6_BIAS_SUMS,          /* i = N, It, Ih, Iw; p = dout, sums */
     PC_OP_TRANSPOSE_MULTI,          /* p[0] = HOST pointer to pc_transpose_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */

@@ -13,7 +13,7 @@ _ALIAS = "picons_amd"
 _me = sys.modules[__name__]
 sys.modules.setdefault(_ALIAS, _me)
 
-_SUBMODULES = ["spec", "synthetic", "capi", "desc", "ops", "spectral", "plan", "model", "step", "dist"]
+_SUBMODULES = ["spec", "synthetic", "capi", "desc", "ops", "spectral", "tail6", "plan", "model", "step", "dist"]
 
 
 def _load_submodules():

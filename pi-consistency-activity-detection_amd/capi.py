@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds")] + \
-               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride")]
+               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride", "Td", "Hd", "Wd")] + [("doff", i32 * 3)]
 
 
 AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "accum", "in_sr", "in_hi", "in_lo", "out_sr", "out_hi", "out_lo"]

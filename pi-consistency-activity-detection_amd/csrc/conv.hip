@@ -592,6 +592,7 @@ struct WgK {
     int mbase, mend;                 // rows [mbase, mend) of D's channels handled by this launch
     int store;                       // one K slice: plain stores instead of atomics
     int nsplit, dbs, sbs, gbs;       // blockIdx.z = problem * nsplit + K slice; pointers advance by these strides per problem
+    int dlat, Td, Hd, Wd, doff[3];   // dlat: D is a sub-lattice (Tq,Hq,Wq) at doff of a [N][Td][Hd][Wd] tensor instead of dense
 };
 
 template <int BM, int BN, int ABL = 0>
@@ -601,6 +602,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     __shared__ __attribute__((aligned(16))) float Ds[2][BK][BM];
     __shared__ __attribute__((aligned(16))) float Ss[2][BK][BN];
     __shared__ int4 ptab[3][BK];                     // per chunk: n, t0, h0, w0 of its 32 positions
+    __shared__ int drow[3][BK];                      // row of D for each position (sub-lattice launches)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -639,6 +641,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
                 const int tq = m % p.Tq; const int n = m / p.Tq;
                 info = make_int4(n, tq * p.istr[0] + p.ioff0[0], hq * p.istr[1] + p.ioff0[1],
                                  wq * p.istr[2] + p.ioff0[2]);
+                drow[c % 3][tid] = p.dlat ? ((n * p.Td + tq + p.doff[0]) * p.Hd + hq + p.doff[1]) * p.Wd + wq + p.doff[2] : pos;
             }
             ptab[c % 3][tid] = info;
         }
@@ -655,7 +658,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
             const int r = drow0 + DRP * j;
             const int pos = c * BK + r;
             const bool v = mval && pos < p.P;
-            const float* src = v ? Dp + (size_t)pos * p.ldd + m0 + dcol : g_zero16;
+            const float* src = v ? Dp + (size_t)drow[c % 3][r] * p.ldd + m0 + dcol : g_zero16;
             glds16(src, ld + j * 1024);
         }
 #pragma unroll
@@ -743,6 +746,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     PC_CHECK_ARG(d->splitk != -1 || (d->ntap[0] == d->KT && d->ntap[1] == d->KH && d->ntap[2] == d->KW), "pc_conv_wgrad: splitk = -1 (plain stores) needs every tap present");
     PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad: trimmed taps exceed the weight extents");
     k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
+    k.dlat = d->Td > 0; k.Td = d->Td; k.Hd = d->Hd; k.Wd = d->Wd;
+    for (int i = 0; i < 3; ++i) k.doff[i] = d->doff[i];
+    PC_CHECK_ARG(!k.dlat || (int64_t)d->N * d->Td * d->Hd * d->Wd < (1ll << 31), "pc_conv_wgrad: D tensor too large");
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad: position count out of range");
     k.P = (int)P;

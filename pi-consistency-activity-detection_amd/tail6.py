@@ -1,0 +1,53 @@
+"""Host side of the merged decoder tail (csrc/tail6.hip, capsules_ucf101.py:504-509): the per-class descriptors.
+
+Input positions fall into 8 classes z = 4*(it == 0) + 2*(ih == 0) + (iw == 0); every class is a rectangular
+sub-lattice of the [It][Ih][Iw] grid (index 0, or indices 1..I-1, per dimension) and has its own weight matrix."""
+from . import desc as D
+
+SP = 128          # 125 column slots (k5t, k5h, k5w) padded to one 128-wide tile
+
+
+def classes(thw):
+    """-> [(z, start[3], extent[3])] of the non-empty classes."""
+    out = []
+    for z in range(8):
+        first = [(z >> 2) & 1, (z >> 1) & 1, z & 1]
+        start = [0 if f else 1 for f in first]
+        ext = [1 if f else thw[d] - 1 for d, f in enumerate(first)]
+        if min(ext) >= 1:
+            out.append((z, start, ext))
+    return out
+
+
+def _sub(d, start, ext):
+    e = dict(d)
+    e.update(Tq=ext[0], Hq=ext[1], Wq=ext[2], ooff=list(start), ioff0=list(start))
+    return e
+
+
+def conv_descs(N, thw, Ci, ldx):
+    """cols[n][i][:] = x[n][i][:] . W5f[n][z]: [(z, desc)], weights at W5f + z*SP*Ci, per-sample stride 8*SP*Ci."""
+    base = D.conv_fwd(N, thw, Ci, ldx, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, groups=N)
+    base["wgstride"] = 8 * SP * Ci
+    return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
+
+
+def dgrad_descs(N, thw, Ci, lddx, accum):
+    """dx[n][i][:] (+)= dcols[n][i][:] . W5t[n][z]: weights at W5t + z*Ci*SP, per-sample stride 8*Ci*SP."""
+    from . import capi
+    base = D.conv_fwd(N, thw, SP, SP, Ci, lddx, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, flags=capi.F_ACCUM if accum else 0, groups=N)
+    base["wgstride"] = 8 * Ci * SP
+    return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
+
+
+def wgrad_descs(N, thw, Ci, ldx):
+    """dW5[n][z][ci][slot] += sum over the class's positions of x[n][i][ci] * dcols[n][i][slot]: one launch per class with the
+    N clip-passes as batched problems; gradient at dW5 + z*Ci*SP, per-sample stride 8*Ci*SP."""
+    per = thw[0] * thw[1] * thw[2]
+    out = []
+    for z, s, e in classes(thw):
+        d = D.wgrad(1, e, Ci, ldx, thw, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+        d.update(ioff0=list(s), Td=thw[0], Hd=thw[1], Wd=thw[2], doff=list(s),
+                 nbatch=N, dbstride=per * ldx, sbstride=per * SP, gbstride=8 * Ci * SP)
+        out.append((z, d))
+    return out

@@ -592,7 +592,7 @@ def test_collapsed_tail_kernels_vs_torch():
 
 def test_merged_tail_vs_torch():
     """upsample4 -> Dropout3d -> smooth as ONE five-tap stride-2 transposed conv with a single output channel
-    (csrc/tail6.hip): 216-column GEMM + gather forward; scatter + two GEMMs + the map back onto the combined weights
+    (csrc/tail6.hip): 125-column GEMMs over the 8 position classes + gather forward; scatter + two GEMMs + the map back onto the combined weights
     backward; output, input gradient and all four parameter gradients against torch (capsules_ucf101.py:504-509)."""
     g = torch.Generator().manual_seed(14)
     N, Ci, Co, taps, J = 3, 8, 12, 27, 27
@@ -612,33 +612,30 @@ def test_merged_tail_vs_torch():
     W4g, b4g, csg, Wpg, bpg = dev(W4), dev(b4), dev(cs), dev(Wp), dev(bp)
     capi.call("pc_tail_combine", ops.ptr(W4g), ops.ptr(b4g), ops.ptr(csg), ops.ptr(Wpg), N, Ci, Co, taps, J,
               ops.ptr(Wt), ops.ptr(Wf), ops.ptr(bc), ops.stream())
-    C6P = 224
-    W6f = torch.empty(N, C6P, Ci, device=DEV); W6t = torch.empty(N, Ci, C6P, device=DEV)
-    ops.tail6_weights(Wf, N, Ci, W6f, W6t)
+    from picons_amd import tail6
+    SP = tail6.SP
+    W5f = torch.empty(N, 8, SP, Ci, device=DEV); W5t = torch.empty(N, 8, Ci, SP, device=DEV)
+    ops.tail6_weights(Wf, N, Ci, W5f, W5t)
     xg = cl(x)
-    cols = torch.empty(N, *I, C6P, device=DEV)
-    d = desc.conv_fwd(N, I, Ci, Ci, C6P, C6P, (1, 1, 1), (1, 1, 1), (0, 0, 0), I, groups=N)
-    d["wgstride"] = C6P * Ci
-    ops.conv_fwd(d, xg, W6f, cols)
+    cols = torch.full((N, *I, SP), 9.0, device=DEV)
+    for z, d in tail6.conv_descs(N, I, Ci, Ci):
+        ops.conv_fwd(d, xg, W5f.view(-1)[z * SP * Ci:], cols)
     o = torch.empty(N, *[2 * v for v in I], device=DEV)
     ops.tail6_gather(cols, bc, bpg, N, *I, o)
     close(o.cpu(), out[:, 0], what="merged forward")
     # backward
     doutg = dev(dout[:, 0])
-    dcols = torch.empty(N, *I, C6P, device=DEV)
+    dcols = torch.empty(N, *I, SP, device=DEV)
     ops.tail6_scatter(doutg, N, *I, dcols)
-    dx = torch.empty(N, *I, Ci, device=DEV)
-    dd = desc.conv_fwd(N, I, C6P, C6P, Ci, Ci, (1, 1, 1), (1, 1, 1), (0, 0, 0), I, groups=N)
-    dd["wgstride"] = Ci * C6P
-    ops.conv_fwd(dd, dcols, W6t, dx)
+    dx = torch.full((N, *I, Ci), 9.0, device=DEV)
+    for z, d in tail6.dgrad_descs(N, I, Ci, Ci, False):
+        ops.conv_fwd(d, dcols, W5t.view(-1)[z * Ci * SP:], dx)
     close(uncl(dx), x.grad, what="merged dgrad")
-    dW6 = torch.zeros(N, Ci, C6P, device=DEV)
-    per = int(np.prod(I))
-    wd = desc.wgrad(1, I, Ci, Ci, I, C6P, C6P, (1, 1, 1), (1, 1, 1), (0, 0, 0))
-    wd.update(nbatch=N, dbstride=per * Ci, sbstride=per * C6P, gbstride=Ci * C6P)
-    ops.conv_wgrad(wd, xg, dcols, dW6)
+    dW5 = torch.zeros(N, 8, Ci, SP, device=DEV)
+    for z, d in tail6.wgrad_descs(N, I, Ci, Ci):
+        ops.conv_wgrad(d, xg, dcols, dW5.view(-1)[z * Ci * SP:])
     Gc = torch.empty(N, Ci, taps, 32, device=DEV)
-    ops.tail6_wgrad_map(dW6, N, Ci, Gc)
+    ops.tail6_wgrad_map(dW5, N, Ci, Gc)
     sums = torch.empty(N, 32, device=DEV)
     ops.tail6_bias_sums(doutg, N, *I, sums)
     dproj = ops.tapsum_bwd(doutg)

@@ -48,7 +48,7 @@ def test_regions_balanced_and_private(lanes):
         lst = p.lists[name]
         regs = _regions(lst)
         if name in ("fwd", "bwd"):
-            assert len(regs) == 7, "one region per Inception module (Mixed_3b..4f)"
+            assert len(regs) == 8, "one region per Inception module (Mixed_3b..4f) + the merged tail's position classes"
         elif name == "prep":
             assert len(regs) == 1, "weight-layout prep: one region"
         else:
@@ -62,6 +62,11 @@ def test_regions_balanced_and_private(lanes):
                 for q, r in enumerate(ptrs):
                     if r is None:
                         continue
+                    if kind == capi.OP_CONV and q == 4:
+                        # a conv writes the sub-lattice (ooff, extents) of its output tensor: the merged tail's position classes
+                        # tile one buffer with disjoint sub-lattices on two lanes
+                        i = op[1]
+                        r = (r, tuple(i[6:9]), tuple(i[17:20]))
                     touched[r].add(lane)
                     if q in WRITES[kind]:
                         written[r].add(lane)

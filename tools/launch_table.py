@@ -16,7 +16,7 @@ from picons_amd.plan import Plan  # noqa: E402
 
 PEAK = 157.3e9      # FLOP per ms
 
-VEC = ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")
+VEC = ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep", "doff")
 
 
 def unflat(i, fields):
