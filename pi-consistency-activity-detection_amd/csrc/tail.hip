@@ -62,41 +62,61 @@ __global__ __launch_bounds__(256) void tail_colsum_kernel(const float* __restric
 }
 
 // dW4[ci][co][tap] (+)= sum_n sum_j G[n][ci][tap][j] * cs[n][co] * Wp[co][j]
-__global__ __launch_bounds__(256) void tail_dw4_kernel(const float* __restrict__ G, const float* __restrict__ cs, const float* __restrict__ Wp,
+// Block = one (ci, tap): the N x 32 slab G[:, ci, tap, :] sits in LDS (every thread reads the same element: broadcast),
+// thread co keeps its row of Wp in registers.
+constexpr int DW4_MAXN = 64;
+__global__ __launch_bounds__(128) void tail_dw4_kernel(const float* __restrict__ G, const float* __restrict__ cs, const float* __restrict__ Wp,
                                                        int N, int Ci, int Co, int taps, int J, float* __restrict__ dW4, int accum) {
-    const int64_t total = (int64_t)Ci * Co * taps;
-    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
-        const int tap = (int)(idx % taps); int64_t r = idx / taps;
-        const int co = (int)(r % Co); const int ci = (int)(r / Co);
+    __shared__ float g[DW4_MAXN][J32];
+    const int ci = blockIdx.x / taps, tap = blockIdx.x - ci * taps;
+    for (int e = threadIdx.x; e < N * J32; e += 128) g[e >> 5][e & 31] = G[(((size_t)(e >> 5) * Ci + ci) * taps + tap) * J32 + (e & 31)];
+    __syncthreads();
+    for (int co = threadIdx.x; co < Co; co += 128) {
+        float wp[J32];
+#pragma unroll
+        for (int j = 0; j < J32; ++j) wp[j] = j < J ? Wp[co * J + j] : 0.f;
         float acc = 0.f;
         for (int n = 0; n < N; ++n) {
-            const float sc = cs ? cs[n * Co + co] : 1.f;
-            const float* g = G + (((size_t)n * Ci + ci) * taps + tap) * J32;
             float a = 0.f;
-            for (int j = 0; j < J; ++j) a += g[j] * Wp[co * J + j];
-            acc += sc * a;
+#pragma unroll
+            for (int j = 0; j < J32; ++j) a += g[n][j] * wp[j];
+            acc += (cs ? cs[n * Co + co] : 1.f) * a;
         }
+        const size_t idx = ((size_t)ci * Co + co) * taps + tap;
         dW4[idx] = (accum ? dW4[idx] : 0.f) + acc;
     }
 }
 
-// dWp[co][j] += cs[n][co] * sum_{ci,tap} W4[ci][co][tap] * G[n][ci][tap][j]     (grid Co x N, atomics over n)
+// dWp[co][j] += cs[n][co] * sum_{ci,tap} W4[ci][co][tap] * G[n][ci][tap][j]
+// Block = (sample n, 8 input channels): its 8 x taps x 32 slab of G sits in LDS; thread (co, half) accumulates 16 of the 32
+// columns over the slab, then one atomic per element (N * Ci/8 adds per element).
+constexpr int DWP_CI = 8;
 __global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__ G, const float* __restrict__ W4, const float* __restrict__ cs,
                                                        int Ci, int Co, int taps, int J, float* __restrict__ dWp) {
-    __shared__ float sh[8][32];
-    const int co = blockIdx.x, n = blockIdx.y, j = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int per_n = Ci * taps;
-    float a = 0.f;
-    for (int e = sl; e < per_n; e += 8) {
-        const int ci = e / taps, tap = e - ci * taps;
-        a += W4[((size_t)ci * Co + co) * taps + tap] * G[(((size_t)n * Ci + ci) * taps + tap) * J32 + j];
-    }
-    sh[sl][j] = a;
+    extern __shared__ float gs[];                       // [DWP_CI * taps][32]
+    const int n = blockIdx.y, ci0 = blockIdx.x * DWP_CI;
+    const int rows = DWP_CI * taps;
+    const float* gsrc = G + ((size_t)n * Ci + ci0) * taps * J32;
+    for (int e = threadIdx.x; e < rows * J32; e += 256) gs[e] = gsrc[e];
     __syncthreads();
-    if (sl == 0 && j < J) {
-        float t = 0.f;
-        for (int q = 0; q < 8; ++q) t += sh[q][j];
-        atomicAdd(dWp + co * J + j, (cs ? cs[n * Co + co] : 1.f) * t);
+    const int half = threadIdx.x & 1;
+    for (int co = threadIdx.x >> 1; co < Co; co += 128) {
+        float acc[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+        for (int r = 0; r < rows; ++r) {
+            const int ci = ci0 + r / taps, tap = r - (r / taps) * taps;
+            const float w = W4[((size_t)ci * Co + co) * taps + tap];
+            const float* gr = gs + r * J32 + half * 16;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[q] += w * gr[q];
+        }
+        const float sc = cs ? cs[n * Co + co] : 1.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int j = half * 16 + q;
+            if (j < J) atomicAdd(dWp + co * J + j, sc * acc[q]);
+        }
     }
 }
 
@@ -147,11 +167,10 @@ extern "C" int pc_tail_grads(const float* G, const float* sums, const float* W4,
                              int Ci, int Co, int taps, int J, int center, float* dW4, float* db4, float* dWp, float* dbp, int accum, pc_stream s_) {
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(G && sums && W4 && b4 && Wp && dW4 && db4 && dWp && dbp && J <= J32, "pc_tail_grads: bad args");
-    const int64_t total = (int64_t)Ci * Co * taps;
-    int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(tail_dw4_kernel, dim3(grid), dim3(256), 0, s, G, cs, Wp, N, Ci, Co, taps, J, dW4, accum);
+    PC_CHECK_ARG(N <= DW4_MAXN && Ci % DWP_CI == 0, "pc_tail_grads: N <= %d and Ci %% %d == 0 expected (N=%d Ci=%d)", DW4_MAXN, DWP_CI, N, Ci);
+    hipLaunchKernelGGL(tail_dw4_kernel, dim3(Ci * taps), dim3(128), 0, s, G, cs, Wp, N, Ci, Co, taps, J, dW4, accum);
     if (!accum) (void)hipMemsetAsync(dWp, 0, sizeof(float) * Co * J, s);
-    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Co, N), dim3(256), 0, s, G, W4, cs, Ci, Co, taps, J, dWp);
+    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Ci / DWP_CI, N), dim3(256), (size_t)DWP_CI * taps * J32 * 4, s, G, W4, cs, Ci, Co, taps, J, dWp);
     hipLaunchKernelGGL(tail_dbias_kernel, dim3(Co), dim3(64), 0, s, sums, b4, cs, Wp, N, Co, J, center, dWp, db4, dbp, accum);
     PC_CHECK_LAUNCH("tail_grads");
     return PC_OK;
