@@ -40,7 +40,8 @@ typedef void* pc_stream;            /* hipStream_t */
 #define PC_F_BNPART  8              /* emit per-block BatchNorm partial sums (sum, sumsq) */
 #define PC_F_NFAST   16             /* GEMM rows ordered (t,h,w,n) instead of (n,t,h,w): a 128-row tile is a narrow spatial
                                        patch of all samples, so taps that are padding for the whole tile are skipped
-                                       (9x9 ConvTranspose / PrimaryCaps dgrad: 784 gathered vs 400 real positions) */
+                                       (9x9 ConvTranspose / PrimaryCaps dgrad: 784 gathered vs 400 real positions); with groups the
+                                       order holds inside each group */
 
 int         pc_version(void);
 const char* pc_last_error(void);

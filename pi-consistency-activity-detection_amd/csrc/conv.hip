@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
         if (lm < p.Mg) {
             int m = g * p.Mg + lm;
             int n = 0;
-            if (p.flags & PC_F_NFAST) { n = m % p.N; m /= p.N; }
+            if (p.flags & PC_F_NFAST) { const int ng = p.N / p.groups; n = g * ng + lm % ng; m = lm / ng; }   // sample fastest within the group
             const int wq = m % p.Wq; m /= p.Wq;
             const int hq = m % p.Hq; m /= p.Hq;
             const int tq = m % p.Tq;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         if (lm < p.Mg) {
             int m = g * p.Mg + lm;
             int n = 0;
-            if (p.flags & PC_F_NFAST) { n = m % p.N; m /= p.N; }
+            if (p.flags & PC_F_NFAST) { const int ng = p.N / p.groups; n = g * ng + lm % ng; m = lm / ng; }   // sample fastest within the group
             const int wq = m % p.Wq; m /= p.Wq;
             const int hq = m % p.Hq; m /= p.Hq;
             const int tq = m % p.Tq;
@@ -537,7 +537,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     PC_CHECK_ARG(!(d->flags & PC_F_BIAS) || bias, "pc_conv_fwd: bias flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_CSCALE) || cscale, "pc_conv_fwd: cscale flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_BNPART) || bnpart, "pc_conv_fwd: bnpart flag without pointer");
-    PC_CHECK_ARG(!(d->flags & PC_F_NFAST) || (groups == 1 && !(d->flags & (PC_F_BNPART | PC_F_CSCALE))), "pc_conv_fwd: NFAST needs groups == 1 and no BN partials / cscale");
+    PC_CHECK_ARG(!(d->flags & PC_F_NFAST) || !(d->flags & (PC_F_BNPART | PC_F_CSCALE)), "pc_conv_fwd: NFAST cannot be combined with BN partials / cscale");
     PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)w % 16 == 0), "pc_conv_fwd: in/w must be 16-byte aligned");
     ConvK k;
     k.in = in; k.w = w; k.bias = bias; k.cscale = cscale; k.out = out; k.bnpart = bnpart;
@@ -563,7 +563,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     if (d->flags & PC_F_NFAST) {
         // n-fastest rows: a tile should hold whole groups of N samples of consecutive w so its tap box is tight;
         // when Wq*N is not a multiple of 128 use 64-row tiles (28 w x 16 samples = 7 tiles of 64, none straddles a row)
-        const long long per_row = (long long)d->Wq * d->N;
+        const long long per_row = (long long)d->Wq * (d->N / groups);
         if (per_row % 128 != 0 && per_row % 64 == 0) { c.bm = 64; c.bn = d->Co >= 128 ? 128 : 64; c.wm = d->Co >= 128 ? 1 : 2; }
     }
     if (c.bm == 64 && c.bn == 128) return launch_conv<64, 128, 1, 4>(k, s);

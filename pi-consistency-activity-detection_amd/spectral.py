@@ -129,8 +129,10 @@ class Layout:
         return d
 
     def dgrad(self):
+        # sample-fastest row order inside each group: a 64-row tile is 4 rows of y for all samples, so the taps that only
+        # reach the zero padding of the 'full' correlation (H rows gathered from OH real ones) are skipped per tile
         out = D.transposed_classes(self.G * self.N, (1, self.OH, 1), self.Co, self.Co, (1, self.H, 1), self.Ci, self.Ci,
-                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G, ldw=self.Co)
+                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G, ldw=self.Co, flags=capi.F_NFAST)
         for d in out:
             d["wgstride"] = self.w_g
         return out
@@ -182,7 +184,7 @@ class LayoutT:
 
     def convT(self):
         out = D.transposed_classes(self.G * self.N, (1, self.H, 1), self.Ci, self.Ci, (1, self.OH, 1), self.Co, self.Co,
-                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G)
+                                   (1, self.KY, 1), (1, 1, 1), (0, 0, 0), groups=self.G, flags=capi.F_NFAST)
         for d in out:
             d["wgstride"] = self.w_g
         return out
