@@ -94,11 +94,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 struct RedP {
     const float* a; int lda; const float* b; int ldb; const float* stat; int C4; int64_t rows, rows_per_group;
     int64_t rows_per_block; int act; float* part;   // part [nblk][2][C]
+    int64_t a_gs, b_gs, stat_gs, part_gs;           // blockIdx.y = batch group: element strides of a, b, stat, part (0 for one group)
 };
 
 template <int MODE>
-__global__ __launch_bounds__(256) void colreduce_kernel(const RedP p) {
+__global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
     __shared__ float sh[256 * 8];
+    p.a += blockIdx.y * p.a_gs; p.b += blockIdx.y * p.b_gs; p.stat += blockIdx.y * p.stat_gs; p.part += blockIdx.y * p.part_gs;
     const int C4 = p.C4, C = C4 * 4;
     const int rpi = 256 / C4;                       // rows per iteration
     const int c4 = threadIdx.x % C4, rl = threadIdx.x / C4;
@@ -483,12 +485,13 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
     const int npg = (int)((rpg + rpb - 1) / rpb);
     float* part = ws;
     float* coef = ws + (size_t)npg * groups * 2 * C;
-    for (int g = 0; g < groups; ++g) {   // one launch per group keeps block row ranges inside the group
+    {   // blockIdx.y = group keeps block row ranges inside the group
         RedP p;
-        p.a = dy + (size_t)g * rpg * lddy; p.lda = lddy; p.b = z + (size_t)g * rpg * ldz; p.ldb = ldz;
-        p.stat = stat + (size_t)g * 4 * C; p.C4 = C / 4; p.rows = rpg; p.rows_per_group = rpg; p.rows_per_block = rpb;
-        p.act = relu ? PC_ACT_RELU : PC_ACT_NONE; p.part = part + (size_t)g * npg * 2 * C;
-        hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg), dim3(256), 0, s, p);
+        p.a = dy; p.lda = lddy; p.b = z; p.ldb = ldz;
+        p.stat = stat; p.C4 = C / 4; p.rows = rpg; p.rows_per_group = rpg; p.rows_per_block = rpb;
+        p.act = relu ? PC_ACT_RELU : PC_ACT_NONE; p.part = part;
+        p.a_gs = rpg * lddy; p.b_gs = rpg * ldz; p.stat_gs = 4 * C; p.part_gs = (int64_t)npg * 2 * C;
+        hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg, groups), dim3(256), 0, s, p);
     }
     PC_CHECK_LAUNCH("bn_bwd reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
@@ -540,6 +543,7 @@ extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, in
         RedP p;
         p.a = dy; p.lda = lddy; p.b = y; p.ldb = ldy; p.stat = nullptr; p.C4 = C / 4; p.rows = rows; p.rows_per_group = rows;
         p.rows_per_block = rpb; p.act = act; p.part = ws;
+        p.a_gs = p.b_gs = p.stat_gs = p.part_gs = 0;
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 0, s, p);
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, nblk, C, dbias, accum);
     }
