@@ -223,10 +223,25 @@ class Plan:
 
     def flush_grad(self, w):
         """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
-        wgrad so a gradient bucket is final (all-reduce can start) as early as possible."""
-        for nm, op in w["unprep"]:
-            self.lists[self.cur].append(op + (self.lane,))
-            self.mark_final(nm)
+        wgrad's layer (flush_unprep, after every layer / Inception module of the backward) so a gradient bucket is final
+        (all-reduce can start) as early as possible."""
+        self._pending_unprep = getattr(self, "_pending_unprep", [])
+        self._pending_unprep.extend(w["unprep"])
+
+    def flush_unprep(self):
+        """Emit the pending kernel-layout -> reference-layout gradient transposes (several weights of an Inception module
+        as ONE multi-job launch) and mark those parameters final."""
+        pend = getattr(self, "_pending_unprep", [])
+        if not pend:
+            return
+        if len(pend) == 1:
+            self.lists[self.cur].append(pend[0][1] + (self.lane,))
+        else:
+            self.multi_jobs = getattr(self, "multi_jobs", [])
+            self.multi_jobs.append([op for _nm, op in pend])
+            self.lists[self.cur].append((capi.OP_TRANSPOSE_MULTI, [len(pend)], [], [("JOBS", len(self.multi_jobs) - 1)], [], self.lane))
+        self.mark_final(*[nm for nm, _op in pend])
+        self._pending_unprep = []
 
     def mark_final(self, *names):
         for nm in names:
@@ -743,6 +758,7 @@ class Plan:
         self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
         for fn in reversed(self.tape):
             fn()
+            self.flush_unprep()
 
     def grad_buckets(self, target_floats=12_000_000):
         """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the
@@ -808,9 +824,22 @@ class Plan:
                 arr[j]["f"][:len(f)] = f
                 arr[j]["l"][:len(l)] = l
                 for q, r in enumerate(p):
+                    if r is not None and r[0] == "JOBS":
+                        tab = self._job_table(self.multi_jobs[r[1]], bases)
+                        keep.append(tab)
+                        r = ("HOST", tab.ctypes.data)
                     arr[j]["p"][q] = 0 if r is None else (r[1] if r[0] == "HOST" else bases[r[0]] + r[1])
             out[name] = arr
         return out
+
+    @staticmethod
+    def _job_table(jobs, bases):
+        """OP_TRANSPOSE tuples -> host array of pc_transpose_job with absolute pointers."""
+        tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
+        for q, op in enumerate(jobs):
+            _kind, i, _f, p, l = op[:5]
+            tab[q] = (bases[p[0][0]] + p[0][1], bases[p[1][0]] + p[1][1], l[0], l[1], i[0], i[1], i[2], i[3], i[4], i[5])
+        return tab
 
     def _merge_prep_transposes(self, lst, bases, keep):
         """The weight re-layouts that read master parameters are independent of each other: all of them on one lane
@@ -820,9 +849,7 @@ class Plan:
         def flush():
             for lane in sorted(pending):
                 jobs = pending[lane]
-                tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
-                for q, (kind, i, f, p, l, _ln) in enumerate(jobs):
-                    tab[q] = (bases[p[0][0]] + p[0][1], bases[p[1][0]] + p[1][1], l[0], l[1], i[0], i[1], i[2], i[3], i[4], i[5])
+                tab = self._job_table(jobs, bases)
                 keep.append(tab)
                 res.append((capi.OP_TRANSPOSE_MULTI, [len(jobs)], [], [("HOST", tab.ctypes.data)], [], lane))
             pending.clear()

@@ -121,8 +121,11 @@ def test_prep_list_is_spread_over_lanes_at_resolve():
     multi = arrs["prep"][[k == capi.OP_TRANSPOSE_MULTI for k in kinds]]
     assert sorted(int(x) for x in multi["lane"]) == [0, 1]
     n_par = sum(1 for op in lst[f + 1:j] if op[0] == capi.OP_TRANSPOSE)
-    assert int(multi["i"][:, 0].sum()) == n_par and sum(len(t) for t in arrs["_tjobs"]) == n_par
-    assert {int(multi["p"][q, 0]) for q in range(2)} == {t.ctypes.data for t in arrs["_tjobs"]}
+    by_ptr = {t.ctypes.data: t for t in arrs["_tjobs"]}
+    assert int(multi["i"][:, 0].sum()) == n_par and sum(len(by_ptr[int(multi["p"][q, 0])]) for q in range(2)) == n_par
+    # the backward's per-module gradient re-layouts are multi-job launches too, every table is owned by the resolved dict
+    bk = arrs["bwd"][arrs["bwd"]["kind"] == capi.OP_TRANSPOSE_MULTI]
+    assert len(bk) >= 7 and all(int(x) in by_ptr and len(by_ptr[int(x)]) == int(n) for x, n in zip(bk["p"][:, 0], bk["i"][:, 0]))
     # idempotent
     p.resolve({"A": 1 << 20, "P": 1 << 30, "G": 1 << 31, "M": 1 << 32, "V": 1 << 33, "R": 1 << 34})
     assert len(p.lists["prep"]) == len(lst)
