@@ -253,8 +253,8 @@ int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
  * is a 9x1 conv with complex channels per frequency u = 0..P/2.  The complex product is taken in its
  * three-multiplication form (X = Xr + i Xi, conj(W) = Wr - i Wi):
  *     t0 = (Xr + Xi) Wr,  t1 = Xi (Wr - Wi),  t2 = Xr (Wr + Wi);   Re = t0 - t1,  Im = t0 - t2,
- * so the whole layer is ONE grouped real conv for pc_conv_fwd / pc_conv_wgrad (3 groups per frequency,
- * Ci -> Co, 9x1 taps): a quarter of the direct form's multiply-adds, equal to it in exact arithmetic.
+ * so the whole layer is ONE grouped real conv for pc_conv_fwd / pc_conv_wgrad (3 groups per complex frequency,
+ * 1 for DC / Nyquist; Ci -> Co, 9x1 taps): a quarter of the direct form's multiply-adds, equal to it in exact arithmetic.
  * The sums/differences of the operands and results are folded into the DFT matrices.  These three
  * HBM-bound helpers are the rest of it. */
 /* out[r][o][c] = sum_i M[o][i] * in[r][i][c] (+ bias[c]; activation on channels >= act_c0; accum adds
@@ -267,13 +267,15 @@ typedef struct pc_axis_desc {
     int32_t in_sr, in_hi, in_lo, out_sr, out_hi, out_lo;
 } pc_axis_desc;
 int pc_axis_linear(const pc_axis_desc* d, const float* in, const float* M, const float* bias, float* out, pc_stream s);
-/* weights in a kernel layout in[A][KY*KX][B] -> the three weight planes per frequency out[U][3][A][KY][B]:
+/* weights in a kernel layout in[A][KY*KX][B] -> weight planes [A][KY][B]: three per complex frequency,
  *   V0 = Wr, V1 = Wr - Wi, V2 = Wr + Wi,  Wr = sum_kx in*tw[u][kx][0], Wi = sum_kx in*tw[u][kx][1]
- * (tw = cos, -sin of 2*pi*u*kx/P).  in = [Co][taps][Ci] gives the forward GEMM weights, in = [Ci][taps][Co]
- * the dgrad GEMM weights. */
-int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, float* out, pc_stream s);
-/* adjoint: kg[a][ky*KX+kx][b] = sum_u tw[u][kx][0]*(d0+d1+d2) + tw[u][kx][1]*(d2-d1), dV = [U][3][A][KY][B] */
-int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, float* kg, pc_stream s);
+ * (tw = cos, -sin of 2*pi*u*kx/P), followed by ONE plane (Wr) for each of the Ur trailing frequencies of tw whose spectrum
+ * is real (DC and, for even P, Nyquist: X and W have no imaginary part there, so one real product is the whole term).
+ * in = [Co][taps][Ci] gives the forward GEMM weights, in = [Ci][taps][Co] the dgrad GEMM weights. */
+int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int Ur, float* out, pc_stream s);
+/* adjoint: kg[a][ky*KX+kx][b] = sum_u tw[u][kx][0]*(d0+d1+d2) + tw[u][kx][1]*(d2-d1) over the complex frequencies plus
+ * tw[u][kx][0]*d0 over the real ones; dV in the plane order of pc_wspec_fwd */
+int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, int Ur, float* kg, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * Merged decoder tail (capsules_ucf101.py:504-509).  upsample4 -> Dropout3d -> smooth composes, per dimension, into one
@@ -314,8 +316,8 @@ enum {
     PC_OP_CMASK_BWD, PC_OP_TAPSUM_FWD, PC_OP_TAPSUM_BWD, PC_OP_LOSS, PC_OP_SPREAD, PC_OP_ADAM,
     PC_OP_TAIL_COMBINE, PC_OP_TAIL_COLSUM, PC_OP_TAIL_GRADS, PC_OP_COL2IM,
     PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
-    PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U; p = in, tw, out */
-    PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U; p = dV, tw, kg */
+    PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U, Ur; p = in, tw, out */
+    PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U, Ur; p = dV, tw, kg */
     PC_OP_TAIL6_WEIGHTS,            /* i = N, Ci; p = wf, W5f, W5t */
     PC_OP_TAIL6_GATHER,             /* i = N, It, Ih, Iw; p = cols, bc, bsm, out */
     PC_OP_TAIL6_SCATTER,            /* i = N, It, Ih, Iw; p = dout, dcols */

@@ -97,8 +97,8 @@ _SIGS = {
     "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
     "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
     "pc_axis_linear": (i32, [vp, vp, vp, vp, vp, vp]),
-    "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
-    "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_tail6_weights": (i32, [vp, i32, i32, vp, vp, vp]),
     "pc_tail6_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "pc_tail6_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp]),

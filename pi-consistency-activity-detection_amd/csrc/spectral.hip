@@ -66,10 +66,11 @@ __global__ __launch_bounds__(256) void axis_linear_kernel(const AxK p) {
 
 constexpr int WS_MAXK = 16;     // tap counts 1..16 are instantiated (the tap arrays must stay in registers)
 
-// in [A][KY*KX][B] -> out [U][3][A][KY][B]: V0 = Wr, V1 = Wr - Wi, V2 = Wr + Wi
+// in [A][KY*KX][B] -> planes [A][KY][B]: three per complex frequency (V0 = Wr, V1 = Wr - Wi, V2 = Wr + Wi), then ONE (Wr)
+// for each of the Ur trailing frequencies whose spectrum is real (DC, Nyquist)
 template <int KX>
 __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict__ in, const float* __restrict__ tw, int A, int B4, int KY,
-                                                         int U, float* __restrict__ out) {
+                                                         int U, int Ur, float* __restrict__ out) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)A * KY * B4) return;
     const int b = (int)(idx % B4) * 4;
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict_
             wr.x += c * v[kx].x; wr.y += c * v[kx].y; wr.z += c * v[kx].z; wr.w += c * v[kx].w;
             wi.x += s * v[kx].x; wi.y += s * v[kx].y; wi.z += s * v[kx].z; wi.w += s * v[kx].w;
         }
+        if (u >= U - Ur) { *(float4*)(o + (int64_t)(3 * (U - Ur) + u - (U - Ur)) * plane) = wr; continue; }
         float* ou = o + (int64_t)u * 3 * plane;
         *(float4*)ou = wr;
         *(float4*)(ou + plane) = make_float4(wr.x - wi.x, wr.y - wi.y, wr.z - wi.z, wr.w - wi.w);
@@ -96,10 +98,10 @@ __global__ __launch_bounds__(256) void wspec_fwd_kernel(const float* __restrict_
     }
 }
 
-// dV [U][3][A][KY][B] -> kg [A][KY*KX][B]:  dWr = d0 + d1 + d2, dWi = d2 - d1
+// plane gradients (same order) -> kg [A][KY*KX][B]:  dWr = d0 + d1 + d2, dWi = d2 - d1  (real frequencies: dWr = d0)
 template <int KX>
 __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ tw, int A, int B4, int KY,
-                                                         int U, float* __restrict__ kg) {
+                                                         int U, int Ur, float* __restrict__ kg) {
     const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (idx >= (int64_t)A * KY * B4) return;
     const int b = (int)(idx % B4) * 4;
@@ -111,8 +113,16 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
     for (int kx = 0; kx < KX; ++kx) acc[kx] = make_float4(0.f, 0.f, 0.f, 0.f);
     const int64_t plane = (int64_t)A * KY * B;
     const float* d = dV + ((int64_t)a * KY + ky) * B + b;
+    for (int u = U - Ur; u < U; ++u) {
+        const float4 d0 = *(const float4*)(d + (int64_t)(3 * (U - Ur) + u - (U - Ur)) * plane);
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) {
+            const float c = tw[(u * KX + kx) * 2];
+            acc[kx].x += c * d0.x; acc[kx].y += c * d0.y; acc[kx].z += c * d0.z; acc[kx].w += c * d0.w;
+        }
+    }
 #pragma unroll 5
-    for (int u = 0; u < U; ++u) {
+    for (int u = 0; u < U - Ur; ++u) {
         const float* du = d + (int64_t)u * 3 * plane;
         const float4 d0 = *(const float4*)du, d1 = *(const float4*)(du + plane), d2 = *(const float4*)(du + 2 * plane);
         const float4 gr = make_float4(d0.x + d1.x + d2.x, d0.y + d1.y + d2.y, d0.z + d1.z + d2.z, d0.w + d1.w + d2.w);
@@ -151,19 +161,19 @@ extern "C" int pc_axis_linear(const pc_axis_desc* d, const float* in, const floa
     return PC_OK;
 }
 
-static int wspec_check(const void* a, const void* b, const void* c, int A, int B, int KY, int KX, int U, const char* who) {
+static int wspec_check(const void* a, const void* b, const void* c, int A, int B, int KY, int KX, int U, int Ur, const char* who) {
     PC_CHECK_ARG(a && b && c, "%s: null pointer", who);
-    PC_CHECK_ARG(A > 0 && B > 0 && B % 4 == 0 && KY > 0 && KX > 0 && KX <= WS_MAXK && U > 0, "%s: bad extents (A=%d B=%d KY=%d KX=%d U=%d)", who, A, B, KY, KX, U);
+    PC_CHECK_ARG(A > 0 && B > 0 && B % 4 == 0 && KY > 0 && KX > 0 && KX <= WS_MAXK && U > 0 && Ur >= 0 && Ur <= U, "%s: bad extents (A=%d B=%d KY=%d KX=%d U=%d Ur=%d)", who, A, B, KY, KX, U, Ur);
     PC_CHECK_ARG(((uintptr_t)a % 16 == 0) && ((uintptr_t)c % 16 == 0), "%s: 16-byte alignment", who);
     return PC_OK;
 }
 
-extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, float* out, pc_stream s_) {
-    const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, "pc_wspec_fwd");
+extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX, int U, int Ur, float* out, pc_stream s_) {
+    const int rc = wspec_check(in, tw, out, A, B, KY, KX, U, Ur, "pc_wspec_fwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
     const dim3 grid((unsigned)cdiv(n, 256));
-#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_fwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, U, out); break;
+#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_fwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, in, tw, A, B / 4, KY, U, Ur, out); break;
     switch (KX) { WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11)
                   WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(15) WS_CASE(16) }
 #undef WS_CASE
@@ -171,12 +181,12 @@ extern "C" int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int 
     return PC_OK;
 }
 
-extern "C" int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, float* kg, pc_stream s_) {
-    const int rc = wspec_check(dV, tw, kg, A, B, KY, KX, U, "pc_wspec_bwd");
+extern "C" int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, int Ur, float* kg, pc_stream s_) {
+    const int rc = wspec_check(dV, tw, kg, A, B, KY, KX, U, Ur, "pc_wspec_bwd");
     if (rc != PC_OK) return rc;
     const int64_t n = (int64_t)A * KY * (B / 4);
     const dim3 grid((unsigned)cdiv(n, 256));
-#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_bwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, dV, tw, A, B / 4, KY, U, kg); break;
+#define WS_CASE(K) case K: hipLaunchKernelGGL(wspec_bwd_kernel<K>, grid, dim3(256), 0, (hipStream_t)s_, dV, tw, A, B / 4, KY, U, Ur, kg); break;
     switch (KX) { WS_CASE(1) WS_CASE(2) WS_CASE(3) WS_CASE(4) WS_CASE(5) WS_CASE(6) WS_CASE(7) WS_CASE(8) WS_CASE(9) WS_CASE(10) WS_CASE(11)
                   WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(15) WS_CASE(16) }
 #undef WS_CASE

@@ -214,13 +214,13 @@ def axis_linear(d, x, M, out, bias=None):
     return out
 
 
-def wspec_fwd(w, tw, A, B, KY, KX, U, out):
-    capi.call("pc_wspec_fwd", ptr(w), ptr(tw), A, B, KY, KX, U, ptr(out), stream())
+def wspec_fwd(w, tw, A, B, KY, KX, U, Ur, out):
+    capi.call("pc_wspec_fwd", ptr(w), ptr(tw), A, B, KY, KX, U, Ur, ptr(out), stream())
     return out
 
 
-def wspec_bwd(dV, tw, A, B, KY, KX, U, kg):
-    capi.call("pc_wspec_bwd", ptr(dV), ptr(tw), A, B, KY, KX, U, ptr(kg), stream())
+def wspec_bwd(dV, tw, A, B, KY, KX, U, Ur, kg):
+    capi.call("pc_wspec_bwd", ptr(dV), ptr(tw), A, B, KY, KX, U, Ur, ptr(kg), stream())
     return kg
 
 

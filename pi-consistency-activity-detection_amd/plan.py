@@ -443,8 +443,8 @@ class Plan:
         sm = {kk: self.const(v) for kk, v in SL.matrices().items()}
         w["wv"] = self.alloc(SL.G * SL.w_g)                  # [g][Co][ky][Ci]  forward (transposed-form) GEMM weight planes
         w["wvt"] = self.alloc(SL.G * SL.w_g)                 # [g][Ci][ky][Co]  dgrad GEMM weight planes
-        self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu], p=[w["fwd"], sm["tw"], w["wv"]], lst="prep")
-        self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu], p=[w["tr"], sm["tw"], w["wvt"]], lst="prep")
+        self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu, SL.Ur], p=[w["fwd"], sm["tw"], w["wv"]], lst="prep")
+        self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[w["tr"], sm["tw"], w["wvt"]], lst="prep")
         xpl = self.alloc(SL.G * SL.x_g)
         tpl = self.alloc(SL.G * SL.t_g)
         self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_planes(), capi.AXIS_FIELDS), p=[x.ref, sm["F"], None, xpl])
@@ -463,7 +463,7 @@ class Plan:
             dwv = self.alloc(SL.G * SL.w_g)
             self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dz.ld), capi.AXIS_FIELDS), p=[dz.ref, sm["Gt"], None, dtpl])
             self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[xpl, dtpl, dwv])
-            self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu], p=[dwv, sm["tw"], w["kg"]])
+            self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[dwv, sm["tw"], w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
@@ -535,8 +535,8 @@ class Plan:
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
             wpc["wv"] = self.alloc(SL.G * SL.w_g)               # [g][Co][ky][Ci]  forward GEMM weight planes
             wpc["wvt"] = self.alloc(SL.G * SL.w_g)              # [g][Ci][ky][Co]  dgrad GEMM weight planes
-            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu], p=[wpc["fwd"], sm["tw"], wpc["wv"]], lst="prep")
-            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu], p=[wpc["tr"], sm["tw"], wpc["wvt"]], lst="prep")
+            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[wpc["fwd"], sm["tw"], wpc["wv"]], lst="prep")
+            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu, SL.Ur], p=[wpc["tr"], sm["tw"], wpc["wvt"]], lst="prep")
         else:
             wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
             self.emit(capi.OP_TRANSPOSE, i=[1, Cpc, KP * KP * xd.C, KP * KP * xd.C, Cpc, 0], l=[0, 0],
@@ -589,7 +589,7 @@ class Plan:
                 dwv = self.alloc(SL.G * SL.w_g)
                 self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dtpl])
                 self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dtpl, xpl, dwv])
-                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu], p=[dwv, sm["tw"], wpc["kg"]])
+                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[dwv, sm["tw"], wpc["kg"]])
             else:
                 self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
                           p=[dcaps.ref, xd.ref, wpc["kg"]])

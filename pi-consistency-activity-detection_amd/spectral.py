@@ -7,9 +7,9 @@ product is taken with three real multiplications (X = Xr + i Xi, conj(W) = Wr - 
 
     t0 = (Xr + Xi) Wr,   t1 = Xi (Wr - Wi),   t2 = Xr (Wr + Wi);     Re Y = t0 - t1,   Im Y = t0 - t2
 
-so the layer is ONE grouped real conv, 3 groups per frequency, Ci -> Co channels, 9x1 taps: 15*3*9 = 405 real
-multiply-adds per (ci, co, output row) instead of 81*20 = 1620 -- a quarter of the direct form's FLOPs, equal to it in
-exact arithmetic.  The operand sums (Xr + Xi) and the result differences are folded into the DFT / inverse-DFT
+so the layer is ONE grouped real conv, 3 groups per complex frequency and 1 for DC / Nyquist (where everything is real),
+Ci -> Co channels, 9x1 taps: (13*3 + 2)*9 = 369 real multiply-adds per (ci, co, output row) instead of 81*20 = 1620 -- under
+a quarter of the direct form's FLOPs, equal to it in exact arithmetic.  The operand sums (Xr + Xi) and the result differences are folded into the DFT / inverse-DFT
 matrices, so backward needs nothing but their transposes.  The GEMMs are the ordinary conv / wgrad kernels; the DFTs,
 the weight planes and their adjoint are the three small kernels of csrc/spectral.hip.
 
@@ -57,22 +57,43 @@ def idft_matrix(P, OW):
     return G
 
 
-def matrices(P, KX):
-    """-> dict of float32 arrays for the three-multiplication form (planes j = 0,1,2 per frequency):
-    F  [3nu][P]  x -> (Xr + Xi, Xi, Xr);      Ft = F^T   (dX planes -> dx)
-    G  [OW][3nu] (t0, t1, t2) -> y = Gr (t0 - t1) + Gi (t0 - t2);      Gt = G^T   (dy -> dt planes)
-    tw [nu][KX][2]."""
-    OW = P - KX + 1
+def freq_order(P):
+    """-> (complex frequencies, real frequencies): u = 1..ceil(P/2)-1 carry a complex spectrum and get three planes; DC and
+    (even P) Nyquist are real for real data and get one.  Planes and twiddles are laid out complex first, then real."""
     nu = n_freq(P)
+    real = [0] + ([nu - 1] if P % 2 == 0 else [])
+    cplx = [u for u in range(nu) if u not in real]
+    return cplx, real
+
+
+def n_planes(P):
+    c, r = freq_order(P)
+    return 3 * len(c) + len(r)
+
+
+def matrices(P, KX):
+    """-> dict of float32 arrays for the three-multiplication form.  Planes: (Xr + Xi, Xi, Xr) per complex frequency, then
+    Xr per real frequency (freq_order):
+    F  [G][P]   x -> operand planes;       Ft = F^T   (operand-plane grads -> dx)
+    G  [OW][G]  result planes -> y = Gr (t0 - t1) + Gi (t0 - t2)  (real frequencies: Gr t);   Gt = G^T   (dy -> result-plane grads)
+    tw [nu][KX][2] in the same frequency order; also U, Ur."""
+    OW = P - KX + 1
+    cplx, real = freq_order(P)
     F2, G2 = dft_matrix(P), idft_matrix(P, OW)
     Fr, Fi = F2[0::2], F2[1::2]
-    F = np.empty((3 * nu, P))
-    F[0::3], F[1::3], F[2::3] = Fr + Fi, Fi, Fr
     Gr, Gi = G2[:, 0::2], G2[:, 1::2]
-    G = np.empty((OW, 3 * nu))
-    G[:, 0::3], G[:, 1::3], G[:, 2::3] = Gr + Gi, -Gr, -Gi
+    Frows, Gcols = [], []
+    for u in cplx:
+        Frows += [Fr[u] + Fi[u], Fi[u], Fr[u]]
+        Gcols += [Gr[:, u] + Gi[:, u], -Gr[:, u], -Gi[:, u]]
+    for u in real:
+        Frows.append(Fr[u])
+        Gcols.append(Gr[:, u])
+    F = np.stack(Frows, 0)
+    G = np.stack(Gcols, 1)
+    tw = twiddles(P, KX)[cplx + real]
     f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
-    return dict(F=f32(F), Ft=f32(F.T), G=f32(G), Gt=f32(G.T), tw=twiddles(P, KX))
+    return dict(F=f32(F), Ft=f32(F.T), G=f32(G), Gt=f32(G.T), tw=f32(tw))
 
 
 def matrices_full(P, W, KX):
@@ -83,9 +104,10 @@ def matrices_full(P, W, KX):
     assert W + KX - 1 == P
     m = matrices(P, 1)                       # OW = P: every output column
     F = np.ascontiguousarray(m["F"][:, :W])
-    tw = twiddles(P, KX).copy()
+    cplx, real = freq_order(P)
+    tw = twiddles(P, KX)[cplx + real].copy()
     tw[..., 1] = -tw[..., 1]
-    return dict(F=F, Ft=np.ascontiguousarray(F.T), G=m["G"], Gt=m["Gt"], tw=tw)
+    return dict(F=F, Ft=np.ascontiguousarray(F.T), G=m["G"], Gt=m["Gt"], tw=np.ascontiguousarray(tw, dtype=np.float32))
 
 
 def axis(R, I, O, C, in_sr, in_hi, in_lo, in_split, out_sr, out_hi, out_lo, out_split, act=0, act_c0=0, accum=0):
@@ -102,7 +124,8 @@ class Layout:
         self.N, self.H, self.W, self.Ci, self.ldx, self.Co, self.ldy, self.KY, self.KX = N, H, W, Ci, ldx, Co, ldy, KY, KX
         self.OH, self.OW = H - KY + 1, W - KX + 1
         self.nu = n_freq(W)
-        self.G = 3 * self.nu
+        self.Ur = len(freq_order(W)[1])
+        self.G = n_planes(W)
         self.x_g = N * H * Ci                     # floats per operand plane
         self.t_g = N * self.OH * Co               # floats per result plane
         self.w_g = Co * KY * Ci                   # floats per weight plane (either layout)
@@ -161,7 +184,8 @@ class LayoutT:
         self.OH, self.OW = H + KY - 1, W + KX - 1
         self.P = self.OW
         self.nu = n_freq(self.P)
-        self.G = 3 * self.nu
+        self.Ur = len(freq_order(self.P)[1])
+        self.G = n_planes(self.P)
         self.x_g = N * H * Ci
         self.t_g = N * self.OH * Co
         self.w_g = Co * KY * Ci
@@ -222,7 +246,7 @@ def conv_transpose_fwd_bwd(x, w, bias, dy):
     xp = torch.empty(L.G * L.x_g, **f32)
     ops.axis_linear(L.x_to_planes(), x, m["F"], xp)
     wv = torch.empty(L.G * L.w_g, **f32)
-    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, wv)
+    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, L.Ur, wv)
     tp = torch.zeros(L.G * L.t_g, **f32)
     for dd in L.convT():
         ops.conv_fwd(dd, xp, wv, tp)
@@ -233,10 +257,10 @@ def conv_transpose_fwd_bwd(x, w, bias, dy):
     dv = torch.empty(L.G * L.w_g, **f32)
     ops.conv_wgrad(L.wgrad(), xp, dtp, dv)
     kg = torch.empty(Ci, KY * KX, Co, **f32)
-    ops.wspec_bwd(dv, m["tw"], Ci, Co, KY, KX, L.nu, kg)
+    ops.wspec_bwd(dv, m["tw"], Ci, Co, KY, KX, L.nu, L.Ur, kg)
     dw = kg.permute(0, 2, 1).reshape(Ci, Co, KY, KX)
     wvt = torch.empty(L.G * L.w_g, **f32)
-    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, wvt)
+    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, L.Ur, wvt)
     dxp = torch.empty(L.G * L.x_g, **f32)
     ops.conv_fwd(L.dgrad(), dtp, wvt, dxp)
     dx = torch.empty(N, H, W, Ci, **f32)
@@ -260,7 +284,7 @@ def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):
     xp = torch.empty(L.G * L.x_g, **f32)
     ops.axis_linear(L.x_to_planes(), x, m["F"], xp)
     wv = torch.empty(L.G * L.w_g, **f32)
-    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, wv)
+    ops.wspec_fwd(wf, m["tw"], Co, Ci, KY, KX, L.nu, L.Ur, wv)
     tp = torch.empty(L.G * L.t_g, **f32)
     ops.conv_fwd(L.conv(), xp, wv, tp)
     y = torch.empty(N, L.OH, L.OW, Co, **f32)
@@ -271,10 +295,10 @@ def primary_caps_fwd_bwd(x, w, bias, dy, act_c0=None):
     dv = torch.empty(L.G * L.w_g, **f32)
     ops.conv_wgrad(L.wgrad(), dtp, xp, dv)
     kg = torch.empty(Co, KY * KX, Ci, **f32)
-    ops.wspec_bwd(dv, m["tw"], Co, Ci, KY, KX, L.nu, kg)
+    ops.wspec_bwd(dv, m["tw"], Co, Ci, KY, KX, L.nu, L.Ur, kg)
     dw = kg.permute(0, 2, 1).reshape(Co, Ci, KY, KX)
     wvt = torch.empty(L.G * L.w_g, **f32)
-    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, wvt)
+    ops.wspec_fwd(wt, m["tw"], Ci, Co, KY, KX, L.nu, L.Ur, wvt)
     dxp = torch.empty(L.G * L.x_g, **f32)
     for dd in L.dgrad():
         ops.conv_fwd(dd, dtp, wvt, dxp)

@@ -27,13 +27,13 @@ def dgrad_all():
 
 stages = [
     ("x -> operand planes (row DFT)", lambda: ops.axis_linear(L.x_to_planes(), x, m["F"], xp)),
-    ("weight planes (fwd layout)", lambda: ops.wspec_fwd(wf, m["tw"], Co, Ci, K, K, L.nu, wv)),
-    ("grouped conv 9x1, 45 groups", lambda: ops.conv_fwd(L.conv(), xp, wv, tp)),
+    ("weight planes (fwd layout)", lambda: ops.wspec_fwd(wf, m["tw"], Co, Ci, K, K, L.nu, L.Ur, wv)),
+    ("grouped conv 9x1, %d groups" % L.G, lambda: ops.conv_fwd(L.conv(), xp, wv, tp)),
     ("result planes -> y (+bias, sigmoid)", lambda: ops.axis_linear(L.planes_to_y(capi.ACT_SIGMOID, 512), tp, m["G"], y, bias=bias)),
     ("dy -> result-plane grads", lambda: ops.axis_linear(L.dy_to_planes(Co), dy, m["Gt"], dtp)),
-    ("wgrad, 45 groups in one launch", lambda: ops.conv_wgrad(L.wgrad(), dtp, xp, dv)),
-    ("weight-plane adjoint", lambda: ops.wspec_bwd(dv, m["tw"], Co, Ci, K, K, L.nu, kg)),
-    ("weight planes (dgrad layout)", lambda: ops.wspec_fwd(wt, m["tw"], Ci, Co, K, K, L.nu, wvt)),
+    ("wgrad, %d groups in one launch" % L.G, lambda: ops.conv_wgrad(L.wgrad(), dtp, xp, dv)),
+    ("weight-plane adjoint", lambda: ops.wspec_bwd(dv, m["tw"], Co, Ci, K, K, L.nu, L.Ur, kg)),
+    ("weight planes (dgrad layout)", lambda: ops.wspec_fwd(wt, m["tw"], Ci, Co, K, K, L.nu, L.Ur, wvt)),
     ("grouped dgrad", dgrad_all),
     ("operand-plane grads -> dx", lambda: ops.axis_linear(L.planes_to_dx(Ci, False), dxp, m["Ft"], dx)),
 ]
