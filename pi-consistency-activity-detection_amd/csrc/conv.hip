@@ -593,10 +593,12 @@ struct WgK {
     int store;                       // one K slice: plain stores instead of atomics
     int nsplit, dbs, sbs, gbs;       // blockIdx.z = problem * nsplit + K slice; pointers advance by these strides per problem
     int dlat, Td, Hd, Wd, doff[3];   // dlat: D is a sub-lattice (Tq,Hq,Wq) at doff of a [N][Td][Hd][Wd] tensor instead of dense
+    int mt, ntl;                     // tiles along Cd and along the columns; the grid is 1-D: mt * ntl * problems * slices blocks
 };
 
-template <int BM, int BN, int ABL = 0>
+template <int BM, int BN, int ABL = 0, int KB = 32>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
+    constexpr int BK = KB;                           // positions per chunk (shadows the file-level BK)
     constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
     static_assert(TM >= 1 && TN >= 1, "tile");
     __shared__ __attribute__((aligned(16))) float Ds[2][BK][BM];
@@ -606,9 +608,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = p.mbase + blockIdx.x * BM, n0 = blockIdx.y * BN;
-    // blockIdx.z = problem * nsplit + K slice
-    const int prob = blockIdx.z / p.nsplit, slice = blockIdx.z - prob * p.nsplit;
+    // XCD-aware order: the blocks of one K slice (every tile reads the same rows of D, and overlapping rows of S) get
+    // consecutive logical ids, i.e. run on one XCD and share its L2
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.mt * p.ntl, tile = lid % tiles, bz = lid / tiles;
+    const int m0 = p.mbase + (tile % p.mt) * BM, n0 = (tile / p.mt) * BN;
+    // bz = problem * nsplit + K slice
+    const int prob = bz / p.nsplit, slice = bz - prob * p.nsplit;
     const int c_begin = slice * p.chunks_per_split;
     const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
@@ -653,6 +659,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     auto gload = [&](int c, int buf) {
         float* ld = &Ds[buf][0][0] + wave * 256;      // wave-uniform base; the DMA adds lane*16 B
         float* ls = &Ss[buf][0][0] + wave * 256;
+        if (ABL != 5)
 #pragma unroll
         for (int j = 0; j < DN; ++j) {
             const int r = drow0 + DRP * j;
@@ -661,6 +668,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
             const float* src = v ? Dp + (size_t)drow[c % 3][r] * p.ldd + m0 + dcol : g_zero16;
             glds16(src, ld + j * 1024);
         }
+        if (ABL != 4)
 #pragma unroll
         for (int j = 0; j < SN; ++j) {
             const int r = srow0 + SRP * j;
@@ -689,23 +697,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     __syncthreads();
     const int ml = wm * (BM / 2) + (lane & 31), nl = wn * (BN / 2) + (lane & 31), kh = lane >> 5;
     for (int c = c_begin; c < c_end; ++c) {
-        const int buf = ABL ? 0 : ((c - c_begin) & 1);
-        if (!ABL) ptab_fill(c + 2);
-        if (!ABL && c + 1 < c_end) gload(c + 1, buf ^ 1);
+        const int buf = (ABL >= 1 && ABL <= 3) ? 0 : ((c - c_begin) & 1);
+        if (!ABL || ABL >= 4) ptab_fill(c + 2);
+        if ((!ABL || ABL == 4 || ABL == 5) && c + 1 < c_end) gload(c + 1, buf ^ 1);   // 4: D tile only, 5: S tile only, 6: position table only
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][ks * 2 + kh][ml + i * 32];
+            for (int i = 0; i < TM; ++i) af[i] = Ds[buf][(ABL >= 2 ? 0 : ks * 2) + kh][ml + i * 32];     // ABL >= 2: one read for the chunk
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][ks * 2 + kh][nl + j * 32];
+            for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][(ABL >= 2 ? 0 : ks * 2) + kh][nl + j * 32];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+        if (ABL < 3) __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -754,11 +762,16 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
     k.nchunks = cdiv(P, BK);
-    PC_CHECK_ARG(cdiv(k.Ntot, 128) <= 65535, "pc_conv_wgrad: too many column tiles");
     static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic: no tile fetch in the K loop (wrong results)
     // rows of D's channels [m_lo, m_hi) with 64- or 128-row tiles
+    static const int wide_env = getenv("PICONS_WGRAD_WIDE") ? atoi(getenv("PICONS_WGRAD_WIDE")) : 3;   // bit 0: 128-row, bit 1: 64-row launches
     auto launch = [&](int m_lo, int m_hi, bool small_m) {
-        const int bm = small_m ? 64 : 128, bn = 128;
+        // 256-column tiles with 16-position chunks for the long-K launches: 17-25 % less tile traffic per FLOP.  The kernel
+        // is bound by the LDS-DMA fill rate, not by the MFMA loop (fetch ablation: 148 TF/s without the fetch, 113-118 with either
+        // operand tile alone, 103 with both): 3x3x3 128->128 @112^2 103 -> 115 TF/s, the 64-channel layers 87 -> 92
+        const bool wide = !abl && k.Ntot >= 512 && ((wide_env & 1) && !small_m || (wide_env & 2) && small_m) && P >= 65536;
+        const int bm = small_m ? 64 : 128, bn = wide ? 256 : 128;
+        k.nchunks = cdiv(P, wide ? 16 : BK);
         const int mt = cdiv(m_hi - m_lo, bm), ntl = cdiv(k.Ntot, bn);
         int splitk = d->splitk;
         const int nb = d->nbatch > 1 ? d->nbatch : 1;
@@ -768,13 +781,12 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             // slots and never spill a few blocks into a third (1026 blocks ran ~25 % slower than 1022); at least
             // 8 chunks (256 positions) per slice
             const int64_t tiles = (int64_t)mt * ntl * nb;
-            const int slots = small_m ? 768 : 512;
+            const int slots = (small_m || wide) ? 768 : 512;
             splitk = (int)(2 * slots / tiles);
             const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
             if (splitk > maxsplit) splitk = maxsplit;
             if (splitk < 1) splitk = 1;
         }
-        if ((int64_t)splitk * nb > 65535) splitk = 65535 / nb;
         WgK kk = k;
         kk.mbase = m_lo; kk.mend = m_hi;
         kk.store = d->splitk == -1;
@@ -782,11 +794,24 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         kk.chunks_per_split = cdiv(k.nchunks, splitk);
         splitk = cdiv(k.nchunks, kk.chunks_per_split);
         kk.nsplit = splitk;
-        dim3 grid(mt, ntl, nb * splitk);
-        if (abl) {
+        kk.mt = mt; kk.ntl = ntl;
+        dim3 grid((unsigned)((int64_t)mt * ntl * nb * splitk));
+        if (abl == 2) {          // + fragment reads hoisted out of the k-step loop
+            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 2>), grid, dim3(256), 0, s, kk);
+            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 2>), grid, dim3(256), 0, s, kk);
+        } else if (abl >= 4 && abl <= 6) {
+            if (abl == 4) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 4>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 4>), grid, dim3(256), 0, s, kk); }
+            if (abl == 5) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 5>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 5>), grid, dim3(256), 0, s, kk); }
+            if (abl == 6) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 6>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 6>), grid, dim3(256), 0, s, kk); }
+        } else if (abl == 3) {   // + no barrier per chunk
+            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 3>), grid, dim3(256), 0, s, kk);
+            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 3>), grid, dim3(256), 0, s, kk);
+        } else if (abl) {
             if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
-        } else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
+        } else if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
+        else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
+        else if (wide) hipLaunchKernelGGL((wgrad_kernel<128, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);
     };
     // 128-row tiles for the bulk.  When the grid is many rounds deep without split-K (PrimaryCaps: 544 = 4*128 + 32
