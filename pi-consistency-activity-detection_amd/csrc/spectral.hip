@@ -30,7 +30,8 @@ __global__ __launch_bounds__(256) void axis_linear_kernel(const AxK p) {
     float* op = p.out + (int64_t)r * p.out_sr + c;
     float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p.bias) b = *(const float4*)(p.bias + c);
-    for (int o0 = 0; o0 < p.O; o0 += AX_OC) {
+    {   // blockIdx.y picks the chunk of AX_OC outputs: more, shorter threads (the tensors are small and the kernel latency-bound)
+        const int o0 = blockIdx.y * AX_OC;
         float4 acc[AX_OC];
 #pragma unroll
         for (int q = 0; q < AX_OC; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -156,7 +157,7 @@ extern "C" int pc_axis_linear(const pc_axis_desc* d, const float* in, const floa
     k.in_split = d->in_split; k.out_split = d->out_split; k.act = d->act; k.act_c0 = d->act_c0; k.accum = d->accum;
     k.in_sr = d->in_sr; k.in_hi = d->in_hi; k.in_lo = d->in_lo; k.out_sr = d->out_sr; k.out_hi = d->out_hi; k.out_lo = d->out_lo;
     const int64_t n = (int64_t)k.R * k.C4;
-    hipLaunchKernelGGL(axis_linear_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), (size_t)d->O * d->I * 4, s, k);
+    hipLaunchKernelGGL(axis_linear_kernel, dim3((unsigned)cdiv(n, 256), (unsigned)cdiv(d->O, AX_OC)), dim3(256), (size_t)d->O * d->I * 4, s, k);
     PC_CHECK_LAUNCH("axis_linear_kernel");
     return PC_OK;
 }
