@@ -277,6 +277,15 @@ int pc_wspec_fwd(const float* in, const float* tw, int A, int B, int KY, int KX,
  * tw[u][kx][0]*d0 over the real ones; dV in the plane order of pc_wspec_fwd */
 int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX, int U, int Ur, float* kg, pc_stream s);
 
+/* The same two maps straight from / to the reference's master layout w[A][B][KY][KX] (OIHW, taps contiguous), so the
+ * 36.7 M-element PrimaryCaps weight needs no kernel-layout copies: rows [a0, a0 + Acnt) of an Atot-row weight (pose and
+ * activation capsules are two tensors).  out_f = planes [g][Atot][KY][B] (forward GEMM), out_t = [g][B][KY][Atot] (dgrad
+ * GEMM); either may be NULL.  The adjoint reads plane gradients in the out_f layout and writes (accum: adds to) dw. */
+int pc_wspec_master_fwd(const float* w, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                        float* out_f, float* out_t, pc_stream s);
+int pc_wspec_master_bwd(const float* dV, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                        float* dw, int accum, pc_stream s);
+
 /* ------------------------------------------------------------------------------------------
  * Merged decoder tail (capsules_ucf101.py:504-509).  upsample4 -> Dropout3d -> smooth composes, per dimension, into one
  * stride-2 transposed conv with five taps k5 = k4 + ks (o = 2i - 2 + k5) and ONE output channel; the single term that
@@ -318,6 +327,8 @@ enum {
     PC_OP_AXIS,                     /* i[0..14] = pc_axis_desc; p = in, M, bias, out */
     PC_OP_WSPEC_FWD,                /* i = A, B, KY, KX, U, Ur; p = in, tw, out */
     PC_OP_WSPEC_BWD,                /* i = A, B, KY, KX, U, Ur; p = dV, tw, kg */
+    PC_OP_WSPEC_MASTER_FWD,         /* i = Acnt, a0, Atot, B, KY, KX, U, Ur; p = w, tw, out_f, out_t */
+    PC_OP_WSPEC_MASTER_BWD,         /* i = Acnt, a0, Atot, B, KY, KX, U, Ur, accum; p = dV, tw, dw */
     PC_OP_TAIL6_WEIGHTS,            /* i = N, Ci; p = wf, W5f, W5t */
     PC_OP_TAIL6_GATHER,             /* i = N, It, Ih, Iw; p = cols, bc, bsm, out */
     PC_OP_TAIL6_SCATTER,            /* i = N, It, Ih, Iw; p = dout, dcols */

@@ -47,8 +47,8 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
 (OP_CONV, OP_WGRAD, OP_BN_FINALIZE, OP_BN_APPLY, OP_BN_EVAL_STAT, OP_BN_BWD, OP_POOL_FWD, OP_POOL_BWD, OP_CHSCALE,
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
- OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN) = range(1, 40)
+ OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN) = range(1, 42)
 MAX_LANES = 8
 
 # numpy mirror of struct pc_transpose_job
@@ -99,6 +99,8 @@ _SIGS = {
     "pc_axis_linear": (i32, [vp, vp, vp, vp, vp, vp]),
     "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
+    "pc_wspec_master_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "pc_wspec_master_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "pc_tail6_weights": (i32, [vp, i32, i32, vp, vp, vp]),
     "pc_tail6_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
     "pc_tail6_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp]),

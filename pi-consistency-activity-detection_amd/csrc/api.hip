@@ -113,6 +113,12 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_wspec_fwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 2), s);
         case PC_OP_WSPEC_BWD:
             return pc_wspec_bwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 2), s);
+        case PC_OP_WSPEC_MASTER_FWD:
+            return pc_wspec_master_fwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7],
+                                       P(float*, 2), P(float*, 3), s);
+        case PC_OP_WSPEC_MASTER_BWD:
+            return pc_wspec_master_bwd(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7],
+                                       P(float*, 2), op.i[8], s);
         case PC_OP_TAIL6_WEIGHTS:
             return pc_tail6_weights(P(const float*, 0), op.i[0], op.i[1], P(float*, 1), P(float*, 2), s);
         case PC_OP_TAIL6_GATHER:

@@ -141,6 +141,72 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
     }
 }
 
+// The same two maps straight from / to the reference's OI(H)W master layout w[A][B][KY][KX] (taps contiguous), so a big
+// weight needs no kernel-layout copies at all.  One thread per (a, b) holds all KY*KX taps in registers.
+// ALONG_A: consecutive threads walk a (for the [g][B][KY][Atot] dgrad layout), else b (for the [g][Atot][KY][B] forward layout).
+template <int KX, int KY, bool ALONG_A>
+__global__ __launch_bounds__(128) void wspec_master_fwd_kernel(const float* __restrict__ w, const float* __restrict__ tw, int Acnt, int a0, int Atot,
+                                                                int B, int U, int Ur, float* __restrict__ out) {
+    const int fast = blockIdx.x * 128 + threadIdx.x, slow = blockIdx.y;
+    const int a = ALONG_A ? fast : slow, b = ALONG_A ? slow : fast;
+    if (a >= Acnt || b >= B) return;
+    float v[KY][KX];
+    const float* src = w + ((size_t)a * B + b) * (KY * KX);
+#pragma unroll
+    for (int ky = 0; ky < KY; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) v[ky][kx] = src[ky * KX + kx];
+    // element (g, ky) of this (a, b): forward layout [g][Atot][KY][B], dgrad layout [g][B][KY][Atot]
+    const int64_t plane = (int64_t)Atot * KY * B;
+    const int64_t base = ALONG_A ? ((int64_t)b * KY) * Atot + a0 + a : ((int64_t)(a0 + a) * KY) * B + b;
+    const int64_t kystep = ALONG_A ? Atot : B;
+    for (int u = 0; u < U; ++u) {
+        const bool real = u >= U - Ur;
+        const int64_t g0 = real ? 3 * (U - Ur) + (u - (U - Ur)) : 3 * u;
+#pragma unroll
+        for (int ky = 0; ky < KY; ++ky) {
+            float wr = 0.f, wi = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) { wr += tw[(u * KX + kx) * 2] * v[ky][kx]; wi += tw[(u * KX + kx) * 2 + 1] * v[ky][kx]; }
+            float* o = out + g0 * plane + base + ky * kystep;
+            o[0] = wr;
+            if (!real) { o[plane] = wr - wi; o[2 * plane] = wr + wi; }
+        }
+    }
+}
+
+// dV planes in the forward layout [g][Atot][KY][B] -> dw[A][B][KY][KX] (+)= ...
+template <int KX, int KY>
+__global__ __launch_bounds__(128) void wspec_master_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ tw, int Acnt, int a0, int Atot,
+                                                                int B, int U, int Ur, float* __restrict__ dw, int accum) {
+    const int b = blockIdx.x * 128 + threadIdx.x, a = blockIdx.y;
+    if (a >= Acnt || b >= B) return;
+    float acc[KY][KX];
+#pragma unroll
+    for (int ky = 0; ky < KY; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) acc[ky][kx] = 0.f;
+    const int64_t plane = (int64_t)Atot * KY * B;
+    const float* d = dV + ((int64_t)(a0 + a) * KY) * B + b;
+    for (int u = 0; u < U; ++u) {
+        const bool real = u >= U - Ur;
+        const int64_t g0 = real ? 3 * (U - Ur) + (u - (U - Ur)) : 3 * u;
+#pragma unroll
+        for (int ky = 0; ky < KY; ++ky) {
+            const float* du = d + g0 * plane + (int64_t)ky * B;
+            const float d0 = du[0], d1 = real ? 0.f : du[plane], d2 = real ? 0.f : du[2 * plane];
+            const float gr = d0 + d1 + d2, gi = d2 - d1;
+#pragma unroll
+            for (int kx = 0; kx < KX; ++kx) acc[ky][kx] += tw[(u * KX + kx) * 2] * gr + tw[(u * KX + kx) * 2 + 1] * gi;
+        }
+    }
+    float* dst = dw + ((size_t)a * B + b) * (KY * KX);
+#pragma unroll
+    for (int ky = 0; ky < KY; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) dst[ky * KX + kx] = (accum ? dst[ky * KX + kx] : 0.f) + acc[ky][kx];
+}
+
 }  // namespace
 
 extern "C" int pc_axis_linear(const pc_axis_desc* d, const float* in, const float* M, const float* bias, float* out, pc_stream s_) {
@@ -192,5 +258,26 @@ extern "C" int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int 
                   WS_CASE(12) WS_CASE(13) WS_CASE(14) WS_CASE(15) WS_CASE(16) }
 #undef WS_CASE
     PC_CHECK_LAUNCH("wspec_bwd_kernel");
+    return PC_OK;
+}
+
+extern "C" int pc_wspec_master_fwd(const float* w, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                                   float* out_f, float* out_t, pc_stream s_) {
+    PC_CHECK_ARG(w && tw && (out_f || out_t) && Acnt > 0 && a0 >= 0 && a0 + Acnt <= Atot && B > 0 && U > 0 && Ur >= 0 && Ur <= U,
+                 "pc_wspec_master_fwd: bad args");
+    PC_CHECK_ARG(KY == 9 && KX == 9, "pc_wspec_master_fwd: only the 9x9 PrimaryCaps kernel is instantiated (KY=%d KX=%d)", KY, KX);
+    hipStream_t s = (hipStream_t)s_;
+    if (out_f) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, false>), dim3(cdiv(B, 128), Acnt), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, out_f);
+    if (out_t) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, true>), dim3(cdiv(Acnt, 128), B), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, out_t);
+    PC_CHECK_LAUNCH("wspec_master_fwd_kernel");
+    return PC_OK;
+}
+
+extern "C" int pc_wspec_master_bwd(const float* dV, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                                   float* dw, int accum, pc_stream s_) {
+    PC_CHECK_ARG(dV && tw && dw && Acnt > 0 && a0 >= 0 && a0 + Acnt <= Atot && B > 0 && U > 0 && Ur >= 0 && Ur <= U, "pc_wspec_master_bwd: bad args");
+    PC_CHECK_ARG(KY == 9 && KX == 9, "pc_wspec_master_bwd: only the 9x9 PrimaryCaps kernel is instantiated (KY=%d KX=%d)", KY, KX);
+    hipLaunchKernelGGL((wspec_master_bwd_kernel<9, 9>), dim3(cdiv(B, 128), Acnt), dim3(128), 0, (hipStream_t)s_, dV, tw, Acnt, a0, Atot, B, U, Ur, dw, accum);
+    PC_CHECK_LAUNCH("wspec_master_bwd_kernel");
     return PC_OK;
 }

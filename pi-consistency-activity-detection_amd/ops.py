@@ -224,6 +224,15 @@ def wspec_bwd(dV, tw, A, B, KY, KX, U, Ur, kg):
     return kg
 
 
+def wspec_master_fwd(w, tw, Acnt, a0, Atot, B, KY, KX, U, Ur, out_f, out_t):
+    capi.call("pc_wspec_master_fwd", ptr(w), ptr(tw), Acnt, a0, Atot, B, KY, KX, U, Ur, ptr(out_f), ptr(out_t), stream())
+
+
+def wspec_master_bwd(dV, tw, Acnt, a0, Atot, B, KY, KX, U, Ur, dw, accum=False):
+    capi.call("pc_wspec_master_bwd", ptr(dV), ptr(tw), Acnt, a0, Atot, B, KY, KX, U, Ur, ptr(dw), int(accum), stream())
+    return dw
+
+
 def tail6_weights(wf, N, Ci, W6f, W6t):
     capi.call("pc_tail6_weights", ptr(wf), N, Ci, ptr(W6f), ptr(W6t), stream())
 

@@ -526,18 +526,23 @@ class Plan:
         s20 = s28 - KP + 1
         npose = spec.IN_CAPS * spec.POSE
         caps_in = self.tensor(N, (1, s20, s20), npose + spec.IN_CAPS, "caps_in")
-        wpc = self.prep_conv_weight(["primary_caps.pose.weight", "primary_caps.a.weight"], [npose, spec.IN_CAPS], xd.C, (1, KP, KP), True)
         spectral_pc = self.spectral_pc and xd.thw[0] == 1
         Cpc = npose + spec.IN_CAPS
+        pc_names = [("primary_caps.pose.weight", 0, npose), ("primary_caps.a.weight", npose, spec.IN_CAPS)]
         if spectral_pc:
-            # row-spectral form: DFT along x, one grouped 9x1 conv (3 real groups per frequency), inverse DFT (spectral.py)
+            # row-spectral form: DFT along x, one grouped 9x1 conv (3 real groups per complex frequency), inverse DFT
+            # (spectral.py).  The weight planes come straight from the master OIHW tensors (no kernel-layout copies of the
+            # 36.7 M-element weight), the gradient goes straight back.
             SL = spectral.Layout(N, xd.thw[1], xd.thw[2], xd.C, xd.ld, Cpc, caps_in.ld, KP, KP)
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
-            wpc["wv"] = self.alloc(SL.G * SL.w_g)               # [g][Co][ky][Ci]  forward GEMM weight planes
-            wpc["wvt"] = self.alloc(SL.G * SL.w_g)              # [g][Ci][ky][Co]  dgrad GEMM weight planes
-            self.emit(capi.OP_WSPEC_FWD, i=[Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[wpc["fwd"], sm["tw"], wpc["wv"]], lst="prep")
-            self.emit(capi.OP_WSPEC_FWD, i=[xd.C, Cpc, KP, KP, SL.nu, SL.Ur], p=[wpc["tr"], sm["tw"], wpc["wvt"]], lst="prep")
+            wpc = dict(wv=self.alloc(SL.G * SL.w_g),             # [g][Co][ky][Ci]  forward GEMM weight planes
+                       wvt=self.alloc(SL.G * SL.w_g))            # [g][Ci][ky][Co]  dgrad GEMM weight planes
+            pl = self.next_prep_lane()
+            for nm, a0, cnt in pc_names:      # pose rows, then activation rows, of the same plane buffers: one lane
+                self.emit(capi.OP_WSPEC_MASTER_FWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[self.P(nm), sm["tw"], wpc["wv"], wpc["wvt"]],
+                          lst="prep", lane=pl)
         else:
+            wpc = self.prep_conv_weight([nm for nm, _a, _c in pc_names], [cnt for _n, _a, cnt in pc_names], xd.C, (1, KP, KP), True)
             wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
             self.emit(capi.OP_TRANSPOSE, i=[1, Cpc, KP * KP * xd.C, KP * KP * xd.C, Cpc, 0], l=[0, 0],
                       p=[wpc["fwd"], wpc["tio"]], lst="prep")
@@ -589,11 +594,14 @@ class Plan:
                 dwv = self.alloc(SL.G * SL.w_g)
                 self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dtpl])
                 self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dtpl, xpl, dwv])
-                self.emit(capi.OP_WSPEC_BWD, i=[Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[dwv, sm["tw"], wpc["kg"]])
+                for nm, a0, cnt in pc_names:
+                    self.emit(capi.OP_WSPEC_MASTER_BWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur, self.acc], p=[dwv, sm["tw"], self.G(nm)])
+                self.mark_final(*[nm for nm, _a, _c in pc_names])
             else:
                 self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
                           p=[dcaps.ref, xd.ref, wpc["kg"]])
-            self.flush_grad(wpc)
+            if not spectral_pc:
+                self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
             dx, acc = self.grad_for_write(xd)
             F_pc = 2 * caps_in.rows * caps_in.C * xd.C * KP * KP
@@ -856,8 +864,9 @@ class Plan:
         for op in lst:
             if op[0] == capi.OP_TRANSPOSE and op[3][0][0] == "P":
                 pending.setdefault(op[5], []).append(op)
-            elif op[0] == capi.OP_FILL or op[0] == capi.OP_FORK:
-                res.append(op)           # fills precede the transposes into their buffer; the fork opens the region
+            elif op[0] in (capi.OP_FILL, capi.OP_FORK, capi.OP_WSPEC_MASTER_FWD):
+                res.append(op)           # fills precede the transposes into their buffer; the fork opens the region; the
+                                         # master-layout weight planes touch nothing the transposes do
             else:
                 flush()
                 res.append(op)

@@ -183,6 +183,35 @@ def test_axis_linear_general_strides():
     close(out.cpu().reshape(R, O, C_), want, rtol=1e-5, what="axis_linear")
 
 
+def test_weight_planes_from_master_layout_match_generic_path():
+    """pc_wspec_master_fwd / _bwd (planes straight from / to the OIHW master tensor, two row ranges like pose + activation
+    capsules) against pc_wspec_fwd / _bwd on the kernel layouts."""
+    from picons_amd import spectral
+    g = torch.Generator().manual_seed(41)
+    A1, A2, B, K, P = 24, 8, 16, 9, 28
+    A = A1 + A2
+    w1 = torch.randn(A1, B, K, K, generator=g).to(DEV); w2 = torch.randn(A2, B, K, K, generator=g).to(DEV)
+    w = torch.cat([w1, w2], 0)
+    m = {k: torch.from_numpy(v).to(DEV) for k, v in spectral.matrices(P, K).items()}
+    U, Ur, G = spectral.n_freq(P), len(spectral.freq_order(P)[1]), spectral.n_planes(P)
+    wf = w.reshape(A, B, K * K).permute(0, 2, 1).contiguous(); wt = w.reshape(A, B, K * K).permute(1, 2, 0).contiguous()
+    ref_f = torch.empty(G, A, K, B, device=DEV); ref_t = torch.empty(G, B, K, A, device=DEV)
+    ops.wspec_fwd(wf, m["tw"], A, B, K, K, U, Ur, ref_f)
+    ops.wspec_fwd(wt, m["tw"], B, A, K, K, U, Ur, ref_t)
+    out_f = torch.full_like(ref_f, 5.0); out_t = torch.full_like(ref_t, 5.0)
+    ops.wspec_master_fwd(w1, m["tw"], A1, 0, A, B, K, K, U, Ur, out_f, out_t)
+    ops.wspec_master_fwd(w2, m["tw"], A2, A1, A, B, K, K, U, Ur, out_f, out_t)
+    close(out_f, ref_f, rtol=1e-5, what="forward-layout planes"); close(out_t, ref_t, rtol=1e-5, what="dgrad-layout planes")
+    dV = torch.randn(G, A, K, B, generator=g).to(DEV)
+    kg = torch.empty(A, K * K, B, device=DEV)
+    ops.wspec_bwd(dV, m["tw"], A, B, K, K, U, Ur, kg)
+    want = kg.permute(0, 2, 1).reshape(A, B, K, K)
+    d1 = torch.full((A1, B, K, K), 5.0, device=DEV); d2 = torch.ones(A2, B, K, K, device=DEV)
+    ops.wspec_master_bwd(dV, m["tw"], A1, 0, A, B, K, K, U, Ur, d1, accum=False)
+    ops.wspec_master_bwd(dV, m["tw"], A2, A1, A, B, K, K, U, Ur, d2, accum=True)
+    close(d1, want[:A1], rtol=1e-5, what="master gradient"); close(d2 - 1.0, want[A1:], rtol=1e-5, what="master gradient (accumulate)")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)

@@ -13,7 +13,7 @@ from picons_amd.plan import Plan
 # p[] slots each op kind writes (the kinds that may appear inside a FORK..JOIN region)
 WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4, 5), capi.OP_BN_APPLY: (2,),
           capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_TRANSPOSE: (1,),
-          capi.OP_FILL: (0,), capi.OP_BN_EVAL_STAT: (4,)}
+          capi.OP_FILL: (0,), capi.OP_BN_EVAL_STAT: (4,), capi.OP_WGRAD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3)}
 
 
 def _plan(lanes, bs=1, hw=112):
