@@ -212,6 +212,27 @@ def test_weight_planes_from_master_layout_match_generic_path():
     close(d1, want[:A1], rtol=1e-5, what="master gradient"); close(d2 - 1.0, want[A1:], rtol=1e-5, what="master gradient (accumulate)")
 
 
+@pytest.mark.parametrize("Ci,Co,thw,N,trim", [(64, 64, (2, 5, 56), 2, False), (64, 192, (3, 4, 28), 2, False), (128, 96, (1, 6, 28), 3, True),
+                                              (64, 48, (2, 3, 112), 1, False)])
+def test_wgrad_row_segment_kernel(Ci, Co, thw, N, trim):
+    """Stride-1 SAME 3x3x3 weight gradient through the row-segment kernel (K chunk = a segment of one image row, the three
+    kw taps share one LDS tile): widths 28 / 56 / 112, 64- and 128-row tiles, ragged Cd, and the 1x3x3 trimmed form of a
+    one-frame input."""
+    g = torch.Generator().manual_seed(51)
+    x = torch.randn(N, Ci, *thw, generator=g)
+    w = (torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    y = F.conv3d(x, w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    d = desc.wgrad(N, thw, Co, Co, thw, Ci, Ci, (3, 3, 3), (1, 1, 1), (1, 1, 1))
+    if trim:
+        d = desc.trim_wgrad(d)
+        assert d["ntap"][0] == 1
+    gw = torch.zeros(Co, 27, Ci, device=DEV)
+    ops.conv_wgrad(d, cl(dy), cl(x), gw)
+    close(gw.cpu(), w.grad.reshape(Co, Ci, 27).permute(0, 2, 1), what="wgrad (row-segment kernel)")
+
+
 def test_conv_epilogue_bias_act_cscale_accum_slice():
     g = torch.Generator().manual_seed(6)
     N, Ci, Co, thw = 2, 8, 40, (2, 6, 6)
