@@ -738,8 +738,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 }
 
 
-// Weight gradient of a stride-1 SAME conv with 3 taps along w (3x3x3, or 1x3x3 when the input has one frame) and
-// Cs % 64 == 0: the K chunk is a segment of ONE image row, the column tile is (kw = 0..2) x 64 channels of one (kt, kh)
+// Weight gradient of a conv with 3 taps, stride 1 and padding 1 along w (any stride along t / h; 3x3x3, or 1x3x3 when the
+// input has one frame) and Cs % 32 == 0: the K chunk is a segment of ONE image row, the column tile is (kw = 0..2) x 64 (or 32) channels of one (kt, kh)
 // tap pair, and the three kw taps read the SAME LDS tile of BKP + 2 input positions at row offsets 0, 1, 2 -- the
 // gathered operand is fetched once per three taps.  The generic kernel above is bound by the LDS-DMA fill of its two
 // streaming operands; for the 64-channel layers this cuts the fill per FLOP by 1.8x.
@@ -747,20 +747,23 @@ struct Wg3K {
     const float* D; const float* S; float* g;
     int N, T, H, W, Cd, ldd, Cs, lds;
     int ntap_t, ntap_h, wk0_t, wk0_h, KH;     // (kt, kh) taps present (trimmed) and their place in the full [KT][KH][3] layout
+    int Ts, Hs, istr_t, istr_h, ioff_t, ioff_h; // S row of output (t, h) and local tap (a, b): (t*istr_t + ioff_t + a, h*istr_h + ioff_h + b)
     int nseg, nchunks, chunks_per_split, nsplit, mt, ncs;   // segments per row; K chunks = N*T*H*nseg
     int taps_full;                            // KT*KH*3: g is [Cd][taps_full][Cs]
 };
 
-template <int BM, int BKP>
+template <int BM, int BKP, int CSB, int WMW>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
-    constexpr int CSB = 64, BN = 3 * CSB, TM = BM / 64, TN = 3;           // 2x2 waves: BM/2 rows x 96 columns each
+    constexpr int BN = 3 * CSB, WNW = 4 / WMW;                             // WMW x WNW waves
+    constexpr int TM = BM / WMW / 32, TN = BN / WNW / 32;
+    static_assert(BM % (WMW * 32) == 0 && BN % (WNW * 32) == 0, "wave tiles");
     constexpr int SROWS = (BKP + 2 + 3) / 4 * 4;                           // S tile rows padded to whole 1 KiB DMA pieces
     constexpr int DI = BKP * BM * 4 / 1024, SI = SROWS * CSB * 4 / 1024;   // DMA wave-instructions per tile
     static_assert((BKP * BM * 4) % 1024 == 0, "D tile must be whole DMA pieces");
     __shared__ __attribute__((aligned(16))) float Ds[2][BKP][BM];
     __shared__ __attribute__((aligned(16))) float Ss[2][SROWS][CSB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WNW, wn = wave % WNW;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.mt * p.ncs * p.ntap_t * p.ntap_h;
     int tile = lid % tiles;
@@ -769,7 +772,6 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     const int csb = tile % p.ncs; tile /= p.ncs;
     const int kh_ = tile % p.ntap_h, kt_ = tile / p.ntap_h;
     const int m0 = mtile * BM, cs0 = csb * CSB;
-    const int dt = kt_ + p.wk0_t - 1, dh = kh_ + p.wk0_h - 1;             // input row offset of this tap pair (pad 1)
     const int c_begin = slice * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
 
@@ -780,9 +782,9 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         const int t = r % p.T; const int n = r / p.T;
         w0 = seg * BKP;
         row_d = ((n * p.T + t) * p.H + h) * p.W;
-        const int ts = t + dt, hs = h + dh;
-        row_s = ((n * p.T + ts) * p.H + hs) * p.W;
-        return (unsigned)ts < (unsigned)p.T && (unsigned)hs < (unsigned)p.H;
+        const int ts = t * p.istr_t + p.ioff_t + kt_, hs = h * p.istr_h + p.ioff_h + kh_;
+        row_s = ((n * p.Ts + ts) * p.Hs + hs) * p.W;
+        return (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
     };
     auto gload = [&](int c, int buf) -> bool {
         int row_d, row_s, w0;
@@ -816,8 +818,8 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     // column tile j of wave wn: columns wn*96 + 32j .. +31 of (kw, cs): kw = col / 64, cs = col % 64
     int kwj[TN], csj[TN];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { const int col = wn * 96 + 32 * j; kwj[j] = col / CSB; csj[j] = col % CSB + (lane & 31); }
-    const int ml = wm * (BM / 2) + (lane & 31), kh = lane >> 5;
+    for (int j = 0; j < TN; ++j) { const int col = wn * (BN / WNW) + 32 * j; kwj[j] = col / CSB; csj[j] = col % CSB + (lane & 31); }
+    const int ml = wm * (BM / WMW) + (lane & 31), kh = lane >> 5;
     bool live = gload(c_begin, 0);
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
@@ -847,7 +849,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int m = m0 + wm * (BM / WMW) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.Cd) continue;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
@@ -882,22 +884,24 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.nchunks = cdiv(P, BK);
     static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic: no tile fetch in the K loop (wrong results)
     // rows of D's channels [m_lo, m_hi) with 64- or 128-row tiles
-    // stride-1 SAME conv with 3 taps along w and 64-channel blocks of S: row-segment kernel (the kw taps share one LDS tile)
+    // conv with 3 taps, stride 1, padding 1 along w and 32- / 64-channel blocks of S: row-segment kernel (the kw taps share
+    // one LDS tile)
     static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
+    const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
     if (row_env && !abl && d->nbatch <= 1 && d->Td == 0 && d->splitk >= 0 && d->KW == 3 && d->ntap[2] == 3 && d->wk0[2] == 0 &&
-        d->istr[0] == 1 && d->istr[1] == 1 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 &&
-        d->ioff0[2] == -1 && d->ioff0[0] == d->wk0[0] - 1 && d->ioff0[1] == d->wk0[1] - 1 && d->KT <= 3 && d->KH <= 3 &&
-        d->Tq == d->Ts && d->Hq == d->Hs && d->Wq == d->Ws && d->Cs % 64 == 0 && d->Ws % 28 == 0) {
+        d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 && d->ioff0[2] == -1 && d->Wq == d->Ws &&
+        (csb64 || csb32) && d->Ws % 28 == 0) {
         Wg3K q;
         q.D = D; q.S = S; q.g = g;
-        q.N = d->N; q.T = d->Ts; q.H = d->Hs; q.W = d->Ws; q.Cd = d->Cd; q.ldd = d->ldd; q.Cs = d->Cs; q.lds = d->lds;
+        q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Ws; q.Cd = d->Cd; q.ldd = d->ldd; q.Cs = d->Cs; q.lds = d->lds;
+        q.Ts = d->Ts; q.Hs = d->Hs; q.istr_t = d->istr[0]; q.istr_h = d->istr[1]; q.ioff_t = d->ioff0[0]; q.ioff_h = d->ioff0[1];
         q.ntap_t = d->ntap[0]; q.ntap_h = d->ntap[1]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
         q.taps_full = d->KT * d->KH * 3;
         const bool small_m = d->Cd <= 64;
-        const int bkp = (small_m && d->Ws % 56 == 0) ? 56 : 28;
+        const int bkp = (csb64 && small_m && d->Ws % 56 == 0) ? 56 : 28;
         q.nseg = d->Ws / bkp;
-        q.nchunks = d->N * d->Ts * d->Hs * q.nseg;
-        q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / 64;
+        q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
+        q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / (csb64 ? 64 : 32);
         const int64_t tiles = (int64_t)q.mt * q.ncs * q.ntap_t * q.ntap_h;
         int splitk = d->splitk > 0 ? d->splitk : (int)(2 * (bkp == 56 ? 512 : 768) / tiles);
         const int maxsplit = q.nchunks / 8 > 0 ? q.nchunks / 8 : 1;
@@ -906,9 +910,10 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.chunks_per_split = cdiv(q.nchunks, splitk);
         q.nsplit = cdiv(q.nchunks, q.chunks_per_split);
         const dim3 grid((unsigned)(tiles * q.nsplit));
-        if (small_m && bkp == 56) hipLaunchKernelGGL((wgrad3_kernel<64, 56>), grid, dim3(256), 0, s, q);
-        else if (small_m) hipLaunchKernelGGL((wgrad3_kernel<64, 28>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((wgrad3_kernel<128, 28>), grid, dim3(256), 0, s, q);
+        if (!csb64) hipLaunchKernelGGL((wgrad3_kernel<128, 28, 32, 4>), grid, dim3(256), 0, s, q);
+        else if (small_m && bkp == 56) hipLaunchKernelGGL((wgrad3_kernel<64, 56, 64, 2>), grid, dim3(256), 0, s, q);
+        else if (small_m) hipLaunchKernelGGL((wgrad3_kernel<64, 28, 64, 2>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((wgrad3_kernel<128, 28, 64, 2>), grid, dim3(256), 0, s, q);
         PC_CHECK_LAUNCH("wgrad3_kernel");
         return PC_OK;
     }

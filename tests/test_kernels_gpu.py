@@ -53,6 +53,9 @@ CONV_CASES = [
     (64, 16, (1, 1, 1), (1, 1, 1), (2, 9, 9), 3),
     (32, 200, (3, 3, 3), (1, 1, 1), (2, 14, 14), 2),
     (48, 136, (1, 3, 3), (1, 1, 1), (1, 20, 20), 4),
+    (64, 192, (3, 3, 3), (2, 1, 1), (4, 6, 56), 2),       # temporal stride 2: row-segment wgrad with 64-channel blocks
+    (96, 128, (3, 3, 3), (1, 1, 1), (2, 5, 28), 2),       # row-segment wgrad with 32-channel blocks
+    (160, 320, (3, 3, 3), (1, 1, 1), (1, 4, 28), 2),
 ]
 
 
