@@ -738,10 +738,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 }
 
 
-// Weight gradient of a conv with 3 taps, stride 1 and padding 1 along w (any stride along t / h; 3x3x3, or 1x3x3 when the
-// input has one frame) and Cs % 32 == 0: the K chunk is a segment of ONE image row, the column tile is (kw = 0..2) x 64 (or 32) channels of one (kt, kh)
-// tap pair, and the three kw taps read the SAME LDS tile of BKP + 2 input positions at row offsets 0, 1, 2 -- the
-// gathered operand is fetched once per three taps.  The generic kernel above is bound by the LDS-DMA fill of its two
+// Weight gradient of a conv with KW = 3 (padding 1) or 9 (no padding: the spectral forms' taps) taps of stride 1 along w
+// (any stride along t / h) and Cs % 32 == 0: the K chunk is a segment of ONE image row, the column tile is (kw = 0..2) x 64 (or 32) channels of one (kt, kh)
+// tap pair, and the KW taps read the SAME LDS tile of BKP + KW - 1 input positions at row offsets 0..KW-1 -- the
+// gathered operand is fetched once per KW taps.  The generic kernel above is bound by the LDS-DMA fill of its two
 // streaming operands; for the 64-channel layers this cuts the fill per FLOP by 1.8x.
 struct Wg3K {
     const float* D; const float* S; float* g;
@@ -749,15 +749,18 @@ struct Wg3K {
     int ntap_t, ntap_h, wk0_t, wk0_h, KH;     // (kt, kh) taps present (trimmed) and their place in the full [KT][KH][3] layout
     int Ts, Hs, istr_t, istr_h, ioff_t, ioff_h; // S row of output (t, h) and local tap (a, b): (t*istr_t + ioff_t + a, h*istr_h + ioff_h + b)
     int nseg, nchunks, chunks_per_split, nsplit, mt, ncs;   // segments per row; K chunks = N*T*H*nseg
-    int taps_full;                            // KT*KH*3: g is [Cd][taps_full][Cs]
+    int taps_full;                            // KT*KH*KW: g is [Cd][taps_full][Cs]
+    int Wsw, padw;                            // width of S and the padding along w (D width W = Wsw - KW + 1 + 2*padw)
+    int nprob, store; long long dbs, sbs, gbs; // independent problems in one launch (pointer strides); plain stores (one K slice)
 };
 
-template <int BM, int BKP, int CSB, int WMW>
+template <int BM, int BKP, int CSB, int WMW, int KW = 3>
 __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
-    constexpr int BN = 3 * CSB, WNW = 4 / WMW;                             // WMW x WNW waves
+    constexpr int BN = KW * CSB, WNW = 4 / WMW;                            // WMW x WNW waves
     constexpr int TM = BM / WMW / 32, TN = BN / WNW / 32;
     static_assert(BM % (WMW * 32) == 0 && BN % (WNW * 32) == 0, "wave tiles");
-    constexpr int SROWS = (BKP + 2 + 3) / 4 * 4;                           // S tile rows padded to whole 1 KiB DMA pieces
+    constexpr int SPIECE = 256 / CSB;                                      // S rows per 1 KiB DMA piece
+    constexpr int SROWS = (BKP + KW - 1 + SPIECE - 1) / SPIECE * SPIECE;   // S tile rows padded to whole DMA pieces
     constexpr int DI = BKP * BM * 4 / 1024, SI = SROWS * CSB * 4 / 1024;   // DMA wave-instructions per tile
     static_assert((BKP * BM * 4) % 1024 == 0, "D tile must be whole DMA pieces");
     __shared__ __attribute__((aligned(16))) float Ds[2][BKP][BM];
@@ -767,7 +770,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.mt * p.ncs * p.ntap_t * p.ntap_h;
     int tile = lid % tiles;
-    const int slice = lid / tiles;
+    const int slice = (lid / tiles) % p.nsplit, prob = lid / (tiles * p.nsplit);
+    const float* Dp = p.D + (size_t)prob * p.dbs;
+    const float* Sp = p.S + (size_t)prob * p.sbs;
+    float* gp = p.g + (size_t)prob * p.gbs;
     const int mtile = tile % p.mt; tile /= p.mt;
     const int csb = tile % p.ncs; tile /= p.ncs;
     const int kh_ = tile % p.ntap_h, kt_ = tile / p.ntap_h;
@@ -783,7 +789,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         w0 = seg * BKP;
         row_d = ((n * p.T + t) * p.H + h) * p.W;
         const int ts = t * p.istr_t + p.ioff_t + kt_, hs = h * p.istr_h + p.ioff_h + kh_;
-        row_s = ((n * p.Ts + ts) * p.Hs + hs) * p.W;
+        row_s = ((n * p.Ts + ts) * p.Hs + hs) * p.Wsw;
         return (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
     };
     auto gload = [&](int c, int buf) -> bool {
@@ -794,14 +800,14 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         for (int i = wave; i < DI; i += 4) {                               // D tile: BKP rows x BM channels
             const int e = i * 64 + lane, r = e / (BM / 4), c4 = e % (BM / 4);
             const bool v = (w0 + r) < p.W && (m0 + c4 * 4) < p.Cd;
-            const float* src = v ? p.D + (size_t)(row_d + w0 + r) * p.ldd + m0 + c4 * 4 : g_zero16;
+            const float* src = v ? Dp + (size_t)(row_d + w0 + r) * p.ldd + m0 + c4 * 4 : g_zero16;
             glds16(src, ld + i * 256);
         }
-        for (int i = wave; i < SI; i += 4) {                               // S tile: positions w0-1 .. w0+BKP (+ padding rows)
+        for (int i = wave; i < SI; i += 4) {                               // S tile: positions w0-pad .. w0-pad+BKP+KW-2 (+ padding rows)
             const int e = i * 64 + lane, r = e / (CSB / 4), c4 = e % (CSB / 4);
-            const int w = w0 - 1 + r;
-            const bool v = r < BKP + 2 && (unsigned)w < (unsigned)p.W;
-            const float* src = v ? p.S + (size_t)(row_s + w) * p.lds + cs0 + c4 * 4 : g_zero16;
+            const int w = w0 - p.padw + r;
+            const bool v = r < BKP + KW - 1 && (unsigned)w < (unsigned)p.Wsw;
+            const float* src = v ? Sp + (size_t)(row_s + w) * p.lds + cs0 + c4 * 4 : g_zero16;
             glds16(src, ls + i * 256);
         }
         return true;
@@ -844,7 +850,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
         live = next_live;
     }
-    const int tapbase = ((kt_ + p.wk0_t) * p.KH + kh_ + p.wk0_h) * 3;     // + kw
+    const int tapbase = ((kt_ + p.wk0_t) * p.KH + kh_ + p.wk0_h) * KW;    // + kw
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -852,8 +858,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
             const int m = m0 + wm * (BM / WMW) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.Cd) continue;
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                atomicAdd(p.g + ((size_t)m * p.taps_full + tapbase + kwj[j]) * p.Cs + cs0 + csj[j], acc[i][j][r]);
+            for (int j = 0; j < TN; ++j) {
+                float* dst = gp + ((size_t)m * p.taps_full + tapbase + kwj[j]) * p.Cs + cs0 + csj[j];
+                if (p.store) *dst = acc[i][j][r];
+                else atomicAdd(dst, acc[i][j][r]);
+            }
         }
 }
 
@@ -888,29 +897,34 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // one LDS tile)
     static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
     const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
-    if (row_env && !abl && d->nbatch <= 1 && d->Td == 0 && d->splitk >= 0 && d->KW == 3 && d->ntap[2] == 3 && d->wk0[2] == 0 &&
-        d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 && d->ioff0[2] == -1 && d->Wq == d->Ws &&
-        (csb64 || csb32) && d->Ws % 28 == 0) {
+    const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
+    const bool row3 = d->KW == 3 && padw == 1 && d->Wq == d->Ws && (csb64 || csb32) && d->Ws % 28 == 0 && nprob == 1 && d->splitk >= 0;
+    const bool row9 = d->KW == 9 && padw == 0 && d->Wq == d->Ws - 8 && d->Wq == 20 && csb64 && d->Tq == 1 && d->Hq == 1;   // spectral forms
+    if (row_env && !abl && d->Td == 0 && d->ntap[2] == d->KW && d->wk0[2] == 0 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 &&
+        d->istep[2] == 1 && (row3 || row9)) {
         Wg3K q;
         q.D = D; q.S = S; q.g = g;
-        q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Ws; q.Cd = d->Cd; q.ldd = d->ldd; q.Cs = d->Cs; q.lds = d->lds;
+        q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Wq; q.Cd = d->Cd; q.ldd = d->ldd; q.Cs = d->Cs; q.lds = d->lds;
         q.Ts = d->Ts; q.Hs = d->Hs; q.istr_t = d->istr[0]; q.istr_h = d->istr[1]; q.ioff_t = d->ioff0[0]; q.ioff_h = d->ioff0[1];
         q.ntap_t = d->ntap[0]; q.ntap_h = d->ntap[1]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
-        q.taps_full = d->KT * d->KH * 3;
-        const bool small_m = d->Cd <= 64;
-        const int bkp = (csb64 && small_m && d->Ws % 56 == 0) ? 56 : 28;
-        q.nseg = d->Ws / bkp;
+        q.taps_full = d->KT * d->KH * d->KW;
+        q.Wsw = d->Ws; q.padw = padw; q.nprob = nprob; q.dbs = d->dbstride; q.sbs = d->sbstride; q.gbs = d->gbstride;
+        const bool small_m = d->Cd <= 64 || row9;
+        const int bkp = row9 ? 20 : ((csb64 && small_m && d->Ws % 56 == 0) ? 56 : 28);
+        q.nseg = d->Wq / bkp;
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
         q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / (csb64 ? 64 : 32);
         const int64_t tiles = (int64_t)q.mt * q.ncs * q.ntap_t * q.ntap_h;
-        int splitk = d->splitk > 0 ? d->splitk : (int)(2 * (bkp == 56 ? 512 : 768) / tiles);
+        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(2 * (bkp == 56 ? 512 : 768) / (tiles * nprob)));
         const int maxsplit = q.nchunks / 8 > 0 ? q.nchunks / 8 : 1;
         if (splitk > maxsplit) splitk = maxsplit;
         if (splitk < 1) splitk = 1;
         q.chunks_per_split = cdiv(q.nchunks, splitk);
         q.nsplit = cdiv(q.nchunks, q.chunks_per_split);
-        const dim3 grid((unsigned)(tiles * q.nsplit));
-        if (!csb64) hipLaunchKernelGGL((wgrad3_kernel<128, 28, 32, 4>), grid, dim3(256), 0, s, q);
+        q.store = d->splitk == -1;
+        const dim3 grid((unsigned)(tiles * q.nsplit * nprob));
+        if (row9) hipLaunchKernelGGL((wgrad3_kernel<64, 20, 64, 2, 9>), grid, dim3(256), 0, s, q);
+        else if (!csb64) hipLaunchKernelGGL((wgrad3_kernel<128, 28, 32, 4>), grid, dim3(256), 0, s, q);
         else if (small_m && bkp == 56) hipLaunchKernelGGL((wgrad3_kernel<64, 56, 64, 2>), grid, dim3(256), 0, s, q);
         else if (small_m) hipLaunchKernelGGL((wgrad3_kernel<64, 28, 64, 2>), grid, dim3(256), 0, s, q);
         else hipLaunchKernelGGL((wgrad3_kernel<128, 28, 64, 2>), grid, dim3(256), 0, s, q);

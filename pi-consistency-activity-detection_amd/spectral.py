@@ -163,7 +163,9 @@ class Layout:
     def wgrad(self):
         """dV[g] [Co][KY][Ci] = dT[g]^T . X[g] for every group in ONE launch (blockIdx.z = g): K is only the N*OH rows
         of one plane (10 chunks at bs=8), so one slice each, plain stores, no zero-fill."""
-        d = D.wgrad(self.N, (1, self.OH, 1), self.Co, self.Co, (1, self.H, 1), self.Ci, self.Ci, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+        # the rows of a plane are described as the w axis (memory is the same: one position per (n, row)), which is what the
+        # row-segment wgrad kernel shares its LDS tile along: the KY taps read one tile of OH + KY - 1 rows
+        d = D.wgrad(self.N, (1, 1, self.OH), self.Co, self.Co, (1, 1, self.H), self.Ci, self.Ci, (1, 1, self.KY), (1, 1, 1), (0, 0, 0),
                     splitk=-1)
         d.update(nbatch=self.G, dbstride=self.t_g, sbstride=self.x_g, gbstride=self.w_g)
         return d
@@ -220,7 +222,7 @@ class LayoutT:
         return d
 
     def wgrad(self):
-        d = D.wgrad(self.N, (1, self.H, 1), self.Ci, self.Ci, (1, self.OH, 1), self.Co, self.Co, (1, self.KY, 1), (1, 1, 1), (0, 0, 0),
+        d = D.wgrad(self.N, (1, 1, self.H), self.Ci, self.Ci, (1, 1, self.OH), self.Co, self.Co, (1, 1, self.KY), (1, 1, 1), (0, 0, 0),
                     splitk=-1)
         d.update(nbatch=self.G, dbstride=self.x_g, sbstride=self.t_g, gbstride=self.w_g)
         return d
