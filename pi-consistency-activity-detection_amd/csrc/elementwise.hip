@@ -8,11 +8,12 @@ namespace {
 
 // ------------------------------------------------------------------------------ BN forward
 // part [groups][npg][2][C]; stat [groups][4][C] = mean, invstd, scale, shift.
-constexpr int FIN_RL = 16;   // row lanes of the partial-sum finalize kernels (1024-thread blocks)
+constexpr int FIN_RL = 64;   // row lanes of the partial-sum finalize kernels (1024-thread blocks)
+constexpr int FIN_CL = 16;   // channels per block: C / 16 blocks, so that even the 64-channel layers spread over a few CUs
 
-// sum over partial rows [npg][2][C] for 64 channels; result valid on threads with rl == 0
+// sum over partial rows [npg][2][C] for FIN_CL channels; result valid on threads with rl == 0
 __device__ __forceinline__ void partial_colsum(const float* __restrict__ part, int npg, int C, int c, int rl,
-                                               double (*sh)[FIN_RL][64], int cl, double& s, double& s2) {
+                                               double (*sh)[FIN_RL][FIN_CL], int cl, double& s, double& s2) {
     double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (c < C) {
         int i = rl;
@@ -27,8 +28,14 @@ __device__ __forceinline__ void partial_colsum(const float* __restrict__ part, i
     sh[0][rl][cl] = a0 + a1; sh[1][rl][cl] = b0 + b1;
     __syncthreads();
     s = 0; s2 = 0;
+    if (rl < 8) {            // two levels: 8 row lanes sum 8 rows each, lane 0 sums those
+        double t = 0, t2 = 0;
+        for (int r = rl * (FIN_RL / 8); r < (rl + 1) * (FIN_RL / 8); ++r) { t += sh[0][r][cl]; t2 += sh[1][r][cl]; }
+        sh[0][rl * (FIN_RL / 8)][cl] = t; sh[1][rl * (FIN_RL / 8)][cl] = t2;
+    }
+    __syncthreads();
     if (rl == 0)
-        for (int r = 0; r < FIN_RL; ++r) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
+        for (int r = 0; r < FIN_RL; r += FIN_RL / 8) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
     __syncthreads();
 }
 
@@ -36,9 +43,9 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                                            int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float mom,
                                                            float* rmean, float* rvar, float* __restrict__ stat) {
-    __shared__ double sh[2][FIN_RL][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double sh[2][FIN_RL][FIN_CL];
+    const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
+    const int c = blockIdx.x * FIN_CL + cl;
     float rm = 0.f, rv = 0.f;
     const bool upd = (rmean != nullptr) && c < C && rl == 0;
     if (upd) { rm = rmean[c]; rv = rvar[c]; }
@@ -154,9 +161,9 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
 __global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
                                                                double count, float* coef, float* dgamma, float* dbeta,
                                                                int accum) {
-    __shared__ double sh[2][FIN_RL][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double sh[2][FIN_RL][FIN_CL];
+    const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
+    const int c = blockIdx.x * FIN_CL + cl;
     double tg = 0.0, tb = 0.0;
     for (int g = 0; g < groups; ++g) {
         double s, s2;
@@ -201,9 +208,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 // partial [nblk][2][C] -> dbias (+)=
 __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
-    __shared__ double sh[2][FIN_RL][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double sh[2][FIN_RL][FIN_CL];
+    const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
+    const int c = blockIdx.x * FIN_CL + cl;
     double s, s2;
     partial_colsum(part, nblk, C, c, rl, sh, cl, s, s2);
     if (rl == 0 && c < C) out[c] = (accum ? out[c] : 0.f) + (float)s;
@@ -447,7 +454,7 @@ extern "C" int pc_bn_finalize(const float* part, int nparts_per_group, int group
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* stat, pc_stream s) {
     PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
                        (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
     PC_CHECK_LAUNCH("bn_finalize");
     return PC_OK;
@@ -494,7 +501,7 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg, groups), dim3(256), 0, s, p);
     }
     PC_CHECK_LAUNCH("bn_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
     const int64_t total4 = rows * (C / 4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, z, ldz, stat, coef, C / 4, total4, rpg, relu, dz, lddz);
     PC_CHECK_LAUNCH("bn_bwd apply");
@@ -545,7 +552,7 @@ extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, in
         p.rows_per_block = rpb; p.act = act; p.part = ws;
         p.a_gs = p.b_gs = p.stat_gs = p.part_gs = 0;
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, s, ws, nblk, C, dbias, accum);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, s, ws, nblk, C, dbias, accum);
     }
     if (dz && (act != PC_ACT_NONE || dz != dy)) {
         PC_CHECK_ARG(lddz % 4 == 0, "pc_act_bwd: lddz");

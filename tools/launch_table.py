@@ -45,6 +45,12 @@ def main():
         if op[0] != capi.OP_WGRAD:
             return 1
         d = unflat(op[1], D.WGRAD_FIELDS)
+        padw = -d["ioff0"][2]
+        row3 = (d["KW"] == 3 and padw == 1 and d["Wq"] == d["Ws"] and (d["Cs"] % 64 == 0 or (d["Cs"] % 32 == 0 and d["Cd"] > 64))
+                and d["Ws"] % 28 == 0 and d.get("nbatch", 0) <= 1 and d.get("splitk", 0) >= 0)
+        row9 = d["KW"] == 9 and padw == 0 and d["Wq"] == 20 and d["Ws"] == 28 and d["Cs"] % 64 == 0 and d["Tq"] == 1 and d["Hq"] == 1
+        if (row3 or row9) and d.get("Td", 0) == 0 and d["ntap"][2] == d["KW"] and d["istr"][2] == 1 and d["istep"] == [1, 1, 1]:
+            return 1        # row-segment kernel: one launch
         full, rem = d["Cd"] // 128 * 128, d["Cd"] % 128
         ntot = d["ntap"][0] * d["ntap"][1] * d["ntap"][2] * d["Cs"]
         deep = (full // 128) * -(-ntot // 128) * max(1, d.get("nbatch", 0)) >= 1024
