@@ -251,6 +251,6 @@ class InceptionI3d(nn.Module):
             outs = []
             for nm in ("trunk_out", "conv1.Conv3d_2c_3x3.y", "conv1.Conv3d_1a_7x7.y"):
                 t = p.named[nm]
-                v = s.view(t.ref, t.rows * t.ld).view(t.N, *t.thw, t.ld)[..., :t.C]
+                v = s.view(t.ref, (t.rows - 1) * t.ld + t.C).as_strided((t.rows, t.C), (t.ld, 1)).view(t.N, *t.thw, t.C)   # a channel slice
                 outs.append(v.permute(0, 4, 1, 2, 3).clone())
         return tuple(outs)

@@ -77,18 +77,39 @@ class Plan:
         self.named = {}           # name -> TR / ref for host access
         # flat parameter layout (reference order / layout)
         self.pshape = spec.param_shapes(num_classes)
+        # the three 1x1x1 Unit3Ds of an Inception module that read the module input (b1a, b2a, b0) run as ONE conv + BN
+        # over their stacked output channels (unit3d with several prefixes): their BN parameters and running statistics
+        # sit next to each other in the flat buffers, in that order.  Names and shapes are the reference's; only the
+        # offsets inside the flat buffers differ from nn.Module.parameters() order.
+        self.fuse_1x1 = os.environ.get("PICONS_FUSE1X1", "1") != "0"
+        self.fused_groups = ([["conv1.%s.%s" % (ent[0], b) for b in ("b1a", "b2a", "b0")] for ent in spec.TRUNK if ent[1] == "mixed"]
+                             if self.fuse_1x1 else [])
+        head = {g[2] + ".conv3d.weight": g for g in self.fused_groups}      # b0 comes first in reference order
+        grouped = {pre + sfx for g in self.fused_groups for pre in g for sfx in (".conv3d.weight", ".bn.weight", ".bn.bias")}
+        order = []
+        for k in self.pshape:
+            if k in head:
+                order += [pre + sfx for sfx in (".conv3d.weight", ".bn.weight", ".bn.bias") for pre in head[k]]
+            elif k not in grouped:
+                order.append(k)
+        assert sorted(order) == sorted(self.pshape)
         self.poff = {}
         o = 0
-        for k, shp in self.pshape.items():
+        for k in order:
             self.poff[k] = o
-            o += int(np.prod(shp))
+            o += int(np.prod(self.pshape[k]))
             o = (o + 3) // 4 * 4       # keep every tensor 16-byte aligned
         self.nparams = o
         self.roff = {}
         o = 0
-        for pre, _ci, co, _k, _s in spec.trunk_units():
-            self.roff[pre + ".bn.running_mean"] = o; o += co
-            self.roff[pre + ".bn.running_var"] = o; o += co
+        units = {pre: co for pre, _ci, co, _k, _s in spec.trunk_units()}
+        rgroup = {g[2]: g for g in self.fused_groups}
+        rskip = {pre for g in self.fused_groups for pre in g}
+        for pre in units:
+            for grp in ([rgroup[pre]] if pre in rgroup else ([] if pre in rskip else [[pre]])):
+                for stat in (".bn.running_mean", ".bn.running_var"):
+                    for q in grp:
+                        self.roff[q + stat] = o; o += units[q]
         self.nrunning = o
         # kernel-layout weight-gradient buffers (wgrad accumulates into them with atomics) live in ONE region so a
         # single fill zeroes them all each step; their total size is the parameter count plus channel padding
@@ -159,14 +180,17 @@ class Plan:
         if x.name not in self.grads:
             base = self.named[x.name]
             g = TR(self.alloc(base.rows * base.ld), base.N, base.thw, base.ld, base.ld, "d_" + x.name)
-            self.grads[x.name] = [g, False]
-        g, init = self.grads[x.name]
-        self.grads[x.name][1] = True
+            self.grads[x.name] = [g, {}]
+        g, written = self.grads[x.name]
         delta = x.ref[1] - self.named[x.name].ref[1]
+        # first writer of a channel slice overwrites, later ones accumulate (slices of one buffer that are written
+        # separately - the module output and the b1a / b2a intermediates ahead of it - never overlap)
+        init = written.get((delta, x.C), False)
+        written[(delta, x.C)] = True
         return TR((g.ref[0], g.ref[1] + delta), x.N, x.thw, x.C, x.ld, g.name), init
 
     def grad_of(self, y):
-        if y.name not in self.grads or not self.grads[y.name][1]:
+        if y.name not in self.grads or not self.grads[y.name][1]:       # no slice written yet
             raise RuntimeError("gradient of %s requested before any consumer wrote it" % y.name)
         g = self.grads[y.name][0]
         delta = y.ref[1] - self.named[y.name].ref[1]
@@ -256,11 +280,23 @@ class Plan:
         self.emit(capi.OP_CONV, i=D.flatten(D.trim_conv(d), D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
 
     def unit3d(self, pre, x, cout, k, stride, out=None, need_dx=True):
-        """Unit3D (pytorch_i3d.py:89-120): SAME conv (no bias) -> BN(train) -> ReLU."""
+        """Unit3D (pytorch_i3d.py:89-120): SAME conv (no bias) -> BN(train) -> ReLU.
+        pre / cout may be lists: several Unit3Ds with the same kernel that read the same x run as ONE conv + BN + ReLU over
+        their stacked output channels (BN is per channel, so stacking is exact); their BN parameters and running
+        statistics must be adjacent in the flat buffers in that order (Plan.__init__ lays the fused groups out so)."""
+        pres, couts = ([pre], [cout]) if isinstance(pre, str) else (list(pre), list(cout))
+        pre, cout = pres[0], sum(couts)
+        for tab, sfxs in ((self.poff, (".bn.weight", ".bn.bias")), (self.roff, (".bn.running_mean", ".bn.running_var"))):
+            for sfx in sfxs:
+                o = tab[pre + sfx]
+                for q, c in zip(pres, couts):
+                    if tab[q + sfx] != o:
+                        raise RuntimeError("stacked Unit3Ds need adjacent %s (%s)" % (sfx, q))
+                    o += c
         Ci = x.C
         othw = tuple(spec.same_out(x.thw[i], k[i], stride[i]) for i in range(3))
         pf = [spec.same_pad(x.thw[i], k[i], stride[i])[0] for i in range(3)]
-        w = self.prep_conv_weight([pre + ".conv3d.weight"], [cout], self.pshape[pre + ".conv3d.weight"][1], k, need_dx, Ipad=Ci)
+        w = self.prep_conv_weight([q + ".conv3d.weight" for q in pres], couts, self.pshape[pre + ".conv3d.weight"][1], k, need_dx, Ipad=Ci)
         z = self.tensor(x.N, othw, cout, pre + ".z")
         y = out if out is not None else self.tensor(x.N, othw, cout, pre + ".y")
         stat = self.alloc(self.groups * 4 * cout)
@@ -297,7 +333,7 @@ class Plan:
                 self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf)), D.WGRAD_FIELDS),
                           p=[dz.ref, x.ref, w["kg"]])
                 self.flush_grad(w)
-                self.mark_final(pre + ".bn.weight", pre + ".bn.bias")
+                self.mark_final(*[q + sfx for q in pres for sfx in (".bn.weight", ".bn.bias")])
             if need_dx and part in ("all", "B"):
                 dz = st["dz"]
                 dx, acc = self.grad_for_write(x)
@@ -327,11 +363,41 @@ class Plan:
         """InceptionModule (pytorch_i3d.py:123-154): four branches off x, channel-concatenated (free here:
         each branch's last BN-apply writes its slice of `out`).  The branches share nothing but x, so a
         multi-lane plan puts each on its own stream, forward and backward."""
-        out = self.tensor(x.N, x.thw, oc[0] + oc[2] + oc[4] + oc[5], pre + ".out")
         c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-        outer, self.tape = self.tape, []
         L = lambda j: j % self.lanes
         one = (1, 1, 1)
+        if self.fuse_1x1:
+            # b1a, b2a and b0 (the 1x1x1 Unit3Ds reading x) as ONE conv + BN + ReLU.  Its output [b1a | b2a | b0] is
+            # one contiguous channel range of a buffer that is `e` channels wider than the module output:
+            # [b1a b2a | b0 b1b b2b b3b]; the module output is the slice behind the two intermediates (ld = wide)
+            e = oc[1] + oc[3]
+            wide = self.tensor(x.N, x.thw, e + c3 + oc[5], pre + ".out")
+            out = wide.slice(e, c3 + oc[5])
+            outer, self.tape = self.tape, []
+            self.unit3d([pre + ".b1a", pre + ".b2a", pre + ".b0"], x, [oc[1], oc[3], oc[0]], one, one, out=wide.slice(0, e + oc[0]))
+            # the big 3x3x3 branch on lane 0, pool branch + the small 3x3x3 branch on lane 1 (measured best of four assignments)
+            self.fork()
+            self.lane = L(0)
+            self.unit3d(pre + ".b1b", wide.slice(0, oc[1]), oc[2], (3, 3, 3), one, out=out.slice(c1, oc[2]))
+            self.lane = L(1)
+            t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
+            self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
+            self.unit3d(pre + ".b2b", wide.slice(oc[1], oc[3]), oc[4], (3, 3, 3), one, out=out.slice(c2, oc[4]))
+            self.lane = 0
+            self.join()
+            (fused, b1b, pool, b3b, b2b), self.tape = self.tape, outer
+
+            def bwd_fused():
+                self.fork()
+                self.lane = L(0); b1b()
+                self.lane = L(1); b2b(); b3b()
+                self.lane = 0
+                self.join()
+                fused(); pool()          # the two writers of d(x), in order on lane 0
+            self.tape.append(bwd_fused)
+            return out
+        out = self.tensor(x.N, x.thw, oc[0] + oc[2] + oc[4] + oc[5], pre + ".out")
+        outer, self.tape = self.tape, []
         self.fork()
         self.lane = L(0)
         t1 = self.unit3d(pre + ".b1a", x, oc[1], one, one)
@@ -775,7 +841,7 @@ class Plan:
         missing = [k for k in self.pshape if k not in self.final_at]
         if missing:
             raise RuntimeError("no backward op finalises %s" % missing[:4])
-        names = list(self.pshape)
+        names = sorted(self.pshape, key=self.poff.get)       # flat-buffer order
         # inside a FORK..JOIN region the side lanes may still be writing: a bucket is ready after the JOIN
         snap, open_at = list(range(len(self.lists["bwd"]) + 1)), None
         for idx, op in enumerate(self.lists["bwd"]):

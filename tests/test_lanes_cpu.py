@@ -129,3 +129,30 @@ def test_prep_list_is_spread_over_lanes_at_resolve():
     # idempotent
     p.resolve({"A": 1 << 20, "P": 1 << 30, "G": 1 << 31, "M": 1 << 32, "V": 1 << 33, "R": 1 << 34})
     assert len(p.lists["prep"]) == len(lst)
+
+
+def test_flat_layout_groups_the_stacked_units(monkeypatch):
+    """Stacked 1x1x1 Unit3Ds (plan.inception) need their BN parameters and running statistics adjacent in the flat
+    buffers: same names and shapes as the reference order, every float covered exactly once, groups adjacent."""
+    p = _plan(1)
+    monkeypatch.setenv("PICONS_FUSE1X1", "0")
+    q = _plan(1)
+    assert list(p.pshape) == list(q.pshape) and p.nparams == q.nparams and p.nrunning == q.nrunning
+    assert list(q.poff) == list(q.pshape) and sorted(p.poff) == sorted(q.poff)
+    for tab, size in ((p.poff, lambda k: -(-int(__import__("numpy").prod(p.pshape[k])) // 4) * 4),
+                      (p.roff, lambda k: p.pshape[k.rsplit(".bn.", 1)[0] + ".bn.weight"][0])):
+        o = 0
+        for k in sorted(tab, key=tab.get):
+            assert tab[k] == o, k
+            o += size(k)
+    assert len(p.fused_groups) == 7
+    for grp in p.fused_groups:
+        for tab, sfxs in ((p.poff, (".bn.weight", ".bn.bias")), (p.roff, (".bn.running_mean", ".bn.running_var"))):
+            for sfx in sfxs:
+                o = tab[grp[0] + sfx]
+                for pre in grp:
+                    assert tab[pre + sfx] == o
+                    o += p.pshape[pre + ".bn.weight"][0]
+    # one conv / BN per group instead of three: 2 x 7 fewer convs forward
+    count = lambda pl, kind: sum(1 for op in pl.lists["fwd"] if op[0] == kind)
+    assert count(q, capi.OP_CONV) - count(p, capi.OP_CONV) == 14 and count(q, capi.OP_BN_APPLY) - count(p, capi.OP_BN_APPLY) == 14

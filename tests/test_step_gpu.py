@@ -200,3 +200,41 @@ def test_multi_lane_replay_matches_single_lane():
         assert rel < 2e-4, (stepid, rel)
     # (no Adam between the steps: its first update is sign-like, so fp32-noise-sized gradient differences
     # would turn into lr-sized parameter differences and the engines would legitimately drift apart)
+
+
+def test_stacked_1x1_units_match_separate_units(monkeypatch):
+    """The three 1x1x1 Unit3Ds of every Inception module that read the module input run as ONE conv + BN + ReLU over
+    their stacked channels, in a buffer wider than the module output (plan.inception).  Against an engine that keeps
+    them separate (PICONS_FUSE1X1=0): same outputs, scalars, running statistics and per-parameter gradients -- the flat
+    buffers are laid out differently, so everything is compared by name."""
+    args = pstep.default_args(bv=True, gv=True, n_frames=3, wt_cons=0.1)
+    monkeypatch.setenv("PICONS_FUSE1X1", "0")
+    e0 = pstep.StepEngine(args, bs=2, hw=112)
+    monkeypatch.setenv("PICONS_FUSE1X1", "1")
+    e1 = pstep.StepEngine(args, bs=2, hw=112)
+    assert not e0.plan.fused_groups and len(e1.plan.fused_groups) == 7
+    assert e0.plan.poff != e1.plan.poff and e0.plan.nparams == e1.plan.nparams
+    e1.load_state({k: v.cpu() for k, v in e0.state_dict().items()})
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, step=1, hw=112)
+    res = []
+    for eng in (e0, e1):
+        eng.stage(lab, unl, perm, drops)
+        eng.forward_backward(1, 0.01)
+        torch.cuda.synchronize()
+        res.append((eng.read_scalars(), [t.clone() for t in eng.outputs()]))
+    (s0, o0), (s1, o1) = res
+    for a, b in zip(o0, o1):
+        assert (a - b).abs().max().item() < 5e-5
+    for k in s0:
+        assert abs(s0[k] - s1[k]) <= 1e-5 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    sd0, sd1 = e0.state_dict(), e1.state_dict()
+    for k in sd0:
+        if "running_" in k:
+            assert torch.allclose(sd0[k], sd1[k], rtol=1e-6, atol=1e-7), k
+    num = den = 0.0
+    for k in e0.plan.pshape:
+        g0, g1 = e0.grad(k), e1.grad(k)
+        num += float((g0 - g1).double().pow(2).sum()); den += float(g0.double().pow(2).sum())
+        if ".bn." in k:          # BN gradients: sums over the same rows, reduced in the same order
+            assert torch.allclose(g0, g1, rtol=2e-4, atol=1e-6), k
+    assert (num / den) ** 0.5 < 2e-4
