@@ -242,6 +242,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
+    // VAR bit 2 (TAP4): Ci == 4 (the stem: 3 channels padded to one 16-byte piece per tap) - a K chunk is 8 consecutive taps of the
+    // tile's tap box instead of 32 channels of one tap, so every 16-byte DMA piece has its own tap (address, validity)
+    constexpr bool TAP4 = (VAR & 4) != 0;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
     const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
@@ -278,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     for (int j = 0; j < AR; ++j) {
         const int row = lrow + 32 * j;
         const int4 ri = ((int4*)rinfo)[row];
-        const int ks = (slot ^ ((row >> 1) & 7)) * 4;
+        const int ks = TAP4 ? 0 : (slot ^ ((row >> 1) & 7)) * 4;
         unsigned m = 0;
         if (ri.x >= 0) {
             for (int a = 0; a < p.ntap[0]; ++a) m |= ((unsigned)(ri.y + a * p.istep[0]) < (unsigned)p.Ti ? 1u : 0u) << a;
@@ -292,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int row = lrow + 32 * j, co = n0 + row;
-        const int ks = (slot ^ ((row >> 1) & 7)) * 4;
+        const int ks = TAP4 ? 0 : (slot ^ ((row >> 1) & 7)) * 4;
         bptr[j] = co < p.Co ? wbase + (size_t)co * p.wtaps * p.ldw + ks : nullptr;
     }
 
@@ -312,7 +315,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     const int b_lo = any_tap ? __builtin_ctz(bh) : 0, b_hi = any_tap ? 31 - __builtin_clz(bh) : -1;
     const int c_lo = any_tap ? __builtin_ctz(bw) : 0, c_hi = any_tap ? 31 - __builtin_clz(bw) : -1;
     int u_a = a_lo, u_b = b_lo, u_c = c_lo, u_ci = 0;
+    // TAP4: this thread's logical 16-byte slot of a chunk (the same for all its rows: the swizzle depends on lrow only)
+    // is tap (8 * chunk + ksl) of the box in (a, b, c) order
+    const int nb_ = b_hi - b_lo + 1, nc_ = c_hi - c_lo + 1;
+    int t_a = a_lo, t_b = b_lo, t_c = c_lo;
+    if (TAP4 && any_tap) {
+        const int ksl = slot ^ ((lrow >> 1) & 7);
+        t_c = c_lo + ksl % nc_;
+        const int r = ksl / nc_;
+        t_b = b_lo + r % nb_; t_a = a_lo + r / nb_;
+    }
     auto fetch = [&](int buf) {
+        if (TAP4) {
+            const bool inb = t_a <= a_hi;
+            const long long da = ((long long)(t_a * p.istep[0] * p.Hi + t_b * p.istep[1]) * p.Wi + t_c * p.istep[2]) * p.ldi;
+            const unsigned sel = inb ? ((1u << t_a) | (1u << (10 + t_b)) | (1u << (20 + t_c))) : 0xffffffffu;   // never matches out of the box
+            const int wtap = ((p.wk0[0] + t_a * p.wkstep[0]) * p.KH + p.wk0[1] + t_b * p.wkstep[1]) * p.KW + p.wk0[2] + t_c * p.wkstep[2];
+            const long long db = (long long)wtap * p.ldw;
+            float* la = As + buf * BM * BK + (wave * 8) * BK;
+            float* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+#pragma unroll
+            for (int j = 0; j < AR; ++j) {
+                const float* src = ((amask[j] & sel) == sel) ? aptr[j] + da : g_zero16;
+                glds16(src, la + j * 32 * BK);
+            }
+#pragma unroll
+            for (int j = 0; j < BR; ++j) {
+                const float* src = (bptr[j] && inb) ? bptr[j] + db : g_zero16;
+                glds16(src, lb + j * 32 * BK);
+            }
+            t_c += 8;
+            while (t_c > c_hi) { t_c -= nc_; if (++t_b > b_hi) { t_b = b_lo; ++t_a; } }
+            return;
+        }
         const long long da = ((long long)(u_a * p.istep[0] * p.Hi + u_b * p.istep[1]) * p.Wi + u_c * p.istep[2]) * p.ldi + u_ci;
         const unsigned sel = (1u << u_a) | (1u << (10 + u_b)) | (1u << (20 + u_c));
         const int wtap = ((p.wk0[0] + u_a * p.wkstep[0]) * p.KH + p.wk0[1] + u_b * p.wkstep[1]) * p.KW + p.wk0[2] + u_c * p.wkstep[2];
@@ -344,7 +379,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks = (a_hi - a_lo + 1) * (b_hi - b_lo + 1) * (c_hi - c_lo + 1) * (p.Ci / BK);
+    const int nchunks = TAP4 ? ((a_hi - a_lo + 1) * nb_ * nc_ + 7) / 8 : (a_hi - a_lo + 1) * nb_ * nc_ * (p.Ci / BK);
     if (nchunks > 0) fetch(0);
     __syncthreads();
     const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
@@ -496,6 +531,11 @@ int launch_conv(const ConvK& k, hipStream_t s) {
     }
     static const int no_glds = getenv("PICONS_CONV_NO_GLDS") ? atoi(getenv("PICONS_CONV_NO_GLDS")) : 0;
     const bool fast = k.Ci % BK == 0;
+    static const int no_tap4 = getenv("PICONS_CONV_NO_TAP4") ? atoi(getenv("PICONS_CONV_NO_TAP4")) : 0;
+    if constexpr (BM == 128 && BN == 64)
+        if (k.Ci == 4 && !no_glds && !no_tap4 && k.ntap[0] <= 10 && k.ntap[1] <= 10 && k.ntap[2] <= 10 && ((uintptr_t)k.in % 16 == 0) && k.ldi % 4 == 0 &&
+            k.ldw % 4 == 0)
+            return launch_conv_glds_v<BM, BN, WM, WN, 4>(k, s);
     if (fast && !no_glds && k.ntap[0] <= 10 && k.ntap[1] <= 10 && k.ntap[2] <= 10 && ((uintptr_t)k.in % 16 == 0) && k.ldi % 4 == 0)
         return launch_conv_glds<BM, BN, WM, WN>(k, s);
     return fast ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
@@ -503,7 +543,8 @@ int launch_conv(const ConvK& k, hipStream_t s) {
 
 // tile choice: minimise padded work, prefer larger tiles when the grid still fills the chip
 struct TileCfg { int bm, bn, wm; };
-inline TileCfg choose_tile(int Mg, int groups, int Co) {
+inline TileCfg choose_tile(int Mg, int groups, int Co, int Ci) {
+    if (Ci == 4) return {128, 64, 2};          // one 16-byte piece per tap: the 8-taps-per-chunk LDS-DMA variant has this tile only
     const TileCfg cand[] = {{128, 128, 2}, {128, 64, 2}, {64, 64, 2}, {128, 32, 4}};
     double best = 1e30; TileCfg bc = cand[0];
     for (const TileCfg& c : cand) {
@@ -525,7 +566,7 @@ inline TileCfg choose_tile(int Mg, int groups, int Co) {
 extern "C" int pc_conv_bnpart_rows(const pc_conv_desc* d) {
     const int groups = d->groups > 0 ? d->groups : 1;
     const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
-    const TileCfg c = choose_tile((int)Mg, groups, d->Co);
+    const TileCfg c = choose_tile((int)Mg, groups, d->Co, d->Ci);
     return groups * cdiv(Mg, c.bm) * c.wm;
 }
 
@@ -554,7 +595,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
     k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
-    TileCfg c = choose_tile(k.Mg, groups, d->Co);
+    TileCfg c = choose_tile(k.Mg, groups, d->Co, d->Ci);
     static const char* force = getenv("PICONS_CONV_TILE");      // diagnostic: "bm,bn" for grouped launches without BN partials
     if (force && groups > 2 && !(d->flags & PC_F_BNPART)) {
         int bm = 0, bn = 0;
@@ -909,7 +950,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.ntap_t = d->ntap[0]; q.ntap_h = d->ntap[1]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
         q.taps_full = d->KT * d->KH * d->KW;
         q.Wsw = d->Ws; q.padw = padw; q.nprob = nprob; q.dbs = d->dbstride; q.sbs = d->sbstride; q.gbs = d->gbstride;
-        const bool small_m = d->Cd <= 64 || row9;
+        // 64-row tiles also when they pad at least 20 % less than 128-row tiles (192 = 3 x 64 vs 2 x 128)
+        const bool small_m = d->Cd <= 64 || row9 || (csb64 && cdiv(d->Cd, 64) * 64 * 5 <= cdiv(d->Cd, 128) * 128 * 4);
         const int bkp = row9 ? 20 : ((csb64 && small_m && d->Ws % 56 == 0) ? 56 : 28);
         q.nseg = d->Wq / bkp;
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
