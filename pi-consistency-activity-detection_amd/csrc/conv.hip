@@ -936,6 +936,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // rows of D's channels [m_lo, m_hi) with 64- or 128-row tiles
     // conv with 3 taps, stride 1, padding 1 along w and 32- / 64-channel blocks of S: row-segment kernel (the kw taps share
     // one LDS tile)
+    // split-K fills `rounds` rounds of resident-block slots: one round measured best on the step (fewer atomics per weight;
+    // the second lane's launches fill what a single round leaves idle)
+    static const int rounds = getenv("PICONS_WGRAD_ROUNDS") ? atoi(getenv("PICONS_WGRAD_ROUNDS")) : 1;
     static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
     const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
     const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
@@ -957,7 +960,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
         q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / (csb64 ? 64 : 32);
         const int64_t tiles = (int64_t)q.mt * q.ncs * q.ntap_t * q.ntap_h;
-        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(2 * (bkp == 56 ? 512 : 768) / (tiles * nprob)));
+        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(rounds * (bkp == 56 ? 512 : 768) / (tiles * nprob)));
         const int maxsplit = q.nchunks / 8 > 0 ? q.nchunks / 8 : 1;
         if (splitk > maxsplit) splitk = maxsplit;
         if (splitk < 1) splitk = 1;
@@ -986,12 +989,12 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         const int nb = d->nbatch > 1 ? d->nbatch : 1;
         if (splitk == -1) splitk = 1;
         else if (splitk <= 0) {
-            // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill two full rounds of
-            // slots and never spill a few blocks into a third (1026 blocks ran ~25 % slower than 1022); at least
+            // resident blocks per CU follow the LDS footprint (64 KiB -> 2, 48 KiB -> 3): fill whole rounds of
+            // slots and never spill a few blocks into the next (1026 blocks ran ~25 % slower than 1022); at least
             // 8 chunks (256 positions) per slice
             const int64_t tiles = (int64_t)mt * ntl * nb;
             const int slots = (small_m || wide) ? 768 : 512;
-            splitk = (int)(2 * slots / tiles);
+            splitk = (int)(rounds * slots / tiles);
             const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
             if (splitk > maxsplit) splitk = maxsplit;
             if (splitk < 1) splitk = 1;
