@@ -907,6 +907,112 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         }
 }
 
+
+// ---- weight gradient of a 4-channel source with stride SW along w (the stem: 7x7x7, stride 2, 3 channels padded to 4) --------
+// One tap of 4 channels is one 16-byte piece, so the generic kernel gathers its S tile piece by piece (64 taps x 16 positions
+// = 1024 pieces per chunk, each input piece fetched ~3x per chunk).  Here the K chunk is a segment of BKP positions of ONE
+// output row, and a block owns ALL (kh, kw) taps of one kt: per kh one LDS row of SW*BKP + KW - 1 input pieces, fetched once.
+// Column n = kw*4 + cs of tap row kh for position k is LDS dword kh*ROW + 4*SW*k + n: 32 consecutive dwords per MFMA operand,
+// conflict-free.  (kw = KW..7 are padding columns, dropped at the store.)  Waves: 2 halves of the 64 channels of D x 2 k-step
+// parities, 7 (= KH) 32x32 accumulators each.  Chunks whose kt tap reads outside the volume along t are not enumerated at all,
+// and the K slices are dealt to the kt taps in proportion to their valid chunks.
+struct Wg4K {
+    const float* D; const float* S; float* g;
+    int N, T, H, W, Cd, ldd, lds;
+    int ntap_t, wk0_t, wk0_h, KH;
+    int Ts, Hs, Wsw, istr_t, istr_h, ioff_t, ioff_h, padw;
+    int nseg, mt, taps_full;
+    int pre[11];                               // slice prefix per kt (ntap_t + 1 entries)
+};
+
+template <int BKP, int KW, int SW, int NKH>
+__global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
+    constexpr int BM = 64;
+    constexpr int ROWP = SW * BKP + KW - 1;                  // pieces per kh row
+    static_assert(SW * (BKP - 1) + 7 < ROWP + 1, "padding columns stay inside the row");
+    constexpr int SPIECES = NKH * ROWP, SI = (SPIECES + 63) / 64, DI = BKP * BM * 4 / 1024;
+    static_assert((BKP * BM * 4) % 1024 == 0 && (BKP / 2) % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(16))) float Ds[2][BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ss[2][SI * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave & 1, wk = wave >> 1;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = lid % p.mt, sl = lid / p.mt;
+    int kt_ = 0;
+    while (kt_ + 1 < p.ntap_t && sl >= p.pre[kt_ + 1]) ++kt_;
+    const int slice = sl - p.pre[kt_], nsplit = p.pre[kt_ + 1] - p.pre[kt_];
+    // output t with a valid source t for this tap
+    int tlo = 0, thi = p.T - 1;
+    while (tlo <= thi && tlo * p.istr_t + p.ioff_t + kt_ < 0) ++tlo;
+    while (thi >= tlo && thi * p.istr_t + p.ioff_t + kt_ >= p.Ts) --thi;
+    const int ntv = thi - tlo + 1;
+    const int nchunks = p.N * ntv * p.H * p.nseg;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = slice * cps, c_end = min(nchunks, c_begin + cps);
+    if (c_begin >= c_end) return;
+    const int m0 = mtile * BM;
+
+    auto gload = [&](int c, int buf) {
+        const int seg = c % p.nseg; int r = c / p.nseg;
+        const int h = r % p.H; r /= p.H;
+        const int t = tlo + r % ntv; const int n = r / ntv;
+        const int w0 = seg * BKP;
+        const int row_d = ((n * p.T + t) * p.H + h) * p.W;
+        const int ts = t * p.istr_t + p.ioff_t + kt_, hs0 = h * p.istr_h + p.ioff_h;
+        float* ld = &Ds[buf][0][0];
+        float* ls = &Ss[buf][0];
+        for (int i = wave; i < DI; i += 4) {
+            const int e = i * 64 + lane, rr = e / (BM / 4), c4 = e % (BM / 4);
+            const bool v = (m0 + c4 * 4) < p.Cd;
+            const float* src = v ? p.D + (size_t)(row_d + w0 + rr) * p.ldd + m0 + c4 * 4 : g_zero16;
+            glds16(src, ld + i * 256);
+        }
+        for (int i = wave; i < SI; i += 4) {
+            const int e = i * 64 + lane, kh = e / ROWP, rr = e - kh * ROWP;
+            const int hs = hs0 + kh, w = w0 * SW - p.padw + rr;
+            const bool v = kh < NKH && (unsigned)hs < (unsigned)p.Hs && (unsigned)w < (unsigned)p.Wsw;
+            const float* src = v ? p.S + ((size_t)((n * p.Ts + ts) * p.Hs + hs) * p.Wsw + w) * p.lds : g_zero16;
+            glds16(src, ls + i * 256);
+        }
+    };
+
+    f32x16 acc[NKH];
+#pragma unroll
+    for (int j = 0; j < NKH; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+    const int nl = lane & 31, kh2 = lane >> 5, ml = wm * 32 + nl;
+    gload(c_begin, 0);
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) gload(c + 1, buf ^ 1);
+        const float* sb = &Ss[buf][0];
+#pragma unroll
+        for (int q = 0; q < BKP / 4; ++q) {
+            const int pp = (2 * q + wk) * 2 + kh2;
+            const float af = Ds[buf][pp][ml];
+            float bf[NKH];
+#pragma unroll
+            for (int j = 0; j < NKH; ++j) bf[j] = sb[j * ROWP * 4 + 4 * SW * pp + nl];
+#pragma unroll
+            for (int j = 0; j < NKH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    if (nl >= KW * 4) return;                  // padding columns
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m >= p.Cd) continue;
+#pragma unroll
+        for (int j = 0; j < NKH; ++j) {
+            const int tap = ((kt_ + p.wk0_t) * p.KH + j + p.wk0_h) * KW;
+            atomicAdd(p.g + ((size_t)m * p.taps_full + tap) * 4 + nl, acc[j][r]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s_) {
@@ -938,7 +1044,42 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // one LDS tile)
     // split-K fills `rounds` rounds of resident-block slots: one round measured best on the step (fewer atomics per weight;
     // the second lane's launches fill what a single round leaves idle)
-    static const int rounds = getenv("PICONS_WGRAD_ROUNDS") ? atoi(getenv("PICONS_WGRAD_ROUNDS")) : 1;
+    static const double rounds = getenv("PICONS_WGRAD_ROUNDS") ? atof(getenv("PICONS_WGRAD_ROUNDS")) : 1.0;
+    static const int s4_env = getenv("PICONS_WGRAD_STEM") ? atoi(getenv("PICONS_WGRAD_STEM")) : 1;
+    if (s4_env && d->Cs == 4 && d->lds % 4 == 0 && d->KW == 7 && d->ntap[2] == 7 && d->wk0[2] == 0 && d->istr[2] == 2 && d->ntap[1] == 7 &&
+        d->ntap[0] <= 10 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 && d->Td == 0 && d->nbatch <= 1 && d->splitk >= 0 &&
+        d->Wq % 28 == 0 && !getenv("PICONS_WGRAD_ABLATE")) {
+        Wg4K q;
+        q.D = D; q.S = S; q.g = g;
+        q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Wq; q.Cd = d->Cd; q.ldd = d->ldd; q.lds = d->lds;
+        q.ntap_t = d->ntap[0]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
+        q.Ts = d->Ts; q.Hs = d->Hs; q.Wsw = d->Ws; q.istr_t = d->istr[0]; q.istr_h = d->istr[1]; q.ioff_t = d->ioff0[0]; q.ioff_h = d->ioff0[1];
+        q.padw = -d->ioff0[2];
+        q.nseg = d->Wq / 28; q.mt = cdiv(d->Cd, 64); q.taps_full = d->KT * d->KH * d->KW;
+        // K slices per kt in proportion to the output t planes whose source plane exists
+        int ntv[10], tot = 0;
+        for (int a = 0; a < q.ntap_t; ++a) {
+            int cnt = 0;
+            for (int t = 0; t < d->Tq; ++t) { const int ts = t * q.istr_t + q.ioff_t + a; cnt += ts >= 0 && ts < d->Ts; }
+            ntv[a] = cnt; tot += cnt;
+        }
+        PC_CHECK_ARG(tot > 0, "pc_conv_wgrad: no valid tap");
+        static const int s4_slots = getenv("PICONS_WGRAD_STEM_SLOTS") ? atoi(getenv("PICONS_WGRAD_STEM_SLOTS")) : 768;   // 162 VGPRs, 28 KiB LDS: 3 blocks per CU
+        const int slots = d->splitk > 0 ? d->splitk * q.ntap_t : s4_slots / q.mt;
+        q.pre[0] = 0;
+        for (int a = 0; a < q.ntap_t; ++a) {
+            int sl = ntv[a] ? (int)((double)slots * ntv[a] / tot) : 0;
+            const int64_t nch = (int64_t)d->N * ntv[a] * d->Hq * q.nseg;
+            if (ntv[a] && sl < 1) sl = 1;
+            if (sl > nch / 4 && nch >= 4) sl = (int)(nch / 4);
+            if (ntv[a] && sl < 1) sl = 1;
+            q.pre[a + 1] = q.pre[a] + sl;
+        }
+        const dim3 grid((unsigned)(q.pre[q.ntap_t] * q.mt));
+        hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7>), grid, dim3(256), 0, s, q);
+        PC_CHECK_LAUNCH("wgrad4_kernel");
+        return PC_OK;
+    }
     static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
     const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
     const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;

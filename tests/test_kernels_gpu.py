@@ -50,6 +50,8 @@ def w_iko(w):
 CONV_CASES = [
     (16, 24, (3, 3, 3), (2, 1, 1), (4, 12, 12), 2),
     (4, 64, (7, 7, 7), (2, 2, 2), (8, 30, 30), 2),
+    (4, 64, (7, 7, 7), (2, 2, 2), (8, 12, 56), 2),        # stem shape with 28-position row segments: wgrad4_kernel, 8-tap LDS-DMA conv
+    (4, 24, (7, 7, 7), (2, 2, 2), (5, 9, 112), 1),        # fewer than 64 output channels, odd extents along t / h
     (64, 16, (1, 1, 1), (1, 1, 1), (2, 9, 9), 3),
     (32, 200, (3, 3, 3), (1, 1, 1), (2, 14, 14), 2),
     (48, 136, (1, 3, 3), (1, 1, 1), (1, 20, 20), 4),
