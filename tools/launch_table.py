@@ -39,7 +39,7 @@ def main():
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"]]
+    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad4_kernel" in r["Kernel_Name"]]
     def n_kernels(op):
         """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (csrc/conv.hip)."""
         if op[0] != capi.OP_WGRAD:
