@@ -279,16 +279,21 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const pc_pool_desc d, 
         const int h = (int)(pos % d.Hi); pos /= d.Hi;
         const int t = (int)(pos % d.Ti); const int n = (int)(pos / d.Ti);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
-        int tap = 0;
-        for (int a = 0; a < d.k[0]; ++a) {
-            const int tn = t + d.padf[0] - a;
-            for (int b = 0; b < d.k[1]; ++b) {
-                const int hn = h + d.padf[1] - b;
-                for (int cc = 0; cc < d.k[2]; ++cc, ++tap) {
-                    const int wn = w + d.padf[2] - cc;
-                    if (tn < 0 || hn < 0 || wn < 0 || tn % d.s[0] || hn % d.s[1] || wn % d.s[2]) continue;
-                    const int to = tn / d.s[0], ho = hn / d.s[1], wo = wn / d.s[2];
-                    if (to >= d.To || ho >= d.Ho || wo >= d.Wo) continue;
+        // windows that cover this input position: per dimension the outputs o with 0 <= x + padf - o*s < k
+        int lo[3], hi[3];
+        const int xs[3] = {t, h, w}, Os[3] = {d.To, d.Ho, d.Wo};
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+            const int top = xs[q] + d.padf[q], bot = top - d.k[q] + 1;
+            hi[q] = min(top / d.s[q], Os[q] - 1);
+            lo[q] = bot <= 0 ? 0 : (bot + d.s[q] - 1) / d.s[q];
+        }
+        for (int to = lo[0]; to <= hi[0]; ++to) {
+            const int a = t + d.padf[0] - to * d.s[0];
+            for (int ho = lo[1]; ho <= hi[1]; ++ho) {
+                const int b = h + d.padf[1] - ho * d.s[1];
+                for (int wo = lo[2]; wo <= hi[2]; ++wo) {
+                    const int tap = (a * d.k[1] + b) * d.k[2] + (w + d.padf[2] - wo * d.s[2]);
                     const size_t op = (size_t)((n * d.To + to) * d.Ho + ho) * d.Wo + wo;
                     const uchar4 ix = *(const uchar4*)(am + op * d.C + c);
                     const f32x4 v = *(const f32x4*)(dy + op * d.ldo + c);
