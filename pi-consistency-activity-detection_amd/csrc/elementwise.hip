@@ -83,15 +83,15 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                                                        int ldy, int relu) {
     const int C = C4 * 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        const int64_t row = idx / C4;
-        const int c = (int)(idx - row * C4) * 4;
-        const float* st = stat + (size_t)(row / rows_per_group) * 4 * C;
-        const f32x4 v = *(const f32x4*)(z + row * ldz + c);
+        const unsigned row = (unsigned)idx / (unsigned)C4;          // total4 < 2^31 (checked by the caller): 32-bit index math
+        const int c = (int)((unsigned)idx - row * C4) * 4;
+        const float* st = stat + (size_t)(row / (unsigned)rows_per_group) * 4 * C;
+        const f32x4 v = *(const f32x4*)(z + (size_t)row * ldz + c);
         const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh = *(const f32x4*)(st + 3 * C + c);
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { const float t = v[e] * sc[e] + sh[e]; o[e] = relu ? fmaxf(t, 0.f) : t; }
-        *(f32x4*)(y + row * ldy + c) = o;
+        *(f32x4*)(y + (size_t)row * ldy + c) = o;
     }
 }
 
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
             const f32x4 dy = *(const f32x4*)(p.a + r * p.lda + c);
             const f32x4 zz = *(const f32x4*)(p.b + r * p.ldb + c);
             if (MODE == 0) {
-                const float* st = p.stat + (size_t)(r / p.rows_per_group) * 4 * C;
+                const float* st = p.stat;              // one batch group per blockIdx.y (p.rows == p.rows_per_group)
                 const f32x4 mean = *(const f32x4*)(st + c), inv = *(const f32x4*)(st + C + c);
                 const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh_ = *(const f32x4*)(st + 3 * C + c);
 #pragma unroll
@@ -186,12 +186,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            float* __restrict__ dz, int lddz) {
     const int C = C4 * 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        const int64_t row = idx / C4;
-        const int c = (int)(idx - row * C4) * 4;
-        const int g = (int)(row / rows_per_group);
+        const unsigned row = (unsigned)idx / (unsigned)C4;
+        const int c = (int)((unsigned)idx - row * C4) * 4;
+        const int g = (int)(row / (unsigned)rows_per_group);
         const float* st = stat + (size_t)g * 4 * C;
         const float* cf = coef + (size_t)g * 2 * C;
-        const f32x4 d = *(const f32x4*)(dy + row * lddy + c), zz = *(const f32x4*)(z + row * ldz + c);
+        const f32x4 d = *(const f32x4*)(dy + (size_t)row * lddy + c), zz = *(const f32x4*)(z + (size_t)row * ldz + c);
         const f32x4 mean = *(const f32x4*)(st + c), inv = *(const f32x4*)(st + C + c);
         const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh_ = *(const f32x4*)(st + 3 * C + c);
         const f32x4 c1 = *(const f32x4*)(cf + c), c2 = *(const f32x4*)(cf + C + c);
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float dd = (relu && !(yv > 0.f)) ? 0.f : d[e];
             o[e] = sc[e] * (dd - c1[e] - (zz[e] - mean[e]) * inv[e] * c2[e]);
         }
-        *(f32x4*)(dz + row * lddz + c) = o;
+        *(f32x4*)(dz + (size_t)row * lddz + c) = o;
     }
 }
 
@@ -219,8 +219,8 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
 __global__ __launch_bounds__(256) void act_bwd_apply_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ y, int ldy,
                                                             int act, int C4, int64_t total4, float* __restrict__ dz, int lddz) {
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        const int64_t row = idx / C4;
-        const int c = (int)(idx - row * C4) * 4;
+        const size_t row = (unsigned)idx / (unsigned)C4;
+        const int c = (int)((unsigned)idx - (unsigned)row * C4) * 4;
         const f32x4 d = *(const f32x4*)(dy + row * lddy + c), yy = *(const f32x4*)(y + row * ldy + c);
         f32x4 o;
 #pragma unroll
@@ -239,12 +239,12 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const pc_pool_desc d, 
                                                           uint8_t* __restrict__ am, int64_t total4) {
     const int C4 = d.C / 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        int64_t pos = idx / C4;
-        const int c = (int)(idx - pos * C4) * 4;
-        const int64_t opos = pos;
-        const int wo = (int)(pos % d.Wo); pos /= d.Wo;
-        const int ho = (int)(pos % d.Ho); pos /= d.Ho;
-        const int to = (int)(pos % d.To); const int n = (int)(pos / d.To);
+        unsigned pos = (unsigned)idx / (unsigned)C4;
+        const int c = (int)((unsigned)idx - pos * C4) * 4;
+        const size_t opos = pos;
+        const int wo = (int)(pos % (unsigned)d.Wo); pos /= (unsigned)d.Wo;
+        const int ho = (int)(pos % (unsigned)d.Ho); pos /= (unsigned)d.Ho;
+        const int to = (int)(pos % (unsigned)d.To); const int n = (int)(pos / (unsigned)d.To);
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {255, 255, 255, 255};
         int tap = 0;
@@ -272,12 +272,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const pc_pool_desc d, 
                                                           float* __restrict__ dx, int accum, int64_t total4) {
     const int C4 = d.C / 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        int64_t pos = idx / C4;
-        const int c = (int)(idx - pos * C4) * 4;
-        const int64_t ipos = pos;
-        const int w = (int)(pos % d.Wi); pos /= d.Wi;
-        const int h = (int)(pos % d.Hi); pos /= d.Hi;
-        const int t = (int)(pos % d.Ti); const int n = (int)(pos / d.Ti);
+        unsigned pos = (unsigned)idx / (unsigned)C4;
+        const int c = (int)((unsigned)idx - pos * C4) * 4;
+        const size_t ipos = pos;
+        const int w = (int)(pos % (unsigned)d.Wi); pos /= (unsigned)d.Wi;
+        const int h = (int)(pos % (unsigned)d.Hi); pos /= (unsigned)d.Hi;
+        const int t = (int)(pos % (unsigned)d.Ti); const int n = (int)(pos / (unsigned)d.Ti);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // windows that cover this input position: per dimension the outputs o with 0 <= x + padf - o*s < k
         int lo[3], hi[3];
@@ -315,9 +315,9 @@ __global__ __launch_bounds__(256) void chscale_kernel(const float* __restrict__ 
                                                       int C4, int64_t total4, float* __restrict__ y, int ldy, int accum) {
     const int C = C4 * 4;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total4; idx += (int64_t)gridDim.x * 256) {
-        const int64_t row = idx / C4;
-        const int c = (int)(idx - row * C4) * 4;
-        const int64_t n = row / pos_per_n;
+        const size_t row = (unsigned)idx / (unsigned)C4;
+        const int c = (int)((unsigned)idx - (unsigned)row * C4) * 4;
+        const size_t n = (unsigned)row / (unsigned)pos_per_n;
         const f32x4 v = *(const f32x4*)(x + row * ldx + c), s = *(const f32x4*)(sc + n * C + c);
         f32x4 o = v * s;
         float* q = y + row * ldy + c;
@@ -477,6 +477,7 @@ extern "C" int pc_bn_apply(const float* z, int ldz, const float* stat, int C, in
                            int relu, pc_stream s) {
     PC_CHECK_ARG(z && stat && y && C % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && groups >= 1 && rows % groups == 0, "pc_bn_apply: bad args (C=%d)", C);
     const int64_t total4 = rows * (C / 4);
+    PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, (hipStream_t)s, z, ldz, stat, C / 4, total4, rows / groups, y, ldy, relu);
     PC_CHECK_LAUNCH("bn_apply");
     return PC_OK;
@@ -508,6 +509,7 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
     PC_CHECK_LAUNCH("bn_bwd reduce");
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
     const int64_t total4 = rows * (C / 4);
+    PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, z, ldz, stat, coef, C / 4, total4, rpg, relu, dz, lddz);
     PC_CHECK_LAUNCH("bn_bwd apply");
     return PC_OK;
@@ -517,6 +519,7 @@ extern "C" int pc_maxpool_fwd(const pc_pool_desc* d, const float* x, float* y, u
     PC_CHECK_ARG(d && x && y && argmax && d->C % 4 == 0 && d->ldi % 4 == 0 && d->ldo % 4 == 0, "pc_maxpool_fwd: bad args");
     PC_CHECK_ARG(d->k[0] * d->k[1] * d->k[2] < 255, "pc_maxpool_fwd: window too large");
     const int64_t total4 = (int64_t)d->N * d->To * d->Ho * d->Wo * (d->C / 4);
+    PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, x, y, argmax, total4);
     PC_CHECK_LAUNCH("maxpool_fwd");
     return PC_OK;
@@ -525,6 +528,7 @@ extern "C" int pc_maxpool_fwd(const pc_pool_desc* d, const float* x, float* y, u
 extern "C" int pc_maxpool_bwd(const pc_pool_desc* d, const float* dy, const uint8_t* argmax, float* dx, int accum, pc_stream s) {
     PC_CHECK_ARG(d && dy && dx && argmax && d->C % 4 == 0 && d->ldi % 4 == 0 && d->ldo % 4 == 0, "pc_maxpool_bwd: bad args");
     const int64_t total4 = (int64_t)d->N * d->Ti * d->Hi * d->Wi * (d->C / 4);
+    PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)s, *d, dy, argmax, dx, accum, total4);
     PC_CHECK_LAUNCH("maxpool_bwd");
     return PC_OK;
@@ -534,6 +538,7 @@ extern "C" int pc_channel_scale(const float* x, int ldx, const float* scale, int
                                 int accum, pc_stream s) {
     PC_CHECK_ARG(x && scale && y && C % 4 == 0 && ldx % 4 == 0 && ldy % 4 == 0, "pc_channel_scale: bad args");
     const int64_t total4 = (int64_t)N * pos_per_n * (C / 4);
+    PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(chscale_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, (hipStream_t)s, x, ldx, scale, pos_per_n, C / 4, total4, y, ldy, accum);
     PC_CHECK_LAUNCH("channel_scale");
     return PC_OK;
@@ -562,6 +567,7 @@ extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, in
     if (dz && (act != PC_ACT_NONE || dz != dy)) {
         PC_CHECK_ARG(lddz % 4 == 0, "pc_act_bwd: lddz");
         const int64_t total4 = rows * (C / 4);
+        PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
         hipLaunchKernelGGL(act_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, y, ldy, act, C / 4, total4, dz, lddz);
     }
     PC_CHECK_LAUNCH("act_bwd");
