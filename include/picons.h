@@ -166,6 +166,17 @@ int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_stream s);
  * Ho*Wo real output positions are multiplied instead of the (Ho+KH-1)*(Wo+KW-1) gathered ones. */
 int pc_col2im(const float* cols, int N, int Ho, int Wo, int KH, int KW, int C, float* dx, int lddx,
               int accum, pc_stream s);
+/* ------------------------------------------------------------------------------------------
+ * Evaluation metrics (evaluate_ucf101.py:142-183, evaluate_jhmdb.py same lines): what the reference does in numpy after
+ * `segmentation.cpu()`.  pc_seg_frame_counts: per frame of `nframes` x `pix` logits (B,1,8,H,W contiguous = frame-major)
+ * and truth masks, counts[frame] = { #(pred+gt == 2), #(pred+gt != 0), #(gt != 0) } with pred = sigmoid(logit) >= 0.5
+ * (:128,:148-149,:160-161); the call zeroes `counts` itself.  pc_map_accumulate: one video -- frames with truth add to
+ * n_frames[label] and, for every threshold k/20 (float32, :72) that the frame's inter/union (float64) reaches, to
+ * frame_hits[label][k]; the video's summed counts do the same for video_hits; n_vids[label] += 1 (:153-183).
+ * All tables int32, [ncls][20] / [ncls], owned and zero-initialised by the caller. */
+int pc_seg_frame_counts(const float* logits, const float* gt, int64_t nframes, int64_t pix, int32_t* counts, pc_stream s);
+int pc_map_accumulate(const int32_t* counts, int64_t nframes, int label, int ncls, int32_t* frame_hits, int32_t* video_hits,
+                      int32_t* n_frames, int32_t* n_vids, pc_stream s);
 int pc_fill(float* p, int64_t n, float v, pc_stream s);
 int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
 

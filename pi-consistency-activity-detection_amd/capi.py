@@ -78,6 +78,8 @@ _SIGS = {
     "pc_ndhwc_to_ncdhw": (i32, [vp, i32, i32, i32, i64, vp, vp]),
     "pc_transpose_batched": (i32, [vp, i32, i32, i32, i64, i32, vp, i64, i32, i32, vp]),
     "pc_col2im": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, i32, vp]),
+    "pc_seg_frame_counts": (i32, [vp, vp, i64, i64, vp, vp]),
+    "pc_map_accumulate": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "pc_fill": (i32, [vp, i64, f32, vp]),
     "pc_axpy": (i32, [vp, vp, i64, f32, vp]),
     "pc_em_ws_floats": (i64, [i32, i32, i32]),

@@ -298,3 +298,22 @@ def timed_collect():
     ms = C.c_float(0); cnt = C.c_int32(0)
     capi.call("pc_run_ops_timed_collect", C.byref(ms), C.byref(cnt))
     return ms.value, cnt.value
+
+
+def seg_frame_counts(logits, gt):
+    """logits / gt: contiguous float32 device tensors with the same number of elements, frame-major ([..., H, W] with any
+    leading dims flattened to frames).  -> int32 [nframes, 3] = (intersection, union, truth pixels) per frame."""
+    if logits.dtype != torch.float32 or gt.dtype != torch.float32 or not logits.is_contiguous() or not gt.is_contiguous():
+        raise ValueError("seg_frame_counts: contiguous float32 tensors")
+    pix = logits.shape[-1] * logits.shape[-2]
+    nframes = logits.numel() // pix
+    if gt.numel() != logits.numel():
+        raise ValueError("seg_frame_counts: %d logits vs %d truth pixels" % (logits.numel(), gt.numel()))
+    counts = torch.empty(nframes, 3, dtype=torch.int32, device=logits.device)
+    capi.call("pc_seg_frame_counts", ptr(logits), ptr(gt), nframes, pix, ptr(counts), stream())
+    return counts
+
+
+def map_accumulate(counts, label, frame_hits, video_hits, n_frames, n_vids):
+    capi.call("pc_map_accumulate", ptr(counts), counts.shape[0], int(label), frame_hits.shape[0], ptr(frame_hits), ptr(video_hits),
+              ptr(n_frames), ptr(n_vids), stream())

@@ -101,3 +101,23 @@ def make_step_inputs(bs, rank=0, step=0, num_classes=24, hw=224):
         (g.random((bs, 128)) < 0.5).astype(np.float32) * 2.0,
     ]
     return lab, unl, perm, drops
+
+
+def make_eval_videos(n, seed=1234, num_classes=24, hw=224):
+    """Synthetic evaluation set in the format the reference's eval loader yields (datasets/ucf_dataloader_eval.py via
+    evaluate_ucf101.py:74-77): (video [F,hw,hw,3] float32 in [0,1], bbox [F,hw,hw,1] float32 {0,1}, label), F = 8..40, one
+    moving box per video over a sub-range of its frames."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for vi in range(n):
+        F = int(rng.integers(8, 41))
+        bbox = np.zeros((F, hw, hw, 1), np.float32)
+        f0 = int(rng.integers(0, max(1, F - 6))); f1 = int(rng.integers(f0 + 3, F + 1))
+        h, w = int(rng.integers(hw // 6, hw // 2)), int(rng.integers(hw // 6, hw // 2))
+        y, x = int(rng.integers(0, hw - h)), int(rng.integers(0, hw - w))
+        for f in range(f0, f1):
+            yy, xx = min(hw - h, y + (f - f0)), min(hw - w, x + 2 * (f - f0))
+            bbox[f, yy:yy + h, xx:xx + w, 0] = 1.0
+        video = rng.random((F, hw, hw, 3), dtype=np.float32)
+        out.append((video, bbox, vi % num_classes))
+    return out
