@@ -8,6 +8,8 @@
 
 namespace {
 
+constexpr int F_SCALAR_EPI = 1 << 29;     // internal flag (PICONS_CONV_SCALAR_EPI=1): 4-byte stores straight from the accumulators
+
 struct ConvK {
     const float* in; const float* w; const float* bias; const float* cscale; float* out; float* bnpart;
     int N, Ti, Hi, Wi, Ci, ldi;
@@ -433,6 +435,44 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
             if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
         }
     }
+    // Output tile through LDS (the operand buffers are free now: the K loop ended on a barrier) so that every lane stores 16
+    // bytes of one row and a wave covers whole 128..512-byte row segments: the accumulator layout (one column, 16 rows per
+    // lane) gives 4-byte stores, 64 per thread, whose drain is NOT hidden behind the other resident block's MFMAs
+    // (0.10 ms of the 0.31 ms K = 128 tail GEMM).  Needs 4-column granularity of the output.
+    static_assert(BM * BN <= 2 * (BM + BN) * BK, "output tile fits the operand buffers");
+    if (((p.Co | p.ldo) & 3) == 0 && ((uintptr_t)p.out & 15) == 0 && !(p.flags & F_SCALAR_EPI) && (!has_bias || ((uintptr_t)bbase & 15) == 0) &&
+        (!has_cs || ((uintptr_t)p.cscale & 15) == 0)) {
+        float* T = smem;                          // [BM][BN]
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
+        __syncthreads();
+        for (int e = tid; e < BM * BN / 4; e += 256) {
+            const int row = e / (BN / 4), c4 = e % (BN / 4);
+            const int op = rout[row], col = n0 + c4 * 4;
+            if (op < 0 || col >= p.Co) continue;
+            f32x4 v = *(const f32x4*)(T + row * BN + c4 * 4);
+            if (has_bias) v += *(const f32x4*)(bbase + col);
+            if (p.act != PC_ACT_NONE) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (col + q >= p.act_c0) {
+                        if (p.act == PC_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
+                        else if (p.act == PC_ACT_SIGMOID) v[q] = 1.0f / (1.0f + expf(-v[q]));
+                    }
+            }
+            if (has_cs) v *= *(const f32x4*)(p.cscale + (size_t)rinfo[row * 4] * p.Co + col);
+            float* o = p.out + (size_t)op * p.ldo + col;
+            if (accum) v += *(const f32x4*)o;
+            *(f32x4*)o = v;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -594,7 +634,8 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     const int64_t M = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(M > 0 && M < (1ll << 31) && (int64_t)d->N * d->To * d->Ho * d->Wo < (1ll << 31) && (int64_t)d->N * d->Ti * d->Hi * d->Wi < (1ll << 31), "pc_conv_fwd: position count out of range");
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
-    k.act = d->act; k.flags = d->flags; k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
+    static const int scalar_epi = getenv("PICONS_CONV_SCALAR_EPI") ? atoi(getenv("PICONS_CONV_SCALAR_EPI")) : 0;
+    k.act = d->act; k.flags = (d->flags & ~F_SCALAR_EPI) | (scalar_epi ? F_SCALAR_EPI : 0); k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
     TileCfg c = choose_tile(k.Mg, groups, d->Co, d->Ci);
     static const char* force = getenv("PICONS_CONV_TILE");      // diagnostic: "bm,bn" for grouped launches without BN partials
     if (force && groups > 2 && !(d->flags & PC_F_BNPART)) {
