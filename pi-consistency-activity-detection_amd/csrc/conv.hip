@@ -24,6 +24,48 @@ constexpr int BK = 32;       // K chunk (floats)
 constexpr int CONV_DEFAULT_VARIANT = 0;
 constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
 
+// Output tile through LDS (the operand buffers are free once the K loop has ended on a barrier) so that every lane stores
+// 16 bytes of one row and a wave covers whole 128..512-byte row segments.  The accumulator layout (one column, 16 rows
+// per lane) gives 4-byte stores, 64 per thread, whose drain is NOT hidden behind the other resident block's MFMAs
+// (0.10 ms of the 0.31 ms K = 128 tail GEMM).  Needs 4-column granularity of the output; returns false otherwise.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ bool store_tile_rows(const f32x16 (&acc)[TM][TN], float* T, const int* rout, const int* rinfo, const ConvK& p,
+                                                const float* bbase, int n0, int wm, int wn, int lane, int tid) {
+    const bool has_bias = p.flags & PC_F_BIAS, has_cs = p.flags & PC_F_CSCALE, accum = p.flags & PC_F_ACCUM;
+    if (!(((p.Co | p.ldo) & 3) == 0 && ((uintptr_t)p.out & 15) == 0 && !(p.flags & F_SCALAR_EPI) && (!has_bias || ((uintptr_t)bbase & 15) == 0) &&
+          (!has_cs || ((uintptr_t)p.cscale & 15) == 0)))
+        return false;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
+        }
+    __syncthreads();
+    for (int e = tid; e < BM * BN / 4; e += 256) {
+        const int row = e / (BN / 4), c4 = e % (BN / 4);
+        const int op = rout[row], col = n0 + c4 * 4;
+        if (op < 0 || col >= p.Co) continue;
+        f32x4 v = *(const f32x4*)(T + row * BN + c4 * 4);
+        if (has_bias) v += *(const f32x4*)(bbase + col);
+        if (p.act != PC_ACT_NONE) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (col + q >= p.act_c0) {
+                    if (p.act == PC_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
+                    else if (p.act == PC_ACT_SIGMOID) v[q] = 1.0f / (1.0f + expf(-v[q]));
+                }
+        }
+        if (has_cs) v *= *(const f32x4*)(p.cscale + (size_t)rinfo[row * 4] * p.Co + col);
+        float* o = p.out + (size_t)op * p.ldo + col;
+        if (accum) v += *(const f32x4*)o;
+        *(f32x4*)o = v;
+    }
+    return true;
+}
+
 template <int BM, int BN, int WM, int WN, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -189,6 +231,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
             if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
         }
     }
+    if (ABL == 0 && store_tile_rows<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, bbase, n0, wm, wn, lane, tid)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -435,44 +478,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
             if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
         }
     }
-    // Output tile through LDS (the operand buffers are free now: the K loop ended on a barrier) so that every lane stores 16
-    // bytes of one row and a wave covers whole 128..512-byte row segments: the accumulator layout (one column, 16 rows per
-    // lane) gives 4-byte stores, 64 per thread, whose drain is NOT hidden behind the other resident block's MFMAs
-    // (0.10 ms of the 0.31 ms K = 128 tail GEMM).  Needs 4-column granularity of the output.
     static_assert(BM * BN <= 2 * (BM + BN) * BK, "output tile fits the operand buffers");
-    if (((p.Co | p.ldo) & 3) == 0 && ((uintptr_t)p.out & 15) == 0 && !(p.flags & F_SCALAR_EPI) && (!has_bias || ((uintptr_t)bbase & 15) == 0) &&
-        (!has_cs || ((uintptr_t)p.cscale & 15) == 0)) {
-        float* T = smem;                          // [BM][BN]
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
-            }
-        __syncthreads();
-        for (int e = tid; e < BM * BN / 4; e += 256) {
-            const int row = e / (BN / 4), c4 = e % (BN / 4);
-            const int op = rout[row], col = n0 + c4 * 4;
-            if (op < 0 || col >= p.Co) continue;
-            f32x4 v = *(const f32x4*)(T + row * BN + c4 * 4);
-            if (has_bias) v += *(const f32x4*)(bbase + col);
-            if (p.act != PC_ACT_NONE) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (col + q >= p.act_c0) {
-                        if (p.act == PC_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
-                        else if (p.act == PC_ACT_SIGMOID) v[q] = 1.0f / (1.0f + expf(-v[q]));
-                    }
-            }
-            if (has_cs) v *= *(const f32x4*)(p.cscale + (size_t)rinfo[row * 4] * p.Co + col);
-            float* o = p.out + (size_t)op * p.ldo + col;
-            if (accum) v += *(const f32x4*)o;
-            *(f32x4*)o = v;
-        }
-        return;
-    }
+    if (store_tile_rows<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, bbase, n0, wm, wn, lane, tid)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
