@@ -144,6 +144,17 @@ static thread_local bool g_ev_init = false;
 // Deferred kernel timing: event pairs recorded by pc_run_ops_timed(..., ms = NULL) wait here until
 // pc_run_ops_timed_collect reads them, so the timed replay adds no host synchronisation of its own.
 static thread_local std::vector<hipEvent_t> g_pending;
+thread_local hipEvent_t pc_tl_ev_start = nullptr, pc_tl_ev_stop = nullptr;
+// timing events are pooled per thread: creating and destroying 212 events per step cost more than recording them
+static thread_local std::vector<hipEvent_t> g_ev_pool;
+static hipEvent_t take_event() {
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+static const bool g_no_ext_events = getenv("PICONS_TIMED_RECORD") && atoi(getenv("PICONS_TIMED_RECORD"));   // 1: hipEventRecord pairs for conv ops too
 
 static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes, int kind, float* ms, int* count) {
     if (!ops && n > 0) { pc_set_error("pc_run_ops: null ops"); return PC_E_ARG; }
@@ -158,7 +169,7 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
     if (kind > 0) {
         for (int k = 0; k < n; ++k) cnt += ops[k].kind == kind;
         ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (cnt > 0 ? cnt : 1));
-        for (int i = 0; i < 2 * cnt; ++i) (void)hipEventCreate(&ev[i]);
+        for (int i = 0; i < 2 * cnt; ++i) ev[i] = take_event();
     }
     int j = 0, rc = PC_OK, k = 0;
     for (; k < n && rc == PC_OK; ++k) {
@@ -181,9 +192,14 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         const int ln = (op.lane > 0 && op.lane < nlanes) ? op.lane : 0;
         const pc_stream s = lanes[ln];
         const bool t = kind > 0 && op.kind == kind;
-        if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
+        // a conv op is exactly one kernel: its event pair rides in the dispatch itself (no extra packets on the stream);
+        // any other kind is bracketed by recorded events
+        const bool ext = t && op.kind == PC_OP_CONV && !g_no_ext_events;
+        if (ext) { pc_tl_ev_start = ev[2 * j]; pc_tl_ev_stop = ev[2 * j + 1]; }
+        else if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
         rc = run_one(op, s);
-        if (t) { (void)hipEventRecord(ev[2 * j + 1], (hipStream_t)s); ++j; }
+        if (ext) { pc_tl_ev_start = pc_tl_ev_stop = nullptr; ++j; }
+        else if (t) { (void)hipEventRecord(ev[2 * j + 1], (hipStream_t)s); ++j; }
     }
     if (rc != PC_OK) {
         char tmp[400];
@@ -192,14 +208,14 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
     }
     if (kind > 0 && !ms) {              // deferred: keep the recorded pairs for pc_run_ops_timed_collect
         for (int i = 0; i < 2 * j; ++i) g_pending.push_back(ev[i]);
-        for (int i = 2 * j; i < 2 * cnt; ++i) (void)hipEventDestroy(ev[i]);
+        for (int i = 2 * j; i < 2 * cnt; ++i) g_ev_pool.push_back(ev[i]);
         free(ev);
         if (count) *count = j;
     } else if (kind > 0) {
         for (int q = 0; q < nlanes; ++q) (void)hipStreamSynchronize((hipStream_t)lanes[q]);
         float total = 0.f;
         for (int i = 0; i < j; ++i) { float e = 0.f; (void)hipEventElapsedTime(&e, ev[2 * i], ev[2 * i + 1]); total += e; }
-        for (int i = 0; i < 2 * cnt; ++i) (void)hipEventDestroy(ev[i]);
+        for (int i = 0; i < 2 * cnt; ++i) g_ev_pool.push_back(ev[i]);
         free(ev);
         if (ms) *ms = total;
         if (count) *count = j;
@@ -229,8 +245,8 @@ extern "C" int pc_run_ops_timed_collect(float* ms, int* count) {
         (void)hipEventSynchronize(g_pending[2 * i + 1]);
         (void)hipEventElapsedTime(&e, g_pending[2 * i], g_pending[2 * i + 1]);
         total += e;
-        (void)hipEventDestroy(g_pending[2 * i]);
-        (void)hipEventDestroy(g_pending[2 * i + 1]);
+        g_ev_pool.push_back(g_pending[2 * i]);
+        g_ev_pool.push_back(g_pending[2 * i + 1]);
     }
     g_pending.clear();
     if (ms) *ms = total;

@@ -1,12 +1,17 @@
 // Internal helpers shared by the gfx950 kernels of libpicons.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
 #include "../../include/picons.h"
 
 void pc_set_error(const char* fmt, ...);
+
+// Set by pc_run_ops_timed around a conv op: the launch then carries the event pair in its own dispatch packet
+// (hipExtLaunchKernelGGL), so timing a kernel costs no extra barrier packets on the stream.  Null otherwise.
+extern thread_local hipEvent_t pc_tl_ev_start, pc_tl_ev_stop;
 
 #define PC_CHECK_ARG(cond, ...)                                   \
     do {                                                          \

@@ -518,7 +518,10 @@ int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
     ConvK p = k;
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
-    hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
+    if (pc_tl_ev_start)
+        hipExtLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, pc_tl_ev_start, pc_tl_ev_stop, 0, p);
+    else
+        hipLaunchKernelGGL((conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>), dim3(p.groups * p.mtiles_g * p.ntiles), dim3(256), lds, s, p);
     PC_CHECK_LAUNCH("conv_gemm_glds_kernel");
     return PC_OK;
 }
@@ -549,7 +552,8 @@ int launch_conv2(const ConvK& k, hipStream_t s) {
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
     const int grid = p.groups * p.mtiles_g * p.ntiles;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, FAST>), dim3(grid), dim3(256), lds, s, p);
+    if (pc_tl_ev_start) hipExtLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, FAST>), dim3(grid), dim3(256), lds, s, pc_tl_ev_start, pc_tl_ev_stop, 0, p);
+    else hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, WM, WN, FAST>), dim3(grid), dim3(256), lds, s, p);
     PC_CHECK_LAUNCH("conv_gemm_kernel");
     return PC_OK;
 }
