@@ -357,9 +357,10 @@ int pc_run_ops(const pc_op* ops, int n, pc_stream s);
  * branches of an Inception module (pytorch_i3d.py:149-154) and their backward run concurrently between
  * a FORK and the matching JOIN.  Lanes >= nlanes fold onto lane 0.  Every list must end joined. */
 int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes);
-/* same, with a hipEvent pair recorded around every op of `kind` on the stream that op runs on;
- * returns elapsed ms summed over those ops in *ms and their count in *count (bench.py roofline
- * leg).  Synchronises all lanes before returning (unless ms == NULL, see below). */
+/* same, with a hipEvent pair around every op of `kind` on the stream that op runs on (for PC_OP_CONV, whose ops are
+ * one kernel each, the pair rides in the kernel's own dispatch and brackets exactly the kernel; other kinds are
+ * bracketed by recorded events); returns elapsed ms summed over those ops in *ms and their count in *count (bench.py
+ * roofline leg).  Synchronises all lanes before returning (unless ms == NULL, see below). */
 int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes);
 /* With ms == NULL pc_run_ops_timed does not synchronise: the event pairs stay pending (per host thread) until this call
  * waits for them and returns their summed elapsed ms and their number. */
