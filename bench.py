@@ -26,6 +26,17 @@ import torch  # noqa: E402
 PEAK_FP32_MFMA_TFLOPS = 157.3        # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = fp32 vector peak
 
 
+def _baseline_metric():
+    """The metric string is BASELINE.json's own (repo root; it travels with the snapshot)."""
+    try:
+        return json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"]
+    except Exception:
+        return "train clips/sec (bs=8, 16\u00d7224\u00d7224, I3D+caps+bv cons) at 1/2/4/8 GPU"
+
+
+METRIC = _baseline_metric()
+
+
 def cpu_baseline(seconds_budget=30.0):
     """CPU oracle (oracle/, kind 'port') on a bounded sample: one bs=2 train step (2 forward passes,
     losses, backward, Adam) at 8x224x224 with all host threads."""
@@ -120,7 +131,7 @@ def main():
                 "kernel_ms_per_step": eng.kind_ms / a.steps,
                 "flops_per_launch": flops_per_launch}
     out = {
-        "metric": "train clips/sec (bs=8, 16x224x224, I3D+caps+bv cons) at 1/2/4/8 GPU",
+        "metric": METRIC,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -1,0 +1,41 @@
+"""GPU: the driver-facing contract of bench.py -- ONE JSON line on stdout with the metric BASELINE.json names, the
+whole-job value, the live roofline leg (HIP events on the kernels' own streams) and, when asked, the CPU baseline."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*flags):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    j = _run("--gpus", "1", "--steps", "3", "--warmup", "1", "--no-cpu-baseline")
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert j["metric"] == base["metric"] and j["unit"] == "clips/s" and j["higher_is_better"] is True
+    assert j["n_gpus"] == 1 and j["steps"] == 3 and j["warmup"] == 1 and j["scaling"] == "weak" and j["dtype"] == "f32"
+    assert j["data"] == "synthetic" and j["vs_baseline"] is None and "model" not in j["config"] and "configs[1]" in j["config"]["workload"]
+    assert abs(j["value"] - 8 * 1000.0 / j["ms_per_step"]) < 1e-6 * j["value"]          # whole-job clips/s at bs = 8
+    assert 100.0 < j["value"] < 1000.0
+    r = j["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
+    assert r["launches_per_step"] > 50 and abs(r["avg_launch_ms"] * r["launches_per_step"] - r["kernel_ms_per_step"]) < 1e-6 * r["kernel_ms_per_step"]
+    assert r["kernel_ms_per_step"] < j["ms_per_step"]                                    # event time of the conv kernels fits inside the step
+    assert r["traffic"] is None or r["traffic"] > 1e6
+    assert all(k in j["loss"] for k in ("total", "loc", "cls", "cons")) and j["cpu_baseline"] is None
+
+
+def test_bench_without_timing_leg_is_not_slower():
+    a = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing")
+    assert a["roofline"] is None and a["ms_per_step"] < 60.0
