@@ -177,6 +177,14 @@ int pc_col2im(const float* cols, int N, int Ho, int Wo, int KH, int KW, int C, f
 int pc_seg_frame_counts(const float* logits, const float* gt, int64_t nframes, int64_t pix, int32_t* counts, pc_stream s);
 int pc_map_accumulate(const int32_t* counts, int64_t nframes, int label, int ncls, int32_t* frame_hits, int32_t* video_hits,
                       int32_t* n_frames, int32_t* n_vids, pc_stream s);
+/* ------------------------------------------------------------------------------------------
+ * Input pipeline (datasets/ucf_dataloader.py:146-173 and the box rasterisation of load_video :204-221): from the decoded
+ * uint8 frames `video` [F][H][W][3] in HBM, the 8 frames `span8` (host array), the S x S crop at (h0, w0): data =
+ * frame / 255 (float64 division, then float32) as NCDHW [3][8][S][S], aug = its horizontal flip, mask [8][S][S] = 1 where
+ * any of the frame's R boxes rects[t][r] = (x0, x1, y0, y1) (device int32, frame coordinates, half-open, already clipped
+ * the way numpy clips `bbox[f, y:y+h, x:x+w]`) covers the pixel, else 0. */
+int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
+                    const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s);
 int pc_fill(float* p, int64_t n, float v, pc_stream s);
 int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
 

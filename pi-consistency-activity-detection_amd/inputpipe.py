@@ -1,0 +1,89 @@
+"""Per-sample input preparation with the pixel work on the device.
+
+Mirrors /root/reference/datasets/ucf_dataloader.py after decoding: `load_video`'s box bookkeeping (:204-264) and
+`__getitem__` (:84-191) -- which annotated frame, which 8 frames (skip 2, falling back to 1 near the start, clamped at the
+end), which 224x224 crop (random for training, centre otherwise), frame / 255, the horizontally flipped copy, the
+foreground mask from the per-frame boxes.  The reference does all of it in numpy on float64 host arrays (9.6 MB per clip
+and copy); here the host only makes the integer decisions, in the reference's order of `np.random` draws (so a seed
+reproduces its choices), uploads the 8 selected uint8 frames (1.8 MB) and `pc_clip_from_u8` writes the fp32 NCDHW tensors
+the step consumes (csrc/inputpipe.hip).  `cv2.resize` of a 224x224 crop to 224x224 (:156,:162) is the identity and is not
+performed.  No CPU path for the pixel work: the op raises without the HIP library."""
+import numpy as np
+import torch
+
+from . import ops
+
+DEPTH = 8
+CROP = 224
+
+
+def frame_boxes(annotations, n_frames):
+    """load_video :204-221: per frame the boxes drawn into `bbox`, plus label, the annotated frame ids and the labeled flag.
+    Consumes the draw of :213-214 like the reference."""
+    if len(annotations) > 1:
+        np.random.randint(0, len(annotations))
+    per_frame = {}
+    multi, label, labeled_vid = [], -1, -1
+    for ann in annotations:
+        multi.extend(ann[4])
+        start_frame, end_frame, label, labeled_vid = ann[0], ann[1], ann[2], ann[5]
+        for f in range(start_frame, min(n_frames, end_frame + 1)):
+            per_frame.setdefault(f, []).append(ann[3][f - start_frame])
+    return per_frame, label, list(set(multi)), labeled_vid
+
+
+def choose_window(annot_frames, vlen):
+    """__getitem__ :107-143 -> 8 frame ids, or None for the all-zero sample."""
+    vskip = 2
+    if len(annot_frames) == 1:
+        sel = annot_frames[0]
+    else:
+        if len(annot_frames) <= 0:
+            return None
+        sel = annot_frames[np.random.randint(0, len(annot_frames))]
+    start = sel - int((DEPTH * vskip) / 2)
+    if start < 0:
+        vskip = 1
+        start = sel - int((DEPTH * vskip) / 2)
+        if start < 0:
+            start, vskip = 0, 1
+    if sel >= vlen:
+        return None
+    if start + (DEPTH * vskip) >= vlen:
+        start = vlen - (DEPTH * vskip)
+    return np.arange(DEPTH) * vskip + start
+
+
+def _empty(device, size):
+    z = torch.zeros(3, DEPTH, size, size, device=device)
+    return {'data': z, 'loc_msk': torch.zeros(1, DEPTH, size, size, device=device), 'action': torch.Tensor([0]), 'aug_data': z, 'label_vid': 0}
+
+
+def get_item(frames, annotations, train=True, device="cuda"):
+    """One sample as `UCF101DataLoader.__getitem__` returns it, with fp32 device tensors instead of float64 host tensors
+    (the train loop casts to `torch.cuda.FloatTensor` first thing, main_ucf101.py:52-56).  frames: decoded uint8 [F,H,W,3]
+    (numpy, or a device tensor when the decoder already writes to HBM), None when the reader failed (:90-98)."""
+    if frames is None:
+        return _empty(device, CROP)
+    vlen, clip_h, clip_w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    per_frame, label, annot_frames, labeled_vid = frame_boxes(annotations, vlen)
+    span = choose_window(annot_frames, vlen)
+    if span is None:
+        return _empty(device, CROP)
+    if train:
+        h0 = np.random.randint(0, clip_h - CROP); w0 = np.random.randint(0, clip_w - CROP)       # :146-149
+    else:
+        h0 = int((clip_h - CROP) / 2); w0 = int((clip_w - CROP) / 2)
+    # boxes of the selected frames, clipped the way numpy clips bbox[f, y:y+h, x:x+w] (:218)
+    R = max([len(per_frame.get(int(f), [])) for f in span] + [1])
+    rects = np.zeros((DEPTH, R, 4), np.int32)
+    for t, f in enumerate(span):
+        for r, (x, y, bw, bh) in enumerate(per_frame.get(int(f), [])):
+            x0, x1, _ = slice(x, x + bw).indices(clip_w); y0, y1, _ = slice(y, y + bh).indices(clip_h)
+            rects[t, r] = (x0, x1, y0, y1)
+    if torch.is_tensor(frames):
+        video, ids = frames.to(device), span
+    else:
+        video, ids = torch.from_numpy(np.ascontiguousarray(frames[span])).to(device), np.arange(DEPTH)   # only the 8 frames travel
+    data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, torch.from_numpy(rects).to(device), CROP)
+    return {'data': data, 'loc_msk': mask.view(1, DEPTH, CROP, CROP), 'action': torch.Tensor([label]), 'aug_data': aug, 'label_vid': labeled_vid}

@@ -317,3 +317,18 @@ def seg_frame_counts(logits, gt):
 def map_accumulate(counts, label, frame_hits, video_hits, n_frames, n_vids):
     capi.call("pc_map_accumulate", ptr(counts), counts.shape[0], int(label), frame_hits.shape[0], ptr(frame_hits), ptr(video_hits),
               ptr(n_frames), ptr(n_vids), stream())
+
+
+def clip_from_u8(video, span, h0, w0, rects, S=224):
+    """video: uint8 device tensor [F,H,W,3]; span: 8 frame ids; rects: int32 device tensor [8,R,4] (x0,x1,y0,y1) or None.
+    -> data, aug [3,8,S,S] float32, mask [8,S,S] float32 (pc_clip_from_u8)."""
+    if video.dtype != torch.uint8 or video.dim() != 4 or video.shape[3] != 3 or not video.is_contiguous():
+        raise ValueError("clip_from_u8: contiguous uint8 [F,H,W,3] frames")
+    F, H, W, _ = video.shape
+    R = 0 if rects is None else int(rects.shape[1])
+    if rects is not None and (rects.dtype != torch.int32 or not rects.is_contiguous() or rects.shape[0] != 8 or rects.shape[2] != 4):
+        raise ValueError("clip_from_u8: rects must be contiguous int32 [8,R,4]")
+    data = torch.empty(3, 8, S, S, device=video.device); aug = torch.empty_like(data); mask = torch.empty(8, S, S, device=video.device)
+    sp = (C.c_int32 * 8)(*[int(v) for v in span])
+    capi.call("pc_clip_from_u8", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(rects) if R else None, R, ptr(data), ptr(aug), ptr(mask), stream())
+    return data, aug, mask
