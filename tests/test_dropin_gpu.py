@@ -123,3 +123,34 @@ def test_helpers_dropin_matches_reference_golden(golden_dir):
             if k == "utils" or k.startswith("utils."):
                 del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_pretrained_trunk_and_reference_checkpoint_loading(tmp_path):
+    """§8f rank 4: `rgb_charades.pt` (a full 400-class I3D state_dict without the 'conv1.' prefix, capsules_ucf101.py:343-352)
+    fills exactly the trunk up to Mixed_4f and ignores the layers the model does not have; a checkpoint written the way the
+    reference writes them (`torch.save(model.state_dict())`, main_ucf101.py:442,451) comes back through load_previous_weights."""
+    ref = synthetic.init_state(3, 24)
+    g = torch.Generator().manual_seed(9)
+    pre = {k[len("conv1."):]: torch.from_numpy(np.asarray(v).copy()) for k, v in ref.items() if k.startswith("conv1.")}
+    for k in list(pre):
+        if pre[k].dtype == torch.float32:
+            pre[k] = torch.randn(pre[k].shape, generator=g) * 0.05
+    pre["Mixed_5b.b0.conv3d.weight"] = torch.randn(256, 832, 1, 1, 1, generator=g)        # layers beyond Mixed_4f / the logits head
+    pre["logits.conv3d.weight"] = torch.randn(400, 1024, 1, 1, 1, generator=g)
+    pre["logits.conv3d.bias"] = torch.randn(400, generator=g)
+    path = str(tmp_path / "rgb_charades.pt")
+    torch.save(pre, path)
+    m = pmodel.CapsNet(pt_path=path, hw=HW)
+    base = pmodel.CapsNet(pt_path=None, hw=HW).state_dict()
+    sd = m.state_dict()
+    for k in sd:
+        if k.startswith("conv1."):
+            assert torch.equal(sd[k].cpu(), pre[k[len("conv1."):]].to(sd[k].dtype)), k
+        else:
+            assert torch.equal(sd[k].cpu(), base[k].cpu()), k                               # head / decoder keep their initialisation
+    ck = str(tmp_path / "best_model_train_loss_1.pth")
+    torch.save(sd, ck)
+    m2 = pmodel.CapsNet(pt_path=None, hw=HW, seed=5)
+    m2.load_previous_weights(ck)
+    sd2 = m2.state_dict()
+    assert list(sd2) == list(sd) and all(torch.equal(sd2[k].cpu(), sd[k].cpu()) for k in sd)
