@@ -185,6 +185,12 @@ int pc_map_accumulate(const int32_t* counts, int64_t nframes, int label, int ncl
  * the way numpy clips `bbox[f, y:y+h, x:x+w]`) covers the pixel, else 0. */
 int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
                     const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s);
+/* JHMDB form (datasets/jhmdb_dataloader.py:167-205): the truth is a per-pixel mask per frame, `maskframes` [F][H][W] uint8
+ * (> 0 = foreground), and only the frames flagged in valid8 (host array; :187-194) carry it: mask = valid && maskframe > 0,
+ * mask_cls [8][S][S] = valid. */
+int pc_clip_from_u8_masks(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
+                          const uint8_t* maskframes, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls,
+                          pc_stream s);
 int pc_fill(float* p, int64_t n, float v, pc_stream s);
 int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
 

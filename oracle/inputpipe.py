@@ -73,3 +73,53 @@ def get_item(clip, annotations, train=True, height=224, width=224):
     flip = video_rgb[:, :, ::-1, :]
     return {'data': torch.from_numpy(np.transpose(video_rgb, [3, 0, 1, 2])), 'loc_msk': torch.from_numpy(np.transpose(label_cls, [3, 0, 1, 2])),
             'action': torch.Tensor([label]), 'aug_data': torch.from_numpy(np.transpose(flip, [3, 0, 1, 2]).copy()), 'label_vid': labeled_vid}
+
+
+def get_item_jhmdb(clip, bbox_clip, label, annot_frames, train=True, height=224, width=224):
+    """/root/reference/datasets/jhmdb_dataloader.py:102-230 after `load_video` (:232-310: cv2 decode + resize + .mat read, not
+    restated): clip [F,H,W,3] frames (uint8 values), bbox_clip [F,H,W] or [F,H,W,1] puppet masks (> 0 foreground), the class id
+    and the frames that carry truth.  Only frames in `annot_frames` (or, at skip 2, whose successor is) get a mask; `mask_cls`
+    marks them."""
+    def empty():
+        z = torch.from_numpy(np.transpose(np.zeros((DEPTH, height, width, 3)), [3, 0, 1, 2]))
+        m = torch.from_numpy(np.transpose(np.zeros((DEPTH, height, width, 1)), [3, 0, 1, 2]))
+        return {'data': z, 'loc_msk': m, 'action': torch.Tensor([0]), 'mask_cls': m.clone(), 'aug_data': z}
+    bbox_clip = np.reshape(bbox_clip, (bbox_clip.shape[0], bbox_clip.shape[1], bbox_clip.shape[2], 1))      # :113 (before the None test, as there)
+    if clip is None:
+        return empty()
+    vlen, clip_h, clip_w, _ = clip.shape
+    vskip = 2
+    if len(annot_frames) == 1:
+        sel = annot_frames[0]
+    else:
+        if len(annot_frames) <= 0:
+            return empty()
+        sel = annot_frames[np.random.randint(0, len(annot_frames))]
+    start = sel - int((DEPTH * vskip) / 2)
+    if start < 0:
+        vskip = 1
+        start = sel - int((DEPTH * vskip) / 2)
+        if start < 0:
+            start, vskip = 0, 1
+    if sel >= vlen:
+        return empty()
+    if start + (DEPTH * vskip) >= vlen:
+        start = vlen - (DEPTH * vskip)
+    span = np.arange(DEPTH) * vskip + start
+    video = clip[span]; boxes = bbox_clip[span]
+    if train:
+        h0 = np.random.randint(0, clip_h - 224); w0 = np.random.randint(0, clip_w - 224)
+    else:
+        h0 = int((clip_h - 224) / 2); w0 = int((clip_w - 224) / 2)
+    video_rgb = np.zeros((DEPTH, height, width, 3)); label_cls = np.zeros((DEPTH, height, width, 1)); mask_cls = np.zeros((DEPTH, height, width, 1))
+    for j in range(DEPTH):
+        video_rgb[j] = video[j][h0:h0 + 224, w0:w0 + 224, :] / 255.
+        valid = (span[j] in annot_frames or span[j] + 1 in annot_frames) if vskip == 2 else (span[j] in annot_frames)     # :187-194
+        if valid:
+            bb = boxes[j][h0:h0 + 224, w0:w0 + 224, 0]
+            label_cls[j, bb > 0, 0] = 1.
+            mask_cls[j] = 1.
+    flip = video_rgb[:, :, ::-1, :]
+    tr = lambda a: torch.from_numpy(np.transpose(a, [3, 0, 1, 2]))
+    return {'data': tr(video_rgb), 'loc_msk': tr(label_cls), 'action': torch.Tensor([label]), 'mask_cls': tr(mask_cls),
+            'aug_data': torch.from_numpy(np.transpose(flip, [3, 0, 1, 2]).copy())}

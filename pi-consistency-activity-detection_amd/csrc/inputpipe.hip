@@ -10,6 +10,7 @@ struct ClipK {
     const uint8_t* video; int F, H, W;
     int span[8]; int h0, w0, S;          // frame ids, crop origin, crop size (224)
     const int32_t* rects; int R;         // [8][R][4] = x0, x1, y0, y1 in frame coordinates (empty: x1 <= x0)
+    const uint8_t* maskf; int valid[8]; float* mask_cls;   // JHMDB form: per-pixel truth frames [F][H][W] (> 0 = foreground), frames that carry truth
     float* data; float* aug; float* mask;   // [3][8][S][S], [3][8][S][S], [8][S][S]
 };
 
@@ -28,21 +29,43 @@ __global__ __launch_bounds__(256) void clip_from_u8_kernel(const ClipK p) {
             p.aug[o + (S - 1 - w)] = v;                               // video_rgb[:, :, ::-1, :]
         }
         float m = 0.f;
-        const int32_t* r = p.rects + (size_t)t * p.R * 4;
-        for (int q = 0; q < p.R; ++q)
-            if (x >= r[q * 4] && x < r[q * 4 + 1] && y >= r[q * 4 + 2] && y < r[q * 4 + 3]) m = 1.f;
+        if (p.maskf) {
+            if (p.valid[t] && p.maskf[((size_t)f * p.H + y) * p.W + x] > 0) m = 1.f;
+            p.mask_cls[idx] = p.valid[t] ? 1.f : 0.f;
+        } else {
+            const int32_t* r = p.rects + (size_t)t * p.R * 4;
+            for (int q = 0; q < p.R; ++q)
+                if (x >= r[q * 4] && x < r[q * 4 + 1] && y >= r[q * 4 + 2] && y < r[q * 4 + 3]) m = 1.f;
+        }
         p.mask[idx] = m;
     }
 }
 
 }  // namespace
 
+static int clip_launch(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S, const int32_t* rects, int R,
+                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s);
+
 extern "C" int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
                                const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s) {
+    return clip_launch(video, F, H, W, span8, h0, w0, S, rects, R, nullptr, nullptr, data, aug, mask, nullptr, s);
+}
+
+extern "C" int pc_clip_from_u8_masks(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
+                                     const uint8_t* maskframes, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls,
+                                     pc_stream s) {
+    PC_CHECK_ARG(maskframes && valid8 && mask_cls, "pc_clip_from_u8_masks: null pointer");
+    return clip_launch(video, F, H, W, span8, h0, w0, S, nullptr, 0, maskframes, valid8, data, aug, mask, mask_cls, s);
+}
+
+static int clip_launch(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S, const int32_t* rects, int R,
+                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s) {
     PC_CHECK_ARG(video && span8 && data && aug && mask && (rects || R == 0), "pc_clip_from_u8: null pointer");
     PC_CHECK_ARG(F >= 1 && S >= 1 && h0 >= 0 && w0 >= 0 && h0 + S <= H && w0 + S <= W && R >= 0, "pc_clip_from_u8: crop %d+%d x %d+%d outside %d x %d", h0, S, w0, S, H, W);
     ClipK k;
     k.video = video; k.F = F; k.H = H; k.W = W; k.h0 = h0; k.w0 = w0; k.S = S; k.rects = rects; k.R = R; k.data = data; k.aug = aug; k.mask = mask;
+    k.maskf = maskf; k.mask_cls = mask_cls;
+    for (int t = 0; t < 8; ++t) k.valid[t] = valid8 ? valid8[t] : 0;
     for (int t = 0; t < 8; ++t) {
         PC_CHECK_ARG(span8[t] >= 0 && span8[t] < F, "pc_clip_from_u8: frame %d outside [0, %d)", span8[t], F);
         k.span[t] = span8[t];

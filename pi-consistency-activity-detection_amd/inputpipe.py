@@ -87,3 +87,32 @@ def get_item(frames, annotations, train=True, device="cuda"):
         video, ids = torch.from_numpy(np.ascontiguousarray(frames[span])).to(device), np.arange(DEPTH)   # only the 8 frames travel
     data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, torch.from_numpy(rects).to(device), CROP)
     return {'data': data, 'loc_msk': mask.view(1, DEPTH, CROP, CROP), 'action': torch.Tensor([label]), 'aug_data': aug, 'label_vid': labeled_vid}
+
+
+def get_item_jhmdb(frames, masks, label, annot_frames, train=True, device="cuda"):
+    """One sample as /root/reference/datasets/jhmdb_dataloader.py `__getitem__` (:102-230) returns it after `load_video`:
+    frames uint8 [F,H,W,3] (the loader's 256x256 resized frames), masks [F,H,W] or [F,H,W,1] puppet masks (> 0 foreground;
+    any dtype, compared against 0 on the host when they are not uint8), the class id and the frames that carry truth.  Keys:
+    data, loc_msk, action, mask_cls, aug_data."""
+    def empty():
+        z = torch.zeros(3, DEPTH, CROP, CROP, device=device); m = torch.zeros(1, DEPTH, CROP, CROP, device=device)
+        return {'data': z, 'loc_msk': m, 'action': torch.Tensor([0]), 'mask_cls': m.clone(), 'aug_data': z}
+    if frames is None:
+        return empty()
+    vlen, clip_h, clip_w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
+    span = choose_window(list(annot_frames) if not isinstance(annot_frames, list) else annot_frames, vlen)
+    if span is None:
+        return empty()
+    vskip = int(span[1] - span[0])
+    if train:
+        h0 = np.random.randint(0, clip_h - CROP); w0 = np.random.randint(0, clip_w - CROP)
+    else:
+        h0 = int((clip_h - CROP) / 2); w0 = int((clip_w - CROP) / 2)
+    af = set(int(a) for a in annot_frames)
+    valid = [(int(f) in af or int(f) + 1 in af) if vskip == 2 else (int(f) in af) for f in span]               # :187-194
+    m = np.asarray(masks).reshape(vlen, clip_h, clip_w)[span]
+    m8 = np.ascontiguousarray(m if m.dtype == np.uint8 else (m > 0).astype(np.uint8))
+    video = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[span])).to(device)
+    data, aug, mask, mask_cls = ops.clip_from_u8_masks(video, np.arange(DEPTH), h0, w0, torch.from_numpy(m8).to(device), valid, CROP)
+    return {'data': data, 'loc_msk': mask.view(1, DEPTH, CROP, CROP), 'action': torch.Tensor([label]), 'mask_cls': mask_cls.view(1, DEPTH, CROP, CROP),
+            'aug_data': aug}

@@ -332,3 +332,17 @@ def clip_from_u8(video, span, h0, w0, rects, S=224):
     sp = (C.c_int32 * 8)(*[int(v) for v in span])
     capi.call("pc_clip_from_u8", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(rects) if R else None, R, ptr(data), ptr(aug), ptr(mask), stream())
     return data, aug, mask
+
+
+def clip_from_u8_masks(video, span, h0, w0, maskframes, valid, S=224):
+    """JHMDB form (pc_clip_from_u8_masks): maskframes uint8 device [F,H,W]; valid: 8 flags.  -> data, aug, mask, mask_cls."""
+    if video.dtype != torch.uint8 or video.dim() != 4 or video.shape[3] != 3 or not video.is_contiguous():
+        raise ValueError("clip_from_u8_masks: contiguous uint8 [F,H,W,3] frames")
+    F, H, W, _ = video.shape
+    if maskframes.dtype != torch.uint8 or tuple(maskframes.shape) != (F, H, W) or not maskframes.is_contiguous():
+        raise ValueError("clip_from_u8_masks: maskframes must be contiguous uint8 [F,H,W]")
+    data = torch.empty(3, 8, S, S, device=video.device); aug = torch.empty_like(data)
+    mask = torch.empty(8, S, S, device=video.device); mask_cls = torch.empty_like(mask)
+    sp = (C.c_int32 * 8)(*[int(v) for v in span]); va = (C.c_int32 * 8)(*[int(bool(v)) for v in valid])
+    capi.call("pc_clip_from_u8_masks", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(maskframes), va, ptr(data), ptr(aug), ptr(mask), ptr(mask_cls), stream())
+    return data, aug, mask, mask_cls

@@ -32,3 +32,21 @@ def case(k):
 
 
 N_CASES = 10
+
+
+def jhmdb_case(k):
+    """-> (frames [F,256,256,3] uint8 or None, puppet masks [F,256,256,1] float64 with part ids 0..5, label, annot_frames, train).
+    0: every frame annotated (the reference's 100 % setting), 1: sparse annotation (frames without truth inside the window),
+    2: short video, window at the start with skip 1, 3: single annotated frame, 4: no annotated frame, 5: test split."""
+    rng = np.random.default_rng(500 + k)
+    F = [30, 34, 12, 26, 20, 28][k]
+    frames = rng.integers(0, 256, (F, 256, 256, 3), dtype=np.uint8)
+    masks = np.zeros((F, 256, 256, 1))
+    for f in range(F):
+        y, x = 60 + f, 40 + 2 * f
+        masks[f, y:y + 90, x:x + 60, 0] = rng.integers(0, 6, (90, 60))
+    ann = [np.arange(F), np.array([3, 9, 10, 17, 30]), np.array([1, 2, 5]), np.array([14]), np.array([], dtype=np.int64), np.arange(F)][k]
+    return frames, masks, 3 + k, ann, k != 5
+
+
+N_JHMDB = 6

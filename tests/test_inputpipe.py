@@ -90,3 +90,36 @@ def test_device_frames_and_bad_arguments():
         ops.clip_from_u8(video.cuda(), span, 7, 26, rects.cuda())
     with pytest.raises(RuntimeError, match="frame"):
         ops.clip_from_u8(video.cuda(), [0, 1, 2, 3, 4, 5, 6, 12], 0, 0, None)
+
+
+# ---------------------------------------------------------------- JHMDB form (datasets/jhmdb_dataloader.py:102-230)
+@pytest.mark.parametrize("k", range(fx.N_JHMDB))
+def test_oracle_matches_reference_jhmdb_loader(k):
+    G = np.load(GOLD)
+    frames, masks, label, ann, train = fx.jhmdb_case(k)
+    np.random.seed(2000 + k)
+    s = oi.get_item_jhmdb(frames, masks.copy(), label, ann, train)
+    d, a, m, mc = s["data"].numpy(), s["aug_data"].numpy(), s["loc_msk"].numpy(), s["mask_cls"].numpy()
+    assert np.array_equal(d[:, :, ::9, ::7], G["jdata_%d" % k]) and np.array_equal(a[:, :, ::9, ::7], G["jaug_%d" % k])
+    assert np.array_equal(np.packbits(m.astype(np.uint8)), G["jmask_%d" % k]) and np.array_equal(mc[0, :, 0, 0], G["jmcls_%d" % k])
+    assert np.array_equal(np.array([d.sum(), a.sum(), m.sum(), mc.sum(), float(s["action"][0])]), G["jsums_%d" % k])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k", range(fx.N_JHMDB))
+def test_device_pipeline_matches_reference_jhmdb_loader(k):
+    from picons_amd import inputpipe as ip
+    G = np.load(GOLD)
+    frames, masks, label, ann, train = fx.jhmdb_case(k)
+    np.random.seed(2000 + k)
+    s = ip.get_item_jhmdb(frames, masks.copy(), label, ann, train)
+    np.random.seed(2000 + k)
+    o = oi.get_item_jhmdb(frames, masks.copy(), label, ann, train)
+    for key in ("data", "aug_data", "loc_msk", "mask_cls"):
+        got = s[key].cpu().numpy()
+        assert got.dtype == np.float32 and np.array_equal(got, o[key].numpy().astype(np.float32)), key
+    assert np.array_equal(np.packbits(s["loc_msk"].cpu().numpy().astype(np.uint8)), G["jmask_%d" % k])
+    assert np.array_equal(s["mask_cls"].cpu().numpy()[0, :, 0, 0], G["jmcls_%d" % k].astype(np.float32))
+    assert float(s["action"][0]) == G["jsums_%d" % k][4]
+    if k == 1:
+        assert 0 < G["jmcls_%d" % k].sum() < 8            # the sparse case really has frames without truth inside the window

@@ -44,6 +44,22 @@ def main():
         out["mask_%d" % k] = np.packbits(m.astype(np.uint8))
         out["sums_%d" % k] = np.array([d.sum(), a.sum(), m.sum(), float(s["action"][0]), float(s["label_vid"])])
         out["dtypes_%d" % k] = np.array([str(s["data"].dtype), str(s["loc_msk"].dtype), str(s["aug_data"].dtype)])
+    # JHMDB: __getitem__ after load_video (datasets/jhmdb_dataloader.py:102-230); load_video itself (cv2 decode / resize, .mat) is stubbed
+    sys.modules["cv2"].INTER_AREA = 3; sys.modules["cv2"].INTER_NEAREST = 0
+    jm = importlib.import_module("datasets.jhmdb_dataloader")
+    for k in range(fx.N_JHMDB):
+        frames, masks, label, ann, train = fx.jhmdb_case(k)
+        ds = object.__new__(jm.JHMDB)
+        ds.name = "train" if train else "test"; ds._height = ds._width = 224; ds.vid_files = ["v%d" % k]
+        ds.load_video = lambda name, fr=frames, mk=masks, lb=label, an=ann: (fr.astype(np.float64), mk.copy(), lb, an)   # frames as the loader holds them: float64
+        np.random.seed(2000 + k)
+        s = ds[0]
+        d = s["data"].numpy(); m = s["loc_msk"].numpy(); a = s["aug_data"].numpy(); mc = s["mask_cls"].numpy()
+        out["jdata_%d" % k] = d[:, :, ::9, ::7].astype(np.float64)
+        out["jaug_%d" % k] = a[:, :, ::9, ::7].astype(np.float64)
+        out["jmask_%d" % k] = np.packbits(m.astype(np.uint8))
+        out["jmcls_%d" % k] = mc[0, :, 0, 0].copy()
+        out["jsums_%d" % k] = np.array([d.sum(), a.sum(), m.sum(), mc.sum(), float(s["action"][0])])
     path = os.path.join(ROOT, "tests", "golden", "input_pipe.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), [float(out["sums_%d" % k][2]) for k in range(fx.N_CASES)])
