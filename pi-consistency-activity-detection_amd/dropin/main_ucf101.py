@@ -5,6 +5,7 @@ model, the bv/gv masks and the optimiser step running on MI355X HIP kernels.
 
 New behaviour is switched by environment variables only, so the CLI is unchanged:
   PICONS_SYNTHETIC=1     synthetic UCF101-24-shaped minibatches (no dataset / decoder libs on the box)
+  PICONS_SYNTHETIC=u8    synthetic decoded uint8 videos + box annotations through the device input pipeline (picons_amd.inputpipe)
   PICONS_STEPS=<n>       steps per epoch in synthetic mode (default 4)
   PICONS_FUSED=0         use the nn.Module + autograd path (model called twice, torch.optim.Adam) instead of
                          the fused step engine (default 1: picons_amd.step.StepEngine, both passes batched)
@@ -122,6 +123,23 @@ class SyntheticLoader:
             yield {k: torch.from_numpy(v) for k, v in mb.items()}
 
 
+class SyntheticVideoLoader(SyntheticLoader):
+    """PICONS_SYNTHETIC=u8: synthetic DECODED videos (uint8 frames + box annotations, what `load_video` has after `vread`) go
+    through the device input pipeline (picons_amd.inputpipe.get_item = UCF101DataLoader.__getitem__ from that point on) and are
+    collated like torch's default collate does, as device fp32 tensors."""
+
+    def __iter__(self):
+        from picons_amd import inputpipe
+        for i in range(self.steps):
+            samples = []
+            for j in range(self.n):
+                frames, ann = synthetic.make_decoded_video(((1234 + self.rank) * 7919 + 2 * i + self.salt) * 64 + j, self.labeled, self.nc)
+                samples.append(inputpipe.get_item(frames, ann, train=True))
+            yield {'data': torch.stack([s['data'] for s in samples]), 'aug_data': torch.stack([s['aug_data'] for s in samples]),
+                   'loc_msk': torch.stack([s['loc_msk'] for s in samples]), 'action': torch.stack([s['action'] for s in samples]),
+                   'label_vid': torch.tensor([s['label_vid'] for s in samples])}
+
+
 def train(args, model, labeled_train_loader, unlabeled_train_loader, optimizer, epoch, save_path, writer, ramp_wt, engine=None, reducer=None):
     """main_ucf101.py:155-223."""
     model.train(mode=True)
@@ -228,11 +246,13 @@ def run(args):
     hw = int(os.environ.get("PICONS_HW", "224"))
     fused = os.environ.get("PICONS_FUSED", "1") != "0"
     steps = int(os.environ.get("PICONS_STEPS", "4"))
-    if os.environ.get("PICONS_SYNTHETIC", "1") != "1":
-        raise RuntimeError("real UCF101/JHMDB loaders need skvideo/cv2 + the dataset, neither is available here; set PICONS_SYNTHETIC=1")
+    mode = os.environ.get("PICONS_SYNTHETIC", "1")
+    if mode not in ("1", "u8"):
+        raise RuntimeError("real UCF101/JHMDB loaders need skvideo/cv2 + the dataset, neither is available here; set PICONS_SYNTHETIC=1 (or u8)")
     n = args.bs // 2
-    labeled_loader = SyntheticLoader(n, True, steps, rank, NUM_CLASSES, hw, 0)
-    unlabeled_loader = SyntheticLoader(n, False, steps, rank, NUM_CLASSES, hw, 1)
+    Loader = SyntheticVideoLoader if (mode == "u8" and hw == 224 and DATASET == "ucf101") else SyntheticLoader
+    labeled_loader = Loader(n, True, steps, rank, NUM_CLASSES, hw, 0)
+    unlabeled_loader = Loader(n, False, steps, rank, NUM_CLASSES, hw, 1)
     val_loader = SyntheticLoader(args.bs, True, 1, rank, NUM_CLASSES, hw, 5)
     print(len(labeled_loader), len(unlabeled_loader), len(val_loader))
 

@@ -89,12 +89,13 @@ class StepEngine:
 
     def load_state(self, state):
         """state: reference-layout state_dict (numpy or torch values, SURVEY §5 key names)."""
+        T = lambda v: (v.detach() if torch.is_tensor(v) else torch.as_tensor(np.asarray(v))).to(self.dev)     # host or device values
         for k in self.plan.pshape:
-            self.param(k).copy_(torch.as_tensor(np.asarray(state[k])).to(self.dev))
+            self.param(k).copy_(T(state[k]))
         for k, o in self.plan.roff.items():
-            v = torch.as_tensor(np.asarray(state[k])).to(self.dev)
+            v = T(state[k])
             self.R[o:o + v.numel()].copy_(v)
-        self.nbt = {k: int(np.asarray(v)) for k, v in state.items() if k.endswith("num_batches_tracked")}
+        self.nbt = {k: int(v.item() if torch.is_tensor(v) else np.asarray(v)) for k, v in state.items() if k.endswith("num_batches_tracked")}
 
     def state_dict(self):
         sd = {}

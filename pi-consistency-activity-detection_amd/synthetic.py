@@ -121,3 +121,18 @@ def make_eval_videos(n, seed=1234, num_classes=24, hw=224):
         video = rng.random((F, hw, hw, 3), dtype=np.float32)
         out.append((video, bbox, vi % num_classes))
     return out
+
+
+def make_decoded_video(seed, labeled=True, num_classes=24, frames_hw=(240, 320)):
+    """One synthetic decoded training video in the form datasets/ucf_dataloader.py `load_video` consumes after `vread`:
+    (uint8 frames [F,H,W,3], annotations [(start, end, label, [[x,y,w,h] per frame], [annotated frame ids], labeled_vid)])."""
+    rng = np.random.default_rng(seed)
+    F = int(rng.integers(32, 48))
+    H, W = frames_hw
+    frames = rng.integers(0, 256, (F, H, W, 3), dtype=np.uint8)
+    s, e = int(rng.integers(0, 4)), int(rng.integers(F - 6, F - 1))
+    x, y = int(rng.integers(0, W - 160)), int(rng.integers(0, H - 140))
+    bw, bh = int(rng.integers(40, 140)), int(rng.integers(40, 120))
+    boxes = [[min(W - bw, x + (f - s)), min(H - bh, y + (f - s) // 2), bw, bh] for f in range(s, e + 1)]
+    annot = sorted(int(v) for v in rng.choice(np.arange(s + 4, e - 4), size=3, replace=False))
+    return frames, [(s, e, int(rng.integers(0, num_classes)), boxes, annot, 1 if labeled else 0)]
