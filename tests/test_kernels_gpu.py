@@ -58,6 +58,9 @@ CONV_CASES = [
     (64, 192, (3, 3, 3), (2, 1, 1), (4, 6, 56), 2),       # temporal stride 2: row-segment wgrad with 64-channel blocks
     (96, 128, (3, 3, 3), (1, 1, 1), (2, 5, 28), 2),       # row-segment wgrad with 32-channel blocks
     (160, 320, (3, 3, 3), (1, 1, 1), (1, 4, 28), 2),
+    (64, 64, (3, 3, 3), (1, 1, 1), (2, 16, 32), 2),       # 128 x 64 tiles on whole 8 x 16 position blocks
+    (32, 192, (3, 3, 3), (2, 1, 1), (4, 24, 48), 1),      # temporal stride 2, three 64-column tiles
+    (96, 64, (1, 3, 3), (1, 1, 1), (1, 8, 16), 4),        # 1x3x3 taps, one tile per plane
 ]
 
 
