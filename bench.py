@@ -62,8 +62,8 @@ def cpu_baseline(seconds_budget=30.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)        # >= 20 timed steps after >= 5 warm-up
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bs", type=int, default=8)
     ap.add_argument("--gv", action="store_true", help="BASELINE config 3 (--gv instead of --bv)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
