@@ -50,6 +50,17 @@ def test_clip_builder_matches_literal_loop(vids):
 
 
 @pytest.mark.gpu
+def test_device_clip_builder_matches_host_builder(vids):
+    from picons_amd import evalmetrics as em
+    for video, bbox, _lab in vids[:4] + vids[-2:]:
+        c, b = em.make_clips(video, bbox)
+        d, bd = em.make_clips_device(video, bbox)
+        assert d.shape[0] == c.shape[0]
+        if c.shape[0]:
+            assert np.array_equal(d.cpu().numpy(), np.transpose(c, [0, 4, 1, 2, 3])) and np.array_equal(bd.cpu().numpy(), b[..., 0])
+
+
+@pytest.mark.gpu
 def test_hip_accumulation_matches_reference_loop(vids):
     from picons_amd import evalmetrics as em
     G = np.load(GOLD)
@@ -60,6 +71,11 @@ def test_hip_accumulation_matches_reference_loop(vids):
     assert r["n_correct"] == int(G["n_correct"])
     assert np.array_equal(r["fmAP"], G["fmAP"], equal_nan=True) and np.array_equal(r["vmAP"], G["vmAP"], equal_nan=True)
     assert r["accuracy"] == int(G["n_correct"]) / float(G["n_vids"].sum())
+    # clips of consecutive videos packed into full batches: same tables
+    rp = em.evaluate(ef.FakeNet().eval().cuda(), vids, pack=True).result()
+    for k in ("frame_ious", "video_ious", "n_tot_frames", "n_vids"):
+        assert np.array_equal(rp[k], G[k]), k
+    assert rp["n_correct"] == int(G["n_correct"])
 
 
 @pytest.mark.gpu
