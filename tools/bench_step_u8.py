@@ -48,8 +48,36 @@ def main():
         out = one(i)
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
+
+    # the same with the next step's samples prepared on a side stream while the current step runs (the step's own
+    # read-back stays where it is: after Adam)
+    side = torch.cuda.Stream()
+
+    def prep(i):
+        with torch.cuda.stream(side):
+            lab = collate([inputpipe.get_item(*vids[(8 * i + j) % 16], train=True) for j in range(4)])
+            unl = collate([inputpipe.get_item(*vids[(8 * i + 4 + j) % 16], train=True) for j in range(4)])
+            ev = torch.cuda.Event(); ev.record(side)
+        perm = torch.randperm(bs, generator=g).numpy()
+        drops = [(torch.rand(bs, c, generator=g) < 0.5).float().numpy() * 2 for c in (832, 128, 832, 128)]
+        return lab, unl, perm, drops, ev
+    nxt = prep(0)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        lab, unl, perm, drops, ev = nxt
+        torch.cuda.current_stream().wait_event(ev)
+        eng.stage(lab, unl, perm, drops)
+        eng.forward_backward(1, ramp)
+        eng.adam(args.lr, 1.0)
+        nxt = prep(i + 1)                       # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above
+        out2 = eng.read_scalars()               # the step's one host sync
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / steps * 1e3
     print(json.dumps({"metric": "train clips/sec incl. input preparation from host uint8 frames (bs=8)", "value": bs / ms * 1e3, "unit": "clips/s",
-                      "ms_per_step": ms, "steps": steps, "loss_total": out["total"]}))
+                      "ms_per_step": ms, "steps": steps, "loss_total": out["total"],
+                      "overlapped": {"value": bs / ms2 * 1e3, "unit": "clips/s", "ms_per_step": ms2, "loss_total": out2["total"],
+                                     "how": "next step's samples prepared on a side stream between Adam's enqueue and the loss read-back"}}))
 
 
 if __name__ == "__main__":
