@@ -51,3 +51,15 @@ def test_bad_descriptor_is_reported_without_gpu(built):
     d = ops.conv_desc(desc.conv_fwd(1, (1, 2, 2), 3, 3, 4, 4, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 2, 2)))
     rc = built.pc_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, None)
     assert rc == -1 and b"multiples of 4" in built.pc_last_error()
+
+
+def test_tools_and_dropin_scripts_compile():
+    """Every script under tools/ and dropin/ at least parses (they only run on a GPU box or in the authoring container)."""
+    import glob
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = glob.glob(os.path.join(root, "tools", "*.py")) + glob.glob(os.path.join(root, "pi-consistency-activity-detection_amd", "dropin", "**", "*.py"), recursive=True) + \
+        [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 15
+    for f in files:
+        compile(open(f).read(), f, "exec")
