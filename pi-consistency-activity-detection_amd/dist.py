@@ -46,26 +46,52 @@ class GradReducer:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
+        # RCCL reduces device memory in place.  With any other backend (gloo: the single-GPU two-process test of the real
+        # engine, tests/test_dp_gpu.py -- RCCL refuses two ranks on one device) device gradients are staged through pinned
+        # host memory: D2H on the side stream behind the bucket's event, the host all-reduce and the H2D copy in wait().
+        self.host_staged = bool(self.cuda and self.world > 1 and dist.get_backend(group) != "nccl")
+        self.host = torch.empty(flat_grad.numel(), dtype=flat_grad.dtype).pin_memory() if self.host_staged else None
         self.handles = []
+        self.launched = []
 
-    def launch(self, i):
+    def launch(self, i, streams=()):
+        """Start bucket i's all-reduce behind everything enqueued so far on torch's current stream and on `streams`
+        (the engine's side lanes: Plan.grad_buckets only marks a bucket ready at joined points, waiting on the
+        side lanes as well makes that independent of the plan)."""
         if self.world == 1:
             return
         _ready, a, b = self.buckets[i]
         view = self.g[a:b]
+        self.launched.append(i)
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream())
+            self.comm_stream.wait_event(ev)
+            for s in streams:
+                self.comm_stream.wait_stream(s)
             with torch.cuda.stream(self.comm_stream):
-                self.comm_stream.wait_event(ev)
-                self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.host_staged:
+                    self.host[a:b].copy_(view, non_blocking=True)
+                else:
+                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def wait(self):
+        """Join every launched bucket before the optimiser reads the gradient."""
+        if self.host_staged and self.launched:
+            self.comm_stream.synchronize()
+            for i in self.launched:
+                _ready, a, b = self.buckets[i]
+                dist.all_reduce(self.host[a:b], op=dist.ReduceOp.SUM, group=self.group)
+            with torch.cuda.stream(self.comm_stream):
+                for i in self.launched:
+                    _ready, a, b = self.buckets[i]
+                    self.g[a:b].copy_(self.host[a:b], non_blocking=True)
         for h in self.handles:
             h.wait()
         self.handles = []
+        self.launched = []
         if self.cuda and self.world > 1:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
@@ -88,3 +114,13 @@ def barrier_max_ms(ms, device=None):
     t = torch.tensor([ms], dtype=torch.float64, device=device or ("cuda" if torch.cuda.is_available() and dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def mean_over_ranks(values, device=None):
+    """Mean over ranks of a few host scalars (losses that drive the LR scheduler / checkpoint policy).  Identity for world 1."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [float(v) for v in values]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64,
+                     device=device if (device and dist.get_backend() == "nccl") else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [float(v) / dist.get_world_size() for v in t.tolist()]

@@ -45,6 +45,8 @@ def iou(split, argv=None):
     args = parser.parse_args(argv)
     random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
 
+    os.environ.setdefault("PICONS_SYNTHETIC", "1")       # also lets CapsNet() start without rgb_charades.pt: every checkpoint
+                                                         # loaded below overwrites the whole state anyway
     jhmdb = os.environ.get("PICONS_DATASET", "ucf101") == "jhmdb"
     n_classes = 21 if jhmdb else 24
     if jhmdb:

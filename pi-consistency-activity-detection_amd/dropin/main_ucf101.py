@@ -246,7 +246,7 @@ def run(args):
     hw = int(os.environ.get("PICONS_HW", "224"))
     fused = os.environ.get("PICONS_FUSED", "1") != "0"
     steps = int(os.environ.get("PICONS_STEPS", "4"))
-    mode = os.environ.get("PICONS_SYNTHETIC", "1")
+    mode = os.environ.setdefault("PICONS_SYNTHETIC", "1")
     if mode not in ("1", "u8"):
         raise RuntimeError("real UCF101/JHMDB loaders need skvideo/cv2 + the dataset, neither is available here; set PICONS_SYNTHETIC=1 (or u8)")
     n = args.bs // 2
@@ -265,6 +265,9 @@ def run(args):
     scheduler = optim.lr_scheduler.ReduceLROnPlateau(optimizer, 'min', min_lr=1e-7, patience=5, factor=0.1)
     ramp_wt = ramp_ups.exp_rampup(args.epochs)
     engine = reducer = None
+    if world > 1 and not fused:
+        # the nn.Module path has no gradient exchange: N ranks would train N independent models and rank 0's would be saved
+        raise RuntimeError("WORLD_SIZE > 1 needs the fused step (PICONS_FUSED=1): the autograd path does no gradient all-reduce")
     if fused:
         engine = pstep.StepEngine(args, bs=args.bs, hw=hw, num_classes=NUM_CLASSES, jhmdb=(DATASET == "jhmdb"), state=model.state_dict(),
                                   device="cuda:%d" % local)
@@ -279,6 +282,10 @@ def run(args):
         if engine is not None:
             model.load_state_dict(engine.state_dict())
         val_loss = validate(model, val_loader, e)
+        # data parallel: every rank must take the same scheduler / checkpoint decisions, so they are taken on the mean of the
+        # per-rank losses (each rank saw its own shard); otherwise ReduceLROnPlateau fires on one rank and the replicas
+        # train at different learning rates from then on
+        train_loss, val_loss = pdist.mean_over_ranks([train_loss, val_loss], device="cuda:%d" % local)
         if rank == 0 and val_loss < prev_best_val_loss:           # checkpoint policy of main_ucf101.py:439-455
             print("Yay!!! Got the val loss down...")
             p = os.path.join(model_save_dir, f'best_model_val_loss_{e}.pth')

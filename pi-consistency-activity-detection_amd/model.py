@@ -34,6 +34,7 @@ class _Slot:
         self.a0 = base - self.arena.data_ptr()
         self.ops = p.resolve(dict(A=base, P=owner._P.data_ptr(), G=owner._G.data_ptr(), M=0, V=0, R=owner._R.data_ptr()))
         self.busy = False
+        self.gen = 0             # bumped each time the slot is taken by a training forward (see _SlotGuard)
         p.upload_consts(self.view)
 
     def view(self, ref, nfloats, dtype=torch.float32):
@@ -41,10 +42,24 @@ class _Slot:
         return self.arena[o:o + 4 * nfloats].view(dtype)
 
 
+class _SlotGuard:
+    """Lives on the autograd ctx of one training forward.  If that graph is dropped without a backward (loss skipped, an
+    exception between forward and backward), the ctx dies and the arena slot is released instead of staying busy forever;
+    the generation check keeps a late finaliser from freeing a slot that a newer forward has taken since."""
+
+    def __init__(self, slot):
+        self.slot, self.gen = slot, slot.gen
+
+    def __del__(self):
+        if self.slot.gen == self.gen:
+            self.slot.busy = False
+
+
 class _CapsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner, slot, n, *params):
         ctx.owner, ctx.slot, ctx.n = owner, slot, n
+        ctx.guard = _SlotGuard(slot)
         ops.run_ops(slot.ops["prep"])
         ops.run_ops(slot.ops["fwd"])
         p = slot.plan
@@ -75,12 +90,14 @@ class _CapsFn(torch.autograd.Function):
 
 
 class CapsNet(nn.Module):
-    """capsules_ucf101.py:334-512.  `pt_path` is loaded if the file exists (trunk keys copied like
-    :343-352); otherwise the deterministic synthetic initialiser is used (no network for the real
-    rgb_charades.pt).  hw / num_classes generalise the reference's fixed 224 / 24."""
+    """capsules_ucf101.py:334-512.  Initial state: init="reference" (default) draws what constructing the reference's
+    CapsNet leaves in the parameters (synthetic.init_state_module: PrimaryCaps N(0, 0.1), ConvCaps randn, BN 1/0, PyTorch's
+    default conv init); init="conditioned" is the parity-test initialiser (SURVEY finding 4).  `pt_path` supplies the trunk
+    (keys copied like :343-352); a missing file raises like the reference's torch.load does, unless PICONS_SYNTHETIC is set
+    (no network for the real rgb_charades.pt) or pt_path is None.  hw / num_classes generalise the fixed 224 / 24."""
 
     def __init__(self, pt_path='../weights/rgb_charades.pt', P=4, pretrained_load='i3d', num_classes=24, hw=224,
-                 device=None, seed=47):
+                 device=None, seed=47, init="reference"):
         super().__init__()
         if not torch.cuda.is_available():
             raise RuntimeError("CapsNet (HIP) needs a GPU: there is no CPU fallback")
@@ -102,8 +119,18 @@ class CapsNet(nn.Module):
             self._params.append(nn.Parameter(self._P[o:o + int(np.prod(shp))].view(shp)))
         self._nbt = {k: 0 for k in spec.buffer_shapes() if k.endswith("num_batches_tracked")}
         self._slots = {}
-        self.load_state_dict(synthetic.init_state(seed, num_classes))
+        if init not in ("reference", "conditioned"):
+            raise ValueError("init must be 'reference' or 'conditioned'")
+        self.load_state_dict(synthetic.init_state_module(seed, num_classes) if init == "reference" else synthetic.init_state(seed, num_classes))
         import os
+        import sys
+        if pt_path and not os.path.exists(pt_path):
+            if os.environ.get("PICONS_SYNTHETIC", "") in ("", "0"):
+                raise FileNotFoundError("pretrained trunk %r not found (the reference's torch.load raises here too: "
+                                        "capsules_ucf101.py:344); pass pt_path=None or set PICONS_SYNTHETIC=1 to train the trunk from its "
+                                        "random initialisation" % pt_path)
+            print("WARNING: pretrained trunk %r not found; PICONS_SYNTHETIC is set, the I3D trunk keeps its random initialisation" % pt_path,
+                  file=sys.stderr)
         if pt_path and os.path.exists(pt_path):
             pre = torch.load(pt_path, map_location="cpu")
             sd = {"conv1." + k: v for k, v in pre.items() if "conv1." + k in self._keyset()}
@@ -202,10 +229,13 @@ class CapsNet(nn.Module):
             s.view(p.in_drop832, n * spec.TRUNK_OUT_CH).copy_((torch.rand(n * spec.TRUNK_OUT_CH, device=self.dev) < 0.5).float() * 2)
             s.view(p.in_drop128, n * 128).copy_((torch.rand(n * 128, device=self.dev) < 0.5).float() * 2)
             s.ops["fwd"][p.op_cmask]["i"][3] = 0 if epoch < thresh_ep else 1
-            s.busy = True
             for k in self._nbt:
                 self._nbt[k] += 1
-            return _CapsFn.apply(self, s, n, *self._params)
+            if torch.is_grad_enabled():
+                s.busy = True            # released by _CapsFn.backward, or by _SlotGuard if the graph is dropped
+                s.gen += 1
+                return _CapsFn.apply(self, s, n, *self._params)
+            # train-mode forward under no_grad (batch statistics, dropout): no backward will come, the slot stays free
         with torch.no_grad():
             ops.run_ops(s.ops["prep"])
             ops.run_ops(s.ops["fwd"])

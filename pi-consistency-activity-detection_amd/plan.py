@@ -117,7 +117,8 @@ class Plan:
         self.kg_base = self.alloc(self.kg_cap // 4)
         self.kg_used = 0
         self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
-        self.alg_flops = {}       # list name -> algorithmic conv FLOPs (all taps, as the reference's convs count them)
+        self.alg_flops = {}       # list name -> conv FLOPs as the layer's own formulation counts them (all taps, padding included)
+        self.issued = {}          # (list name, op kind) -> FLOPs the emitted (trimmed) descriptors multiply, real channel counts
 
     # ------------------------------------------------------------------ memory
     def alloc(self, nfloats, name=""):
@@ -277,7 +278,14 @@ class Plan:
         Dgrad launches book the layer's FORWARD FLOPs once (alg_dgrad) and pass alg=0, so gather-form overheads
         (padding taps, the 28x28 gather of the 20x20 PrimaryCaps dgrad) never inflate the roofline numerator."""
         self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + (_conv_flops(d) if alg is None else alg)
-        self.emit(capi.OP_CONV, i=D.flatten(D.trim_conv(d), D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+        t = D.trim_conv(d)
+        self.issued[(self.cur, capi.OP_CONV)] = self.issued.get((self.cur, capi.OP_CONV), 0) + _conv_flops(t)
+        self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+
+    def wgrad_op(self, d, p):
+        """Emit a weight-gradient launch and book the FLOPs its (already trimmed) descriptor multiplies."""
+        self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
+        self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p)
 
     def unit3d(self, pre, x, cout, k, stride, out=None, need_dx=True):
         """Unit3D (pytorch_i3d.py:89-120): SAME conv (no bias) -> BN(train) -> ReLU.
@@ -294,16 +302,18 @@ class Plan:
                         raise RuntimeError("stacked Unit3Ds need adjacent %s (%s)" % (sfx, q))
                     o += c
         Ci = x.C
+        Ci_real = self.pshape[pre + ".conv3d.weight"][1]          # 3 for the RGB stem, whose clip is padded to 4 channels
         othw = tuple(spec.same_out(x.thw[i], k[i], stride[i]) for i in range(3))
         pf = [spec.same_pad(x.thw[i], k[i], stride[i])[0] for i in range(3)]
-        w = self.prep_conv_weight([q + ".conv3d.weight" for q in pres], couts, self.pshape[pre + ".conv3d.weight"][1], k, need_dx, Ipad=Ci)
+        w = self.prep_conv_weight([q + ".conv3d.weight" for q in pres], couts, Ci_real, k, need_dx, Ipad=Ci)
         z = self.tensor(x.N, othw, cout, pre + ".z")
         y = out if out is not None else self.tensor(x.N, othw, cout, pre + ".y")
         stat = self.alloc(self.groups * 4 * cout)
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
-        F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw))
+        F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         if self.training:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART, groups=self.groups)
+            d["Ci_real"] = Ci_real
             nrows = _bnpart_rows(d)
             part = self.alloc(nrows * 2 * cout)
             self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part)
@@ -313,6 +323,7 @@ class Plan:
             g_apply = self.groups
         else:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw)
+            d["Ci_real"] = Ci_real
             self.conv_op(d, x.ref, w["fwd"], z.ref)
             self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
                       p=[gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
@@ -330,8 +341,9 @@ class Plan:
                 ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
                 self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
                           p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
-                self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf)), D.WGRAD_FIELDS),
-                          p=[dz.ref, x.ref, w["kg"]])
+                wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
+                wd["Cs_real"] = Ci_real
+                self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]])
                 self.flush_grad(w)
                 self.mark_final(*[q + sfx for q in pres for sfx in (".bn.weight", ".bn.bias")])
             if need_dx and part in ("all", "B"):
@@ -449,8 +461,7 @@ class Plan:
             ws = self.alloc(_act_bwd_ws(out.rows, cout))
             self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), D.WGRAD_FIELDS),
-                      p=[dz.ref, x.ref, w["kg"]])
+            self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), [dz.ref, x.ref, w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
             if need_dx:
@@ -492,8 +503,7 @@ class Plan:
             else:
                 self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
-            self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), D.WGRAD_FIELDS),
-                      p=[x.ref, dz.ref, w["kg"]])
+            self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), [x.ref, dz.ref, w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
@@ -528,7 +538,7 @@ class Plan:
             dtpl = self.alloc(SL.G * SL.t_g)
             dwv = self.alloc(SL.G * SL.w_g)
             self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dz.ld), capi.AXIS_FIELDS), p=[dz.ref, sm["Gt"], None, dtpl])
-            self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[xpl, dtpl, dwv])
+            self.wgrad_op(SL.wgrad(), [xpl, dtpl, dwv])
             self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[dwv, sm["tw"], w["kg"]])
             self.flush_grad(w)
             self.mark_final(name + ".bias")
@@ -659,13 +669,13 @@ class Plan:
                 dtpl = self.alloc(SL.G * SL.t_g)
                 dwv = self.alloc(SL.G * SL.w_g)
                 self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dtpl])
-                self.emit(capi.OP_WGRAD, i=D.flatten(SL.wgrad(), D.WGRAD_FIELDS), p=[dtpl, xpl, dwv])
+                self.wgrad_op(SL.wgrad(), [dtpl, xpl, dwv])
                 for nm, a0, cnt in pc_names:
                     self.emit(capi.OP_WSPEC_MASTER_BWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur, self.acc], p=[dwv, sm["tw"], self.G(nm)])
                 self.mark_final(*[nm for nm, _a, _c in pc_names])
             else:
-                self.emit(capi.OP_WGRAD, i=D.flatten(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))), D.WGRAD_FIELDS),
-                          p=[dcaps.ref, xd.ref, wpc["kg"]])
+                self.wgrad_op(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))),
+                              [dcaps.ref, xd.ref, wpc["kg"]])
             if not spectral_pc:
                 self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
@@ -719,6 +729,7 @@ class Plan:
         for dd in D.transposed_classes(N, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1, flags=capi.F_BIAS, groups=N):
             dd["wgstride"] = 32 * 27 * 128
             dd["bgstride"] = 32
+            dd["Co_real"] = J
             F_tail += _conv_flops(dd)
             self.conv_op(dd, cat112.ref, wf, proj.ref, bias=bc)
         out = self.tensor(N, othw, 1, "out")
@@ -736,14 +747,15 @@ class Plan:
             xin_per = cat112.thw[0] * cat112.thw[1] * cat112.thw[2] * cat112.ld
             # per-sample dWc[n][ci][tap][j] = sum_i x[n,i,ci] * dproj[n, 2i-1+k, j]: N problems in one launch
             wd = D.trim_wgrad(D.wgrad(1, cat112.thw, 128, cat112.ld, othw, 32, 32, k3, s2, p1))
-            wd.update(nbatch=N, dbstride=xin_per, sbstride=per_n * 32, gbstride=128 * 27 * 32)
-            self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS), p=[cat112.ref, dproj.ref, Gc])
+            wd.update(nbatch=N, dbstride=xin_per, sbstride=per_n * 32, gbstride=128 * 27 * 32, Cs_real=J)
+            self.wgrad_op(wd, [cat112.ref, dproj.ref, Gc])
             self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
                       p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
             self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
             dx, acc = self.grad_for_write(cat112)
             dd = D.conv_fwd(N, othw, 32, 32, 128, dx.ld, k3, s2, p1, cat112.thw, flags=capi.F_ACCUM if acc else 0, groups=N, ldw=32)
             dd["wgstride"] = 128 * 27 * 32
+            dd["Ci_real"] = J
             self.conv_op(dd, dproj.ref, wt, dx.ref, alg=F_tail)
         self.tape.append(bwd_smooth)
         return out
@@ -783,7 +795,7 @@ class Plan:
             self.fork()
             for z, wd in tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld):
                 self.lane = 0 if z == 0 else 1 % self.lanes
-                self.emit(capi.OP_WGRAD, i=D.flatten(wd, D.WGRAD_FIELDS), p=[cat112.ref, dcols, off(dW5, z * 128 * SP)])
+                self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, z * 128 * SP)])
             for q, (z, dd) in enumerate(tail6.dgrad_descs(N, cat112.thw, 128, dx.ld, acc)):
                 self.lane = 0 if z == 0 else 1 % self.lanes
                 self.conv_op(dd, dcols, off(w5t, z * 128 * SP), dx.ref, alg=F_t6 if q == 0 else 0)
@@ -807,8 +819,8 @@ class Plan:
         self.seg32 = self.in_seg
         self.dout = self.alloc(N * per)
         self.dpred = self.alloc(N * C)
-        self.scalars = self.alloc(16)
-        self.spread_out = self.alloc(4)
+        self.scalars = self.alloc(32)                 # [0,16) consistency / supervised scalars, [16,20) spread loss: one D2H reads both
+        self.spread_out = off(self.scalars, 16)
         self.emit(capi.OP_FILL, p=[self.dpred], l=[N * C], f=[0.0])
         self.op_spread = len(self.lists["loss"])
         self.emit(capi.OP_SPREAD, i=[n, C], f=[0.2, float(args.wt_cls)], p=[self.pred, self.in_cls, self.in_labeled, self.spread_out, self.dpred])
@@ -940,31 +952,25 @@ class Plan:
         return res
 
     def flops(self, only_kind=None):
-        """Algorithmic FLOPs (2*M*N*K, real channel counts) of the conv / wgrad ops per list."""
-        tot = {}
-        if only_kind == capi.OP_CONV:
-            return {name: self.alg_flops.get(name, 0) for name in self.lists}
-        for name, lst in self.lists.items():
-            s = 0
-            for kind, i, f, p, l, _lane in lst:
-                if only_kind is not None and kind != only_kind:
-                    continue
-                if kind == capi.OP_CONV:
-                    N, Ci, Tq, Hq, Wq, Co = i[0], i[4], i[6], i[7], i[8], i[12]
-                    nt = i[23] * i[24] * i[25]
-                    s += 2 * N * Tq * Hq * Wq * (27 if (Co == 32 and Ci == 128 and nt == 1) else Co) * (3 if Ci == 4 else (27 if (Ci == 32 and Co == 128 and nt == 1) else Ci)) * nt
-                elif kind == capi.OP_WGRAD:
-                    N, Tq, Hq, Wq, Cd, Cs = i[0], i[1], i[2], i[3], i[4], i[9]
-                    nt = i[14] * i[15] * i[16]
-                    nb = max(1, i[30]) if len(i) > 30 else 1          # problems batched in one launch (spectral PrimaryCaps)
-                    s += 2 * N * Tq * Hq * Wq * (27 if (Cd == 32 and Cs == 128 and nt == 1) else Cd) * (3 if Cs == 4 else Cs) * nt * nb
-            tot[name] = s
-        return tot
+        """FLOPs ISSUED per list (2*M*N*K of the emitted, tap-trimmed descriptors with the real channel counts -- zero-padding
+        taps dropped at descriptor level and padded channels are not work).  only_kind: OP_CONV / OP_WGRAD / None (both)."""
+        kinds = (capi.OP_CONV, capi.OP_WGRAD) if only_kind is None else (only_kind,)
+        return {name: sum(self.issued.get((name, k), 0) for k in kinds) for name in self.lists}
+
+    def flops_reference_counted(self):
+        """Conv / dgrad FLOPs per list as the layers' own formulation counts them (all taps incl. padding; every dgrad at its
+        layer's forward FLOPs).  Kept beside flops() so the two roofline fractions can be told apart."""
+        return {name: self.alg_flops.get(name, 0) for name in self.lists}
 
 
 def _conv_flops(d):
-    return 2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * (27 if (d["Co"] == 32 and d["Ci"] == 128) else d["Co"]) * \
-        (3 if d["Ci"] == 4 else (27 if (d["Ci"] == 32 and d["Co"] == 128) else d["Ci"])) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
+    """2*M*N*K of a conv descriptor with the real channel counts (Ci_real / Co_real where the kernel sees padded ones)."""
+    return 2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * d.get("Co_real", d["Co"]) * d.get("Ci_real", d["Ci"]) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
+
+
+def _wgrad_flops(d):
+    return (2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * d.get("Cd_real", d["Cd"]) * d.get("Cs_real", d["Cs"]) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
+            * max(1, d.get("nbatch", 0)))
 
 
 # --- workspace sizing mirrors of the C side (kept in sync by tests/test_plan_cpu.py on CPU)

@@ -123,12 +123,14 @@ class StepEngine:
         data = cat("data")[perm].to(self.dev, torch.float32, non_blocking=True)
         aug = cat("aug_data")[perm].to(self.dev, torch.float32, non_blocking=True)
         seg = cat("loc_msk")[perm].to(self.dev, torch.float32, non_blocking=True)
-        act = cat("action")[perm].reshape(-1).to(self.dev, torch.float32)
+        act_h = cat("action")[perm].reshape(-1).to(torch.float32)
         if self.jhmdb:        # main_jhmdb.py:68-70
             lab = torch.cat([torch.ones(len(label_mb["action"])), torch.zeros(len(unlabel_mb["action"]))])
         else:
             lab = cat("label_vid")
-        lab = lab[perm].to(self.dev, torch.int32)
+        lab_h = lab[perm].to(torch.int32)
+        self.labels_host, self.action_host = lab_h.cpu(), act_h.cpu()      # kept from the host inputs (no read-back)
+        act, lab = act_h.to(self.dev), lab_h.to(self.dev)
         self.aview(p.in_data, n * per).copy_(data.reshape(-1))
         self.aview(p.in_aug, n * per).copy_(aug.reshape(-1))
         self.aview(p.in_seg, n * per // 3).copy_(seg.reshape(-1))
@@ -137,8 +139,6 @@ class StepEngine:
         d = [torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.dev) for x in drops]
         self.aview(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH).copy_(torch.cat([d[0], d[2]]).reshape(-1))
         self.aview(p.in_drop128, 2 * n * 128).copy_(torch.cat([d[1], d[3]]).reshape(-1))
-        self.labels_host = lab.cpu()
-        self.action_host = act.cpu()
 
     # ------------------------------------------------------------------ execution
     def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
@@ -166,7 +166,7 @@ class StepEngine:
                 if ready > done:
                     run(o["bwd"][done:ready])
                     done = ready
-                reducer.launch(i)
+                reducer.launch(i, self.side)
             if done < len(o["bwd"]):
                 run(o["bwd"][done:])
 
@@ -182,9 +182,8 @@ class StepEngine:
 
     def read_scalars(self):
         """One packed D2H for the step's loss scalars (replaces the reference's five .item() syncs)."""
-        s = self.aview(self.plan.scalars, 16).cpu()
-        sp = self.aview(self.plan.spread_out, 2).cpu()
-        loc, cons, cls = float(s[0]), float(s[1]), float(sp[0])
+        s = self.aview(self.plan.scalars, 20).cpu()           # spread_out sits at scalars + 16 (plan.build_loss)
+        loc, cons, cls = float(s[0]), float(s[1]), float(s[16])
         a = self.args
         return dict(total=a.wt_loc * loc + a.wt_cls * cls + a.wt_cons * cons, loc=loc, cls=cls, cons=cons,
                     bce=float(s[2]), dice=float(s[3]), l2=float(s[4]), lvar=float(s[5]), lgrad=float(s[6]))
@@ -225,25 +224,3 @@ class StepEngine:
     def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, reducer=None):
         self.stage(label_mb, unlabel_mb, perm, drops)
         return self.run_staged(epoch, wt_ramp, lr, reducer)
-
-
-def smoke_check(device="cuda:0", hw=224):
-    """One bs=2 train step on the GPU checked against the CPU oracle (used by __graft_entry__.smoke)."""
-    import os
-    from oracle import step as ostep
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))   # the oracle crawls when torch oversubscribes a 256-thread host
-    args = default_args(bv=True, n_frames=5, wt_cons=0.1, lr=1e-4, epochs=100)
-    eng = StepEngine(args, bs=2, hw=hw, device=device)
-    lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=0, hw=hw)
-    ramp = exp_rampup(100)(1)
-    got = eng.train_step(lab, unl, 1, ramp, perm, drops)
-    out, _flip, pred = eng.outputs()
-    P = ostep.as_torch_params(synthetic.init_state(47, 24))
-    oa = ostep.default_args(bv=True, n_frames=5, wt_cons=0.1)
-    ref = ostep.train_step(P, oa, lab, unl, 1, ramp, perm, drops)
-    dl = max(abs(got[k] - float(ref[k])) for k in ("total", "loc", "cls", "cons"))
-    dp = (pred.cpu() - ref["predicted_action"]).abs().max().item()
-    dm = (out.cpu() - ref["output"]).abs().max().item()
-    print("smoke: |dloss| %.2e  |dlogits| %.2e  |dmask| %.2e  total %.6f" % (dl, dp, dm, got["total"]))
-    assert dl <= 1e-4 and dp <= 1e-3 and dm <= 1e-3, "HIP step disagrees with the CPU oracle"
-    return got

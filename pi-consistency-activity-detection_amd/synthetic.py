@@ -61,6 +61,46 @@ def init_state(seed=47, num_classes=24, conditioned=True):
     return out
 
 
+def init_state_module(seed=47, num_classes=24):
+    """What constructing the reference's CapsNet leaves in its parameters (synthetic draws of the same distributions):
+    PyTorch's default Conv / ConvTranspose init U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weights and biases, BatchNorm 1 / 0
+    (pytorch_i3d.py:69-80), PrimaryCaps weights N(0, 0.1) (capsules_ucf101.py:36,39), ConvCaps beta_u / beta_a / weights
+    randn (:97-103), upsample1-4 / smooth weights N(0, 0.02) (:359-374).  This is the drop-in CapsNet's initial state; the
+    trunk is then overwritten by rgb_charades.pt when that file exists (:343-352)."""
+    sd = OrderedDict()
+    shapes = spec.param_shapes(num_classes)
+    for name, shp in shapes.items():
+        g = _rng(name, seed + 7919)
+        n = int(np.prod(shp))
+        wname = name.rsplit(".", 1)[0] + ".weight"
+        if name.endswith(".bn.weight"):
+            v = np.ones(n)
+        elif name.endswith(".bn.bias"):
+            v = np.zeros(n)
+        elif name in ("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a"):
+            v = g.normal(0.0, 1.0, n)
+        elif name in ("primary_caps.pose.weight", "primary_caps.a.weight"):
+            v = g.normal(0.0, 0.1, n)
+        elif name.endswith(".weight") and (name.startswith("upsample") or name.startswith("smooth")):
+            v = g.normal(0.0, 0.02, n)
+        else:       # default-initialised conv weights and all conv biases: fan_in = weight.shape[1] * receptive field
+            wshp = shapes[wname] if wname in shapes else shp
+            bound = 1.0 / np.sqrt(int(np.prod(wshp[1:])))
+            v = g.uniform(-bound, bound, n)
+        sd[name] = v.astype(np.float32).reshape(shp)
+    out = OrderedDict()
+    for key in spec.state_dict_keys(num_classes):
+        if key in sd:
+            out[key] = sd[key]
+        elif key.endswith("running_mean"):
+            out[key] = np.zeros(spec.buffer_shapes()[key], np.float32)
+        elif key.endswith("running_var"):
+            out[key] = np.ones(spec.buffer_shapes()[key], np.float32)
+        else:
+            out[key] = np.zeros((), np.int64)
+    return out
+
+
 def make_minibatch(n, labeled, seed, num_classes=24, hw=224, frames=spec.FRAMES):
     """One dataloader-shaped dict (SURVEY §8(b) minibatch contract;
     /root/reference/datasets/ucf_dataloader.py:179-191): float64 `data`/`aug_data`

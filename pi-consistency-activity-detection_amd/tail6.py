@@ -5,6 +5,7 @@ sub-lattice of the [It][Ih][Iw] grid (index 0, or indices 1..I-1, per dimension)
 from . import desc as D
 
 SP = 128          # 125 column slots (k5t, k5h, k5w) padded to one 128-wide tile
+NSLOT = 125       # the slots that carry work (FLOP booking)
 
 
 def classes(thw):
@@ -29,6 +30,7 @@ def conv_descs(N, thw, Ci, ldx):
     """cols[n][i][:] = x[n][i][:] . W5f[n][z]: [(z, desc)], weights at W5f + z*SP*Ci, per-sample stride 8*SP*Ci."""
     base = D.conv_fwd(N, thw, Ci, ldx, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, groups=N)
     base["wgstride"] = 8 * SP * Ci
+    base["Co_real"] = NSLOT
     return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
 
 
@@ -37,6 +39,7 @@ def dgrad_descs(N, thw, Ci, lddx, accum):
     from . import capi
     base = D.conv_fwd(N, thw, SP, SP, Ci, lddx, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, flags=capi.F_ACCUM if accum else 0, groups=N)
     base["wgstride"] = 8 * Ci * SP
+    base["Ci_real"] = NSLOT
     return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
 
 
@@ -48,6 +51,6 @@ def wgrad_descs(N, thw, Ci, ldx):
     for z, s, e in classes(thw):
         d = D.wgrad(1, e, Ci, ldx, thw, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0))
         d.update(ioff0=list(s), Td=thw[0], Hd=thw[1], Wd=thw[2], doff=list(s),
-                 nbatch=N, dbstride=per * ldx, sbstride=per * SP, gbstride=8 * Ci * SP)
+                 nbatch=N, dbstride=per * ldx, sbstride=per * SP, gbstride=8 * Ci * SP, Cs_real=NSLOT)
         out.append((z, d))
     return out

@@ -20,21 +20,71 @@ def _oracle_params(ncls=24):
 
 
 def test_state_dict_surface():
-    m = pmodel.CapsNet(pt_path=None, hw=HW)
+    m = pmodel.CapsNet(pt_path=None, hw=HW, init="conditioned")
     sd = m.state_dict()
     assert list(sd.keys()) == spec.state_dict_keys(24) and len(sd) == 293
     ref = synthetic.init_state(47, 24)
     for k in ("conv1.Mixed_4f.b3b.conv3d.weight", "primary_caps.pose.weight", "upsample4.weight", "conv_caps.weights"):
         assert tuple(sd[k].shape) == ref[k].shape and np.array_equal(sd[k].cpu().numpy(), ref[k])
     assert sum(p.numel() for p in m.parameters()) == 48003705
-    m2 = pmodel.CapsNet(pt_path=None, hw=HW, seed=3)
+    m2 = pmodel.CapsNet(pt_path=None, hw=HW, seed=3, init="conditioned")
     m2.load_state_dict(sd)
     assert torch.equal(m2.state_dict()["smooth.weight"], sd["smooth.weight"])
 
 
+def test_default_init_follows_the_reference_and_missing_trunk_raises(monkeypatch, tmp_path):
+    """CapsNet() starts from what constructing the reference's module leaves in its parameters (capsules_ucf101.py:36,39,
+    97-103,359-374; pytorch_i3d.py:69-80), not from the parity-test initialiser; a missing rgb_charades.pt raises like the
+    reference's torch.load (:344) unless PICONS_SYNTHETIC says the run is synthetic."""
+    m = pmodel.CapsNet(pt_path=None, hw=HW)
+    sd = {k: v.cpu() for k, v in m.state_dict().items()}
+    assert abs(float(sd["primary_caps.pose.weight"].std()) - 0.1) < 2e-3 and abs(float(sd["primary_caps.a.weight"].std()) - 0.1) < 2e-3
+    assert abs(float(sd["conv_caps.weights"].std()) - 1.0) < 2e-2 and abs(float(sd["conv_caps.beta_u"].std()) - 1.0) < 0.15
+    for k in ("upsample1.weight", "upsample4.weight", "smooth.weight"):
+        assert abs(float(sd[k].std()) - 0.02) < 2e-3, k
+    for k, v in sd.items():
+        if k.endswith(".bn.weight"):
+            assert torch.all(v == 1), k
+        if k.endswith(".bn.bias"):
+            assert torch.all(v == 0), k
+    w = sd["conv112.weight"]
+    bound = 1.0 / (64 * 27) ** 0.5                        # PyTorch default: U(-1/sqrt(fan_in), 1/sqrt(fan_in)), bias too
+    assert float(w.abs().max()) <= bound and float(w.abs().max()) > 0.95 * bound
+    assert float(sd["conv112.bias"].abs().max()) <= bound
+    assert float(sd["upsample4.bias"].abs().max()) <= 1.0 / (128 * 27) ** 0.5        # ConvTranspose: fan_in from weight.shape[1]
+    monkeypatch.delenv("PICONS_SYNTHETIC", raising=False)
+    with pytest.raises(FileNotFoundError):
+        pmodel.CapsNet(pt_path=str(tmp_path / "no_such_rgb_charades.pt"), hw=HW)
+    monkeypatch.setenv("PICONS_SYNTHETIC", "1")
+    pmodel.CapsNet(pt_path=str(tmp_path / "no_such_rgb_charades.pt"), hw=HW)       # warns, keeps the random trunk
+
+
+def test_forward_without_backward_does_not_leak_arena_slots():
+    """A training-mode forward under no_grad takes no slot; a forward whose graph is dropped without backward gives its
+    slot back (the autograd ctx's guard), so repeated calls keep using ONE arena instead of allocating a new one each time."""
+    m = pmodel.CapsNet(pt_path=None, hw=HW, init="conditioned").cuda()
+    m.train(mode=True); m.training = True
+    x = torch.rand(2, 3, 8, HW, HW, device="cuda")
+    act, lab = torch.zeros(2, 1, device="cuda"), torch.tensor([1, 0], device="cuda")
+    with torch.no_grad():
+        for _ in range(3):
+            m(x, act, lab, 1, 11)
+    assert len(m._slots[(2, True)]) == 1 and not m._slots[(2, True)][0].busy
+    for _ in range(3):
+        out, pred, _f = m(x, act, lab, 1, 11)
+        assert m._slots[(2, True)][0].busy
+        del out, pred, _f                                  # graph dropped, no backward
+    assert len(m._slots[(2, True)]) == 1 and not m._slots[(2, True)][0].busy
+    a, _p, _f = m(x, act, lab, 1, 11)
+    b, _p2, _f2 = m(x, act, lab, 1, 11)                    # the reference's two passes: two live graphs -> two slots
+    assert len(m._slots[(2, True)]) == 2
+    (a.sum() + b.sum()).backward()
+    assert not any(s.busy for s in m._slots[(2, True)])
+
+
 def test_module_forward_backward_two_passes_vs_oracle():
     torch.manual_seed(0)
-    m = pmodel.CapsNet(pt_path=None, hw=HW).cuda()
+    m = pmodel.CapsNet(pt_path=None, hw=HW, init="conditioned").cuda()
     m.train(mode=True); m.training = True
     lab, unl, perm, _ = synthetic.make_step_inputs(2, hw=HW)
     data = torch.cat([torch.from_numpy(lab["data"]), torch.from_numpy(unl["data"])]).float()
@@ -83,7 +133,7 @@ def test_module_forward_backward_two_passes_vs_oracle():
 
 
 def test_eval_forward_and_trunk_vs_oracle():
-    m = pmodel.CapsNet(pt_path=None, hw=HW).cuda()
+    m = pmodel.CapsNet(pt_path=None, hw=HW, init="conditioned").cuda()
     m.eval(); m.training = False
     lab, unl, _, _ = synthetic.make_step_inputs(2, hw=HW)
     data = torch.cat([torch.from_numpy(lab["data"]), torch.from_numpy(unl["data"])]).float()
@@ -140,8 +190,8 @@ def test_pretrained_trunk_and_reference_checkpoint_loading(tmp_path):
     pre["logits.conv3d.bias"] = torch.randn(400, generator=g)
     path = str(tmp_path / "rgb_charades.pt")
     torch.save(pre, path)
-    m = pmodel.CapsNet(pt_path=path, hw=HW)
-    base = pmodel.CapsNet(pt_path=None, hw=HW).state_dict()
+    m = pmodel.CapsNet(pt_path=path, hw=HW, init="conditioned")
+    base = pmodel.CapsNet(pt_path=None, hw=HW, init="conditioned").state_dict()
     sd = m.state_dict()
     for k in sd:
         if k.startswith("conv1."):

@@ -130,7 +130,7 @@ def test_evaluate_with_the_real_network_teacher_forced():
     order, the (B,1,8,H,W) frame order against the truth frames and the ragged last batch are all exercised."""
     from picons_amd import evalmetrics as em, model as pmodel, synthetic
     hw = 112
-    m = pmodel.CapsNet(pt_path=None, hw=hw).cuda()
+    m = pmodel.CapsNet(pt_path=None, hw=hw, init="conditioned").cuda()
     m.eval(); m.training = False
     vids = synthetic.make_eval_videos(2, seed=3, hw=hw)
     rec = []
@@ -167,7 +167,7 @@ def test_dropin_evaluate_cli(tmp_path, monkeypatch, capsys):
     monkeypatch.setenv("PICONS_SYNTHETIC", "1"); monkeypatch.setenv("PICONS_EVAL_VIDEOS", "1")
     saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k in ("models", "utils") or k.startswith(("models.", "utils."))}
     try:
-        m = pmodel.CapsNet(pt_path=None)
+        m = pmodel.CapsNet(pt_path=None, init="conditioned")
         for tag in ("a", "b"):
             torch.save(m.state_dict(), str(tmp_path / ("best_model_train_%s.pth" % tag)))
         del m

@@ -149,7 +149,7 @@ def test_state_keys():
     assert len(spec.param_shapes(24)) == 158
 
 
-STEP_CASES = ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv"]
+STEP_CASES = ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8", "step_refinit_bv5"]
 
 
 @pytest.mark.parametrize("tag", STEP_CASES)
@@ -158,22 +158,27 @@ def test_full_step(golden_dir, tag):
     if not os.path.exists(path):
         pytest.skip("fixture not generated")
     if tag != "step_bv5" and not os.environ.get("PICONS_SLOW"):
-        pytest.skip("slow (≈40 s each): set PICONS_SLOW=1")
+        pytest.skip("slow (40 s each, 3 min for the bs = 8 cases): set PICONS_SLOW=1")
     S = np.load(path)
     ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
     akw = dict(eval(str(S["args"])))
     args = ostep.default_args(**akw)
-    state = synthetic.init_state(seed=47, num_classes=ncls, conditioned=True)
+    bs = int(S["bs"]) if "bs" in S.files else 2
+    conditioned = bool(int(S["conditioned"])) if "conditioned" in S.files else True
+    state = synthetic.init_state(seed=47, num_classes=ncls, conditioned=conditioned)
     P = ostep.as_torch_params(state)
-    lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=stepid, num_classes=ncls)
+    lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid, num_classes=ncls)
     torch.set_num_threads(int(S["_threads"]))
     r = ostep.train_step(P, args, lab, unl, epoch, float(S["ramp"]), perm, drops)
     r["total"].backward()
-    # bars from BASELINE.json north_star: logits / masks 1e-3, loss scalars 1e-4
-    close(r["predicted_action"], S["predicted_action"], 1e-3, what="logits")
-    close(r["output"][:, :, :, ::8, ::8], S["output_sample"], 1e-3, what="mask logits")
+    # bars from BASELINE.json north_star: logits / masks 1e-3, loss scalars 1e-4.  With the reference's own init (SURVEY
+    # finding 4) fp32 runs of the same code differ by more than that between thread counts; that fixture was produced at the
+    # thread count recorded in it, and gets the bars the reference meets against its own fp64 run (kept in the fixture)
+    t_out, t_loss = (1e-3, 1e-4) if conditioned else (5e-3, 5e-3)
+    close(r["predicted_action"], S["predicted_action"], t_out, what="logits")
+    close(r["output"][:, :, :, ::8, ::8], S["output_sample"], t_out, what="mask logits")
     for k in ("total", "loc", "cls", "cons"):
-        close(r[k], S[k], 1e-4, what=k)
+        close(r[k], S[k], t_loss, what=k)
     gn = dict(zip([str(x) for x in S["grad_names"]], S["grad_norms"]))
     for n, ref in gn.items():
         got = float(P[n].grad.norm())
@@ -182,5 +187,9 @@ def test_full_step(golden_dir, tag):
         if k.startswith("grad::"):
             ref = S[k]
             close(P[k[6:]].grad, ref, 2e-2 * np.abs(ref).max() + 1e-8, what=k)
+        if k.startswith("gsample::"):
+            ref = S[k]
+            stride = {"upsample3.weight": 7, "upsample4.weight": 13, "primary_caps.pose.weight": 997, "primary_caps.a.weight": 97}[k[9:]]
+            close(P[k[9:]].grad.reshape(-1)[::stride], ref, 2e-2 * np.abs(ref).max() + 1e-8, what=k)
         if k.startswith("buf::"):
             close(P[k[5:]], S[k], 1e-5, what=k)

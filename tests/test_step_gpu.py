@@ -15,24 +15,50 @@ from picons_amd import spec, step as pstep, synthetic
 pytestmark = pytest.mark.gpu
 
 
-def run_pair(akw, hw, bs, epoch, ncls=24, jhmdb=False, stepid=0, lr=1e-4):
+def run_pair(akw, hw, bs, epoch, ncls=24, jhmdb=False, stepid=0, lr=1e-4, conditioned=True):
     args = pstep.default_args(lr=lr, **akw)
-    eng = pstep.StepEngine(args, bs=bs, hw=hw, num_classes=ncls, jhmdb=jhmdb)
+    state = synthetic.init_state(47, ncls, conditioned=conditioned)
+    eng = pstep.StepEngine(args, bs=bs, hw=hw, num_classes=ncls, jhmdb=jhmdb, state=state)
     lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid, num_classes=ncls, hw=hw)
     ramp = pstep.exp_rampup(100)(epoch)
     eng.stage(lab, unl, perm, drops)
     eng.forward_backward(epoch, ramp)
     torch.cuda.synchronize()
-    P = ostep.as_torch_params(synthetic.init_state(47, ncls))
+    P = ostep.as_torch_params(state)
     oa = ostep.default_args(dataset="jhmdb" if jhmdb else "ucf101", **akw)
     ref = ostep.train_step(P, oa, lab, unl, epoch, ramp, perm, drops)
     ref["total"].backward()
     # fp64 run of the same oracle: the anchor for gradients (the fp32 reference differs from ITSELF by ~1 % on
     # gradients across thread counts, SURVEY finding 4, so fp32-vs-fp32 bars tighter than that are meaningless)
-    P64 = ostep.as_torch_params(synthetic.init_state(47, ncls), dtype=torch.float64)
+    P64 = ostep.as_torch_params(state, dtype=torch.float64)
     ref64 = ostep.train_step(P64, oa, lab, unl, epoch, ramp, perm, drops, dtype=torch.float64)
     ref64["total"].backward()
     return eng, ref, P, P64
+
+
+def check_gradients_fp64_anchored(eng, P, P64, tag):
+    """Every parameter gradient: relative L2 per tensor against the fp64 oracle, judged next to the fp32 oracle's own
+    distance from it (the fp32 reference differs from ITSELF by ~1 % on gradients, SURVEY finding 4)."""
+    bad, rows = [], []
+    num_g = num_c = den_all = 0.0
+    for name in eng.plan.pshape:
+        g = eng.grad(name).cpu().double(); r32 = P[name].grad.double(); r64 = P64[name].grad
+        den = r64.norm().item() + 1e-12
+        rel_g = (g - r64).norm().item() / den
+        rel_c = (r32 - r64).norm().item() / den
+        rows.append((name, rel_g, rel_c, den))
+        num_g += (g - r64).norm().item() ** 2; num_c += (r32 - r64).norm().item() ** 2; den_all += den ** 2
+        if rel_g > max(4 * rel_c, 5e-3) and (g - r64).abs().max().item() > 1e-7:
+            bad.append((name, rel_g, rel_c, den))
+    tot_g, tot_c = (num_g / den_all) ** 0.5, (num_c / den_all) ** 0.5
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/step_grad_err_%s.txt" % tag, "w") as f:
+        f.write("whole-gradient rel-L2 vs fp64 oracle: hip %.3e   fp32-oracle %.3e\n" % (tot_g, tot_c))
+        for r in sorted(rows, key=lambda r: -r[1])[:40]:
+            f.write("%-44s hip %.3e  cpu32 %.3e  |g| %.3e\n" % r)
+    assert not bad, bad[:10]
+    assert tot_g <= max(3 * tot_c, 2e-3), (tot_g, tot_c)
+    return rows
 
 
 CASES = [
@@ -55,27 +81,7 @@ def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
     assert (pred.cpu() - ref["predicted_action"]).abs().max().item() <= 1e-3
     assert (out.cpu() - ref["output"]).abs().max().item() <= 1e-3
     assert (flip.cpu() - ref["flip_op"]).abs().max().item() <= 1e-3
-    # every parameter gradient: relative L2 per tensor against the fp64 oracle, judged next to the fp32
-    # oracle's own distance from it
-    bad, rows = [], []
-    num_g = num_c = den_all = 0.0
-    for name in eng.plan.pshape:
-        g = eng.grad(name).cpu().double(); r32 = P[name].grad.double(); r64 = P64[name].grad
-        den = r64.norm().item() + 1e-12
-        rel_g = (g - r64).norm().item() / den
-        rel_c = (r32 - r64).norm().item() / den
-        rows.append((name, rel_g, rel_c, den))
-        num_g += (g - r64).norm().item() ** 2; num_c += (r32 - r64).norm().item() ** 2; den_all += den ** 2
-        if rel_g > max(4 * rel_c, 5e-3) and (g - r64).abs().max().item() > 1e-7:
-            bad.append((name, rel_g, rel_c, den))
-    tot_g, tot_c = (num_g / den_all) ** 0.5, (num_c / den_all) ** 0.5
-    os.makedirs("gpurun_out", exist_ok=True)
-    with open("gpurun_out/step_grad_err_%s.txt" % tag, "w") as f:
-        f.write("whole-gradient rel-L2 vs fp64 oracle: hip %.3e   fp32-oracle %.3e\n" % (tot_g, tot_c))
-        for r in sorted(rows, key=lambda r: -r[1])[:40]:
-            f.write("%-44s hip %.3e  cpu32 %.3e  |g| %.3e\n" % r)
-    assert not bad, bad[:10]
-    assert tot_g <= max(3 * tot_c, 2e-3), (tot_g, tot_c)
+    check_gradients_fp64_anchored(eng, P, P64, tag)
     # BN running statistics after the two passes
     for pre, _ci, co, _k, _s in spec.trunk_units()[:6] + spec.trunk_units()[-3:]:
         for nm in ("running_mean", "running_var"):
@@ -91,17 +97,25 @@ def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
         assert (eng.param(k).cpu() - P[k].detach()).abs().max().item() <= 5e-5, k   # half an Adam step (lr 1e-4): |g| ~ eps entries amplify the ~2 % gradient noise
 
 
-@pytest.mark.parametrize("tag", ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv"])
+GSAMPLE_STRIDE = {"upsample3.weight": 7, "upsample4.weight": 13, "primary_caps.pose.weight": 997, "primary_caps.a.weight": 97}
+
+
+@pytest.mark.parametrize("tag", ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8"])
 def test_step_vs_reference_golden_full_size(golden_dir, tag):
+    """HIP step against THE REFERENCE'S OWN outputs.  The two *_bs8 fixtures are BASELINE configs[1] (--bv --n_frames 5)
+    and configs[2] (--gv, thresholds None) at the batch size the metric is quoted on: 4 labeled + 4 unlabeled clips, i.e. the
+    B-dependent semantics (gv (B,B,...) broadcast utils/losses.py:74-76, joint Dice :44-57, Spread /b^2 :34-35, BN statistics
+    over 8 clips per pass pytorch_i3d.py:116-119)."""
     S = np.load(os.path.join(golden_dir, tag + ".npz"))
     ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
+    bs = int(S["bs"]) if "bs" in S.files else 2
     akw = dict(eval(str(S["args"])))
     jh = akw.pop("dataset", "ucf101") == "jhmdb"
     for k in ("wt_seg",):
         akw.pop(k, None)
     args = pstep.default_args(**akw)
-    eng = pstep.StepEngine(args, bs=2, hw=224, num_classes=ncls, jhmdb=jh)
-    lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=stepid, num_classes=ncls)
+    eng = pstep.StepEngine(args, bs=bs, hw=224, num_classes=ncls, jhmdb=jh)
+    lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid, num_classes=ncls)
     eng.stage(lab, unl, perm, drops)
     eng.forward_backward(epoch, float(S["ramp"]))
     got = eng.read_scalars()
@@ -125,13 +139,102 @@ def test_step_vs_reference_golden_full_size(golden_dir, tag):
         if k.startswith("grad::"):
             ref = S[k]
             assert np.abs(eng.grad(k[6:]).cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-8, k
+        if k.startswith("gsample::"):        # strided samples of the big 224-only / PrimaryCaps gradients
+            ref = S[k]
+            g = eng.grad(k[9:]).reshape(-1)[::GSAMPLE_STRIDE[k[9:]]].cpu().numpy()
+            assert np.abs(g - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-8, k
         if k.startswith("buf::") and not k.endswith("num_batches_tracked"):
             o = eng.plan.roff[k[5:]]
             assert np.abs(eng.R[o:o + S[k].size].cpu().numpy() - S[k]).max() <= 1e-5, k
 
 
+BS8 = [("bv5_bs8", dict(bv=True, n_frames=5, wt_cons=0.1), 4), ("gv_bs8", dict(gv=True, wt_cons=0.1), 5)]
+
+
+@pytest.mark.parametrize("tag,akw,stepid", BS8)
+def test_step_bs8_full_size_vs_oracle(tag, akw, stepid):
+    """BASELINE configs[1] / configs[2] exactly as bench.py runs them (bs = 8, 8x224x224, epoch 1) against the CPU oracle on
+    the same clips: loss scalars 1e-4, logits / masks 1e-3, and EVERY parameter gradient per tensor against an fp64 run of
+    the oracle -- this is where the 224-only kernels (the stem's wgrad4, conv112's row-segment wgrad, the 256-column
+    wgrad tiles, upsample3 / the merged tail, the spectral PrimaryCaps at M = 6400) meet a per-tensor bar."""
+    eng, ref, P, P64 = run_pair(akw, 224, 8, 1, stepid=stepid)
+    got = eng.read_scalars()
+    out, flip, pred = eng.outputs()
+    for k in ("total", "loc", "cls", "cons"):
+        assert abs(got[k] - float(ref[k])) <= 1e-4, (k, got[k], float(ref[k]))
+    assert (pred.cpu() - ref["predicted_action"]).abs().max().item() <= 1e-3
+    assert (out.cpu() - ref["output"]).abs().max().item() <= 1e-3
+    assert (flip.cpu() - ref["flip_op"]).abs().max().item() <= 1e-3
+    rows = {r[0]: r for r in check_gradients_fp64_anchored(eng, P, P64, tag)}
+    for name in ("conv1.Conv3d_1a_7x7.conv3d.weight", "conv112.weight", "upsample3.weight", "upsample4.weight",
+                 "smooth.weight", "primary_caps.pose.weight", "primary_caps.a.weight"):
+        assert name in rows
+    for pre, _ci, co, _k, _s in spec.trunk_units()[:4] + spec.trunk_units()[-3:]:       # BN statistics over 8 clips per pass
+        for nm in ("running_mean", "running_var"):
+            key = pre + ".bn." + nm
+            o = eng.plan.roff[key]
+            assert (eng.R[o:o + co].cpu() - P[key]).abs().max().item() <= 1e-5, key
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm((a - b).ravel()) / (np.linalg.norm(b.ravel()) + 1e-300))
+
+
+def test_step_reference_init_vs_reference_fp64(golden_dir):
+    """SURVEY 8(c) "reference-init case": the reference's OWN initialisation (PrimaryCaps weights N(0, 0.1), ConvCaps.weights
+    randn: capsules_ucf101.py:36,39,103 -- what real checkpoints look like), where EM routing amplifies fp32 rounding so
+    far that the fp32 reference disagrees with itself at the 1e-3 level (SURVEY finding 4).  The fixture holds an fp32 AND an
+    fp64 run of the reference itself; the HIP step is judged in rel-L2 against the fp64 run: <= 1e-3, and no further from
+    it than 2x the fp32 reference's own distance."""
+    S = np.load(os.path.join(golden_dir, "step_refinit_bv5.npz"))
+    assert int(S["conditioned"]) == 0
+    bs, stepid, epoch = int(S["bs"]), int(S["stepid"]), int(S["epoch"])
+    akw = dict(eval(str(S["args"])))
+    akw.pop("dataset", None)
+    eng = pstep.StepEngine(pstep.default_args(**akw), bs=bs, hw=224, state=synthetic.init_state(47, 24, conditioned=False))
+    lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid)
+    eng.stage(lab, unl, perm, drops)
+    eng.forward_backward(epoch, float(S["ramp"]))
+    got = eng.read_scalars()
+    out, _flip, pred = eng.outputs()
+    lines = []
+    for key, mine in (("predicted_action", pred.cpu().numpy()), ("output_sample", out[:, :, :, ::8, ::8].cpu().numpy()),
+                      ("output_frame_sum", out.sum(dim=(-1, -2)).cpu().numpy())):
+        r_hip, r_ref = _rel(mine, S["f64::" + key]), _rel(S[key], S["f64::" + key])
+        lines.append("%-20s rel-L2 vs fp64 reference: hip %.3e   fp32 reference %.3e" % (key, r_hip, r_ref))
+        assert r_hip <= 1e-3, (key, r_hip, r_ref)
+        assert r_hip <= max(2 * r_ref, 2e-5), (key, r_hip, r_ref)
+    for k in ("total", "loc", "cls", "cons"):
+        d_hip, d_ref = abs(got[k] - float(S["f64::" + k])), abs(float(S[k]) - float(S["f64::" + k]))
+        lines.append("%-20s |d| vs fp64 reference: hip %.3e   fp32 reference %.3e   value %.6f" % (k, d_hip, d_ref, float(S["f64::" + k])))
+        assert d_hip <= max(1e-3 * abs(float(S["f64::" + k])), 2 * d_ref, 1e-5), (k, d_hip, d_ref)
+    names = [str(x) for x in S["grad_names"]]
+    n32, n64 = dict(zip(names, S["grad_norms"])), dict(zip(names, S["f64::grad_norms"]))
+    worst = []
+    for n in names:
+        d_hip, d_ref = abs(float(eng.grad(n).norm()) - n64[n]), abs(n32[n] - n64[n])
+        worst.append((d_hip / max(n64[n], 1e-30), d_ref / max(n64[n], 1e-30), n))
+        assert d_hip <= max(2 * d_ref, 2e-2 * n64[n]) + 1e-9, (n, d_hip, d_ref, n64[n])
+    for k in S.files:
+        if k.startswith("f64::grad::") or k.startswith("f64::gsample::"):
+            name = k.split("::")[2]
+            g = eng.grad(name).reshape(-1)
+            if "gsample" in k:
+                g = g[::GSAMPLE_STRIDE[name]]
+            r_hip, r_ref = _rel(g.cpu().numpy(), S[k].reshape(-1)), _rel(S[k[5:]].reshape(-1), S[k].reshape(-1))
+            lines.append("%-44s grad rel-L2 vs fp64 reference: hip %.3e   fp32 reference %.3e" % (name, r_hip, r_ref))
+            assert r_hip <= max(2 * r_ref, 5e-3), (name, r_hip, r_ref)
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/step_refinit.txt", "w") as f:
+        f.write("\n".join(lines) + "\n")
+        for w in sorted(worst, reverse=True)[:12]:
+            f.write("|g| rel. error vs fp64: hip %.3e  fp32 reference %.3e  %s\n" % w)
+
+
 def test_smoke_entry():
-    pstep.smoke_check(hw=112)
+    import __graft_entry__ as entry
+    entry.smoke_check(hw=112)
 
 
 def test_segmented_backward_matches_unsegmented():

@@ -20,7 +20,7 @@ from picons_amd import evalmetrics, model as pmodel, ops, synthetic  # noqa: E40
 
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-    m = pmodel.CapsNet(pt_path=None).cuda()
+    m = pmodel.CapsNet(pt_path=None, init="conditioned").cuda()
     m.eval(); m.training = False
     vids = synthetic.make_eval_videos(n, seed=5)
     nclips = sum(evalmetrics.make_clips(v, b)[0].shape[0] for v, b, _l in vids)

@@ -172,7 +172,7 @@ def gen_masks():
 
 
 # ----------------------------------------------------------------------------- full steps
-def gen_steps():
+def gen_steps(only_tags=None):
     import importlib
     from models.capsules_ucf101 import CapsNet, ConvCaps
     import torch.nn as nn
@@ -180,22 +180,38 @@ def gen_steps():
     from oracle.step import default_args
     from oracle.losses import exp_rampup
 
+    # (tag, main module, classes, flags, epoch, synthetic step id, bs, conditioned init, also run the reference in fp64)
     cases = [
-        ("step_bv5", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 0),
-        ("step_gv_pseudo", "main_ucf101", 24, dict(gv=True, lower_thresh=0.2, upper_thresh=0.9, wt_cons=0.1), 12, 1),
-        ("step_bvgv3", "main_ucf101", 24, dict(bv=True, gv=True, n_frames=3, predict_maps=True), 3, 2),
-        ("step_jhmdb_bv", "main_jhmdb", 21, dict(bv=True, n_frames=5, wt_cons=0.1, dataset="jhmdb"), 1, 3),
+        ("step_bv5", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 0, 2, True, False),
+        ("step_gv_pseudo", "main_ucf101", 24, dict(gv=True, lower_thresh=0.2, upper_thresh=0.9, wt_cons=0.1), 12, 1, 2, True, False),
+        ("step_bvgv3", "main_ucf101", 24, dict(bv=True, gv=True, n_frames=3, predict_maps=True), 3, 2, 2, True, False),
+        ("step_jhmdb_bv", "main_jhmdb", 21, dict(bv=True, n_frames=5, wt_cons=0.1, dataset="jhmdb"), 1, 3, 2, True, False),
+        # BASELINE configs[1] / configs[2] at the batch size the metric is quoted on (4 labeled + 4 unlabeled)
+        ("step_bv5_bs8", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 4, 8, True, False),
+        ("step_gv_bs8", "main_ucf101", 24, dict(gv=True, wt_cons=0.1), 1, 5, 8, True, False),
+        # the reference's own initialisation (PrimaryCaps std 0.1, ConvCaps.weights randn: capsules_ucf101.py:36,39,103),
+        # fp32 and fp64 runs of the reference (SURVEY 8c "reference-init case")
+        ("step_refinit_bv5", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 6, 2, False, True),
     ]
-    for tag, mainmod, ncls, akw, epoch, stepid in cases:
-        t0 = time.time()
-        state = synthetic.init_state(seed=47, num_classes=ncls, conditioned=True)
+    if only_tags:
+        cases = [c for c in cases if c[0] in only_tags]
+    BIG = ["conv1.Conv3d_1a_7x7.conv3d.weight", "conv112.weight"]        # full gradients of two 224-only layers (bs = 8 cases)
+
+    def run_reference(case, double):
+        """One train step of the reference itself (main_*.train_model_interface + backward) -> dict of outputs."""
+        tag, mainmod, ncls, akw, epoch, stepid, bs, conditioned, _with64 = case
+        ref_import.install_shims(double=double)
+        state = synthetic.init_state(seed=47, num_classes=ncls, conditioned=conditioned)
         pt = ref_import.synthetic_charades(state)
         model = CapsNet(pt_path=pt)
-        if ncls != 24:       # the 21-class file is absent; assemble from the same classes
+        if ncls != 24:       # SURVEY 8c: the 21-class file is absent; assemble from the same classes
             model.conv_caps = ConvCaps(32, ncls, (1, 1), 4, stride=(1, 1), iters=3)
             model.upsample1 = nn.ConvTranspose2d(ncls * 16, 64, kernel_size=9, stride=1, padding=0)
         model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
-        lab, unl, perm, drops = synthetic.make_step_inputs(2, rank=0, step=stepid, num_classes=ncls)
+        if double:
+            model.double()
+            model.conv_caps.ln_2pi = model.conv_caps.ln_2pi.double()
+        lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid, num_classes=ncls)
         model.dropout3d = ref_import.ScriptedDropout(drops)
         model.train(True); model.training = True
         main = importlib.import_module(mainmod)
@@ -217,32 +233,53 @@ def gen_steps():
         output, pred_action, _seg, _act, total, loc, cls, cons = out
         total.backward()
         d = dict(num_classes=np.array(ncls), epoch=np.array(epoch), stepid=np.array(stepid), ramp=np.array(ramp),
+                 bs=np.array(bs), conditioned=np.array(int(conditioned)),
                  args=np.array(repr(sorted(vars(args).items()))),
                  predicted_action=pred_action, output_sample=output[:, :, :, ::8, ::8],
                  output_frame_sum=output.sum(dim=(-1, -2)), output_min=output.min(), output_max=output.max(),
                  total=total, loc=loc, cls=cls, cons=cons)
         gn = {}
-        for n, p in model.named_parameters():
+        params = dict(model.named_parameters())
+        for n, p in params.items():
             gn[n] = float(p.grad.norm()) if p.grad is not None else -1.0
         d["grad_names"] = np.array(list(gn.keys()))
         d["grad_norms"] = np.array(list(gn.values()))
         for n in ["conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "smooth.weight", "smooth.bias",
                   "upsample4.bias", "conv1.Conv3d_1a_7x7.bn.weight", "conv1.Conv3d_1a_7x7.bn.bias",
                   "conv1.Mixed_4f.b3b.bn.weight", "conv1.Mixed_3b.b1b.bn.bias", "primary_caps.a.bias",
-                  "conv1.Mixed_4f.b0.conv3d.weight", "conv28.bias"]:
-            d["grad::" + n] = dict(model.named_parameters())[n].grad
+                  "conv1.Mixed_4f.b0.conv3d.weight", "conv28.bias"] + (BIG if bs == 8 else []):
+            d["grad::" + n] = params[n].grad
+        if bs == 8 or not conditioned:
+            # strided samples of the big 224-only / PrimaryCaps gradients (full tensors are MBs)
+            d["gsample::upsample3.weight"] = params["upsample3.weight"].grad.reshape(-1)[::7]
+            d["gsample::upsample4.weight"] = params["upsample4.weight"].grad.reshape(-1)[::13]
+            d["gsample::primary_caps.pose.weight"] = params["primary_caps.pose.weight"].grad.reshape(-1)[::997]
+            d["gsample::primary_caps.a.weight"] = params["primary_caps.a.weight"].grad.reshape(-1)[::97]
         sd = model.state_dict()
         for n in ["conv1.Conv3d_1a_7x7.bn.running_mean", "conv1.Conv3d_1a_7x7.bn.running_var",
                   "conv1.Mixed_4f.b3b.bn.running_mean", "conv1.Mixed_4f.b3b.bn.running_var",
                   "conv1.Mixed_4f.b3b.bn.num_batches_tracked"]:
             d["buf::" + n] = sd[n]
+        return d
+
+    for case in cases:
+        t0 = time.time()
+        d = run_reference(case, False)
+        if case[8]:
+            d64 = run_reference(case, True)
+            ref_import.install_shims(double=False)
+            for k, v in d64.items():        # the fp64 run of the reference: the anchor the fp32 runs are judged against
+                if k.startswith(("grad::", "gsample::")) or k in ("predicted_action", "output_sample", "output_frame_sum",
+                                                                  "total", "loc", "cls", "cons", "grad_norms"):
+                    d["f64::" + k] = v
         d["seconds"] = np.array(time.time() - t0)
-        save(tag + ".npz", d)
+        save(case[0] + ".npz", d)
 
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--steps", default=None, help="comma-separated step fixture tags (default: all)")
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
     ref_import.install_shims()
@@ -252,4 +289,4 @@ if __name__ == "__main__":
     if a.only in (None, "masks"):
         gen_masks()
     if a.only in (None, "steps"):
-        gen_steps()
+        gen_steps(a.steps.split(",") if a.steps else None)
