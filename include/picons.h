@@ -191,6 +191,17 @@ int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* sp
 int pc_clip_from_u8_masks(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
                           const uint8_t* maskframes, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls,
                           pc_stream s);
+/* cv2.resize on uint8 images [n][H][W][C] -> [n][Ho][Wo][C] (C <= 4), the calls of the reference's loaders:
+ * datasets/jhmdb_dataloader.py:252 (frames, INTER_AREA 320x240 -> 256x256), :267,:281 (puppet masks, INTER_NEAREST),
+ * :192,:208 and ucf_dataloader.py:165,171 (224 crop -> frame size, INTER_LINEAR; the identity at 224).  OpenCV's 8-bit
+ * algorithm restated (csrc/inputpipe.hip has the rules).  pc_resize_tables is HOST arithmetic (no GPU needed): it writes the
+ * int32 coordinate / coefficient table for one (interpolation = cv2 flag 0 nearest | 1 linear | 3 area, sizes) into `tab` if
+ * `cap` words suffice and returns the word count; the caller uploads it once and passes the device copy to pc_resize_u8.
+ * binarize != 0: the result is (value > 0) of resizing a non-negative mask in float, i.e. 1 where a tap with a positive
+ * weight meets a positive sample (`cv2.resize(bbox_img, ...) > 0`, ucf_dataloader.py:170-172). */
+int64_t pc_resize_tables(int interpolation, int H, int W, int Ho, int Wo, int32_t* tab, int64_t cap);
+int pc_resize_u8(const uint8_t* src, int n, int H, int W, int C, int Ho, int Wo, const int32_t* dev_tab, int binarize,
+                 uint8_t* dst, pc_stream s);
 int pc_fill(float* p, int64_t n, float v, pc_stream s);
 int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
 

@@ -82,6 +82,8 @@ _SIGS = {
     "pc_map_accumulate": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "pc_clip_from_u8": (i32, [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "pc_clip_from_u8_masks": (i32, [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, C.POINTER(C.c_int32), vp, vp, vp, vp, vp]),
+    "pc_resize_tables": (i64, [i32, i32, i32, i32, i32, vp, i64]),
+    "pc_resize_u8": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),
     "pc_fill": (i32, [vp, i64, f32, vp]),
     "pc_axpy": (i32, [vp, vp, i64, f32, vp]),
     "pc_em_ws_floats": (i64, [i32, i32, i32]),

@@ -48,7 +48,9 @@ struct FwdState {
     float mu[3][MAXC][16];
     float s2[3][MAXC][16];
     float aout[3][MAXC];
+    float sd[3][MAXC][16];     // sum_i co (v - mu) as the rounded arithmetic leaves it (zero in exact arithmetic up to eps/(rs+eps))
     float D[4];                // stdv + eps per iteration
+    static constexpr bool KEEP_SD = true;
     static __device__ __forceinline__ int ti(int t) { return t; }
     __device__ __forceinline__ float& r_prev(int t, int i, int c) { return R[t - 1][i][c]; }
     __device__ __forceinline__ float& r_next(int t, int i, int c) { return R[t][i][c]; }
@@ -65,6 +67,7 @@ struct FwdLite {
     float s2[1][MAXC][16];
     float aout[1][MAXC];
     float D[4];
+    static constexpr bool KEEP_SD = false;
     static __device__ __forceinline__ int ti(int) { return 0; }
     __device__ __forceinline__ float& r_prev(int, int i, int c) { return R1[i][c]; }
     __device__ __forceinline__ float& r_next(int, int i, int c) { return R1[i][c]; }
@@ -171,15 +174,29 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
             }
         }
         xwave_sum<NW>(m, red, wv, lane);
+        float sdv[CJ];
+#pragma unroll
+        for (int j = 0; j < CJ; ++j) sdv[j] = 0.f;
         for (int i = i0; i < i1; ++i) {
             const f32x4 prow = *(const f32x4*)&st->P[i][p * 4];
 #pragma unroll
             for (int j = 0; j < CJ; ++j) {
                 const int c = cg + 4 * j;
-                if (c < C) { const float d = vote(WT, prow, i, c, q, C) - m[j]; sg[j] += st->rnorm(i, c) * irs[j] * d * d; }
+                if (c < C) {
+                    const float d = vote(WT, prow, i, c, q, C) - m[j], cw = st->rnorm(i, c) * irs[j];
+                    sg[j] += cw * d * d;
+                    if (ST::KEEP_SD) sdv[j] += cw * d;
+                }
             }
         }
         xwave_sum<NW>(sg, red, wv, lane);
+        if (ST::KEEP_SD) {
+            // The backward needs d sigma^2 / d mu = -2 sum_i co (v - mu) with the SAME rounded differences the sigma^2 above was
+            // built from: the rounding error of mu then cancels between this term and the direct 2 co (v - mu) term of each
+            // vote's gradient (as it does in autograd).  Its exact-arithmetic value -2 mu eps / (rs + eps) does not cancel it,
+            // and where one input capsule owns a class (v - mu -> 0, 1 / sigma^2 large) that left errors of 100 %.
+            xwave_sum<NW>(sdv, red, wv, lane);
+        }
         float cost[CJ]; double csum = 0.0;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) {
@@ -187,7 +204,7 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
             cost[j] = 0.f;
             if (c < C) {
                 sg[j] += EPS;
-                if (wv == 0) { st->mu[tt][c][h] = m[j]; st->s2[tt][c][h] = sg[j]; }
+                if (wv == 0) { st->mu[tt][c][h] = m[j]; st->s2[tt][c][h] = sg[j]; if (ST::KEEP_SD) ((FwdState*)st)->sd[tt][c][h] = sdv[j]; }
                 cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[tt][c]);
                 csum += (double)cost[j];
             }
@@ -371,8 +388,9 @@ __global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(con
                     const float G = sum16(beta_u[c * 16 + h] + 0.5f * logf(s2v));
                     const float ds = bs->ds2[t][c][h] + dcost * rsv * 0.5f / s2v;
                     ds_new[j] = ds;
-                    // d sigma^2 / d mu through sum_i co (v-mu)^2 :  -2 ds * mu * eps/(rs+eps)
-                    dmu_add[j] = bs->dmu[t][c][h] - 2.f * ds * st->mu[t][c][h] * (EPS / (rsv + EPS));
+                    // d sigma^2 / d mu through sum_i co (v-mu)^2 :  -2 ds * sum_i co (v - mu), the sum as the forward's rounded
+                    // arithmetic leaves it (see em_forward)
+                    dmu_add[j] = bs->dmu[t][c][h] - 2.f * ds * st->sd[t][c][h];
                     drs_new[j] = dcost * G;
                     if (wv == 0 && live) { dbu[c * 16 + h] += dcost * rsv; if (h == 0) dba[c] += LAMBDA * du[j]; }
                 }

@@ -7,7 +7,10 @@ foreground mask from the per-frame boxes.  The reference does all of it in numpy
 and copy); here the host only makes the integer decisions, in the reference's order of `np.random` draws (so a seed
 reproduces its choices), uploads the 8 selected uint8 frames (1.8 MB) and `pc_clip_from_u8` writes the fp32 NCDHW tensors
 the step consumes (csrc/inputpipe.hip).  `cv2.resize` of a 224x224 crop to 224x224 (:156,:162) is the identity and is not
-performed.  No CPU path for the pixel work: the op raises without the HIP library."""
+performed; for another frame size (`size=`) the crop is resized on the device with cv2's 8-bit INTER_LINEAR arithmetic and the
+box mask with the positivity rule of its float path (pc_resize_u8).  The JHMDB loader's own resizes -- every decoded frame
+to 256x256 with INTER_AREA, every puppet mask with INTER_NEAREST (jhmdb_dataloader.py:252,267,281) -- are `load_video_jhmdb`.
+No CPU path for the pixel work: the ops raise without the HIP library."""
 import numpy as np
 import torch
 
@@ -59,17 +62,27 @@ def _empty(device, size):
     return {'data': z, 'loc_msk': torch.zeros(1, DEPTH, size, size, device=device), 'action': torch.Tensor([0]), 'aug_data': z, 'label_vid': 0}
 
 
-def get_item(frames, annotations, train=True, device="cuda"):
+def _resized_sample(video8, mask8, size):
+    """The per-frame `cv2.resize(img, (size, size), INTER_LINEAR)` of __getitem__ (:165,:171) for a frame size other than the
+    crop: video8 uint8 [8,224,224,3], mask8 uint8 {0,1} [8,224,224] on the device -> data, aug [3,8,size,size], mask [8,size,size]."""
+    v = ops.resize_u8(video8, size, size, 1)
+    m = ops.resize_u8(mask8, size, size, 1, binarize=True)
+    data = (v.to(torch.float64) / 255.).to(torch.float32).permute(3, 0, 1, 2).contiguous()      # img / 255. in float64, then fp32
+    return data, torch.flip(data, [3]), m.to(torch.float32)
+
+
+def get_item(frames, annotations, train=True, device="cuda", size=CROP):
     """One sample as `UCF101DataLoader.__getitem__` returns it, with fp32 device tensors instead of float64 host tensors
     (the train loop casts to `torch.cuda.FloatTensor` first thing, main_ucf101.py:52-56).  frames: decoded uint8 [F,H,W,3]
-    (numpy, or a device tensor when the decoder already writes to HBM), None when the reader failed (:90-98)."""
+    (numpy, or a device tensor when the decoder already writes to HBM), None when the reader failed (:90-98).
+    size: the loader's frame size `[h, w]` (square); every caller of the reference uses 224, where the resize is the identity."""
     if frames is None:
-        return _empty(device, CROP)
+        return _empty(device, size)
     vlen, clip_h, clip_w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     per_frame, label, annot_frames, labeled_vid = frame_boxes(annotations, vlen)
     span = choose_window(annot_frames, vlen)
     if span is None:
-        return _empty(device, CROP)
+        return _empty(device, size)
     if train:
         h0 = np.random.randint(0, clip_h - CROP); w0 = np.random.randint(0, clip_w - CROP)       # :146-149
     else:
@@ -85,8 +98,25 @@ def get_item(frames, annotations, train=True, device="cuda"):
         video, ids = frames.to(device), span
     else:
         video, ids = torch.from_numpy(np.ascontiguousarray(frames[span])).to(device), np.arange(DEPTH)   # only the 8 frames travel
-    data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, torch.from_numpy(rects).to(device), CROP)
-    return {'data': data, 'loc_msk': mask.view(1, DEPTH, CROP, CROP), 'action': torch.Tensor([label]), 'aug_data': aug, 'label_vid': labeled_vid}
+    rects_d = torch.from_numpy(rects).to(device)
+    if size != CROP:
+        crop8 = video.contiguous()[torch.as_tensor(np.asarray(ids), device=video.device).long(), h0:h0 + CROP, w0:w0 + CROP].contiguous()
+        _d, _a, m224 = ops.clip_from_u8(video.contiguous(), ids, h0, w0, rects_d, CROP)          # the box mask of the crop
+        data, aug, mask = _resized_sample(crop8, m224.to(torch.uint8), size)
+    else:
+        data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, rects_d, CROP)
+    return {'data': data, 'loc_msk': mask.view(1, DEPTH, size, size), 'action': torch.Tensor([label]), 'aug_data': aug, 'label_vid': labeled_vid}
+
+
+def load_video_jhmdb(frames, part_mask, device="cuda"):
+    """The pixel work of the JHMDB loader's `load_video` (jhmdb_dataloader.py:236-283) on the device: every decoded frame
+    (uint8 [F,240,320,3] as cv2.VideoCapture yields them) resized to 256x256 with cv2.INTER_AREA (:252), every puppet mask
+    (`part_mask` uint8 [240,320,M] from the .mat file) with cv2.INTER_NEAREST (:267,:281).  -> (frames uint8 [F,256,256,3],
+    masks uint8 [M,256,256], annot_frames = arange(M)) -- what get_item_jhmdb consumes (device tensors stay on the device)."""
+    f = (frames if torch.is_tensor(frames) else torch.from_numpy(np.ascontiguousarray(frames))).to(device).contiguous()
+    pm = np.ascontiguousarray(np.transpose(np.asarray(part_mask), (2, 0, 1))) if not torch.is_tensor(part_mask) else part_mask.permute(2, 0, 1).contiguous()
+    m = (pm if torch.is_tensor(pm) else torch.from_numpy(pm)).to(device).to(torch.uint8).contiguous()
+    return ops.resize_u8(f, 256, 256, 3), ops.resize_u8(m, 256, 256, 0), np.arange(m.shape[0])
 
 
 def get_item_jhmdb(frames, masks, label, annot_frames, train=True, device="cuda"):
@@ -110,9 +140,17 @@ def get_item_jhmdb(frames, masks, label, annot_frames, train=True, device="cuda"
         h0 = int((clip_h - CROP) / 2); w0 = int((clip_w - CROP) / 2)
     af = set(int(a) for a in annot_frames)
     valid = [(int(f) in af or int(f) + 1 in af) if vskip == 2 else (int(f) in af) for f in span]               # :187-194
-    m = np.asarray(masks).reshape(vlen, clip_h, clip_w)[span]
-    m8 = np.ascontiguousarray(m if m.dtype == np.uint8 else (m > 0).astype(np.uint8))
-    video = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[span])).to(device)
-    data, aug, mask, mask_cls = ops.clip_from_u8_masks(video, np.arange(DEPTH), h0, w0, torch.from_numpy(m8).to(device), valid, CROP)
+    idx = torch.as_tensor(np.asarray(span)).long()
+    if torch.is_tensor(masks):          # load_video_jhmdb's device tensors: only the 8 frames are gathered, nothing travels
+        m8d = masks.reshape(vlen, clip_h, clip_w)[idx.to(masks.device)].to(device)
+        m8d = (m8d if m8d.dtype == torch.uint8 else (m8d > 0).to(torch.uint8)).contiguous()
+    else:
+        m = np.asarray(masks).reshape(vlen, clip_h, clip_w)[span]
+        m8d = torch.from_numpy(np.ascontiguousarray(m if m.dtype == np.uint8 else (m > 0).astype(np.uint8))).to(device)
+    if torch.is_tensor(frames):
+        video = frames[idx.to(frames.device)].to(device).contiguous()
+    else:
+        video = torch.from_numpy(np.ascontiguousarray(np.asarray(frames)[span])).to(device)
+    data, aug, mask, mask_cls = ops.clip_from_u8_masks(video, np.arange(DEPTH), h0, w0, m8d, valid, CROP)
     return {'data': data, 'loc_msk': mask.view(1, DEPTH, CROP, CROP), 'action': torch.Tensor([label]), 'mask_cls': mask_cls.view(1, DEPTH, CROP, CROP),
             'aug_data': aug}

@@ -346,3 +346,29 @@ def clip_from_u8_masks(video, span, h0, w0, maskframes, valid, S=224):
     sp = (C.c_int32 * 8)(*[int(v) for v in span]); va = (C.c_int32 * 8)(*[int(bool(v)) for v in valid])
     capi.call("pc_clip_from_u8_masks", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(maskframes), va, ptr(data), ptr(aug), ptr(mask), ptr(mask_cls), stream())
     return data, aug, mask, mask_cls
+
+
+_RESIZE_TABS = {}
+
+
+def resize_u8(src, Ho, Wo, interpolation, binarize=False):
+    """cv2.resize(src, (Wo, Ho), interpolation) on uint8 device images (pc_resize_u8): src [n,H,W,C] or [n,H,W] contiguous;
+    interpolation = cv2's flag value (0 nearest, 1 linear, 3 area).  The coordinate / coefficient table is computed on the
+    host by the library (pc_resize_tables) and cached on the device per (interpolation, sizes, device)."""
+    if src.dtype != torch.uint8 or not src.is_contiguous() or src.dim() not in (3, 4):
+        raise ValueError("resize_u8: contiguous uint8 [n,H,W,C] or [n,H,W]")
+    n, H, W = int(src.shape[0]), int(src.shape[1]), int(src.shape[2])
+    Cc = int(src.shape[3]) if src.dim() == 4 else 1
+    key = (int(interpolation), H, W, int(Ho), int(Wo), str(src.device))
+    tab = _RESIZE_TABS.get(key)
+    if tab is None:
+        need = capi.lib().pc_resize_tables(int(interpolation), H, W, int(Ho), int(Wo), None, 0)
+        if need < 0:
+            capi.check(int(need))
+        host = np.zeros(int(need), np.int32)
+        got = capi.lib().pc_resize_tables(int(interpolation), H, W, int(Ho), int(Wo), C.c_void_p(host.ctypes.data), int(need))
+        assert got == need
+        tab = _RESIZE_TABS[key] = torch.from_numpy(host).to(src.device)
+    dst = torch.empty((n, int(Ho), int(Wo)) + ((Cc,) if src.dim() == 4 else ()), dtype=torch.uint8, device=src.device)
+    capi.call("pc_resize_u8", ptr(src), n, H, W, Cc, int(Ho), int(Wo), ptr(tab), int(bool(binarize)), ptr(dst), stream())
+    return dst

@@ -144,6 +144,7 @@ def test_eval_forward_and_trunk_vs_oracle():
         o_out, o_pred, _ = ocaps.capsnet_forward(P, data, action, torch.zeros(2), 0, 0, False, None, None)
     assert (out.cpu() - o_out).abs().max().item() <= 1e-3 and (pred.cpu() - o_pred).abs().max().item() <= 1e-3
     tr = pmodel.InceptionI3d(157, in_channels=3, final_endpoint='Mixed_4f', hw=HW)
+    tr.load_state_dict({k[len("conv1."):]: v for k, v in synthetic.init_state(47, 24).items() if k.startswith("conv1.")})
     tr.eval()
     x, o56, o112 = tr(data.cuda())
     with torch.no_grad():

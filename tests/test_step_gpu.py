@@ -135,14 +135,18 @@ def test_step_vs_reference_golden_full_size(golden_dir, tag):
     bad = [(n, float(eng.grad(n).norm()), r) for n, r in gn.items()
            if abs(float(eng.grad(n).norm()) - r) > loose.get(n, 2e-2) * max(r, 1e-6) + 1e-7]
     assert not bad, bad[:10]
+    # element-wise against the fp32 reference's own gradients: 2 % of the tensor's max at bs = 2; 5 % at bs = 8, where both this
+    # path and the fp32 reference are 1.2-1.4 % (whole-gradient rel-L2) from an fp64 run (gpurun_out/step_grad_err_*_bs8.txt) --
+    # the tight per-tensor bar at that size is the fp64-anchored one of test_step_bs8_full_size_vs_oracle
+    gtol = 2e-2 if bs == 2 else 5e-2
     for k in S.files:
         if k.startswith("grad::"):
             ref = S[k]
-            assert np.abs(eng.grad(k[6:]).cpu().numpy() - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-8, k
+            assert np.abs(eng.grad(k[6:]).cpu().numpy() - ref).max() <= gtol * np.abs(ref).max() + 1e-8, k
         if k.startswith("gsample::"):        # strided samples of the big 224-only / PrimaryCaps gradients
             ref = S[k]
             g = eng.grad(k[9:]).reshape(-1)[::GSAMPLE_STRIDE[k[9:]]].cpu().numpy()
-            assert np.abs(g - ref).max() <= 2e-2 * np.abs(ref).max() + 1e-8, k
+            assert np.abs(g - ref).max() <= gtol * np.abs(ref).max() + 1e-8, k
         if k.startswith("buf::") and not k.endswith("num_batches_tracked"):
             o = eng.plan.roff[k[5:]]
             assert np.abs(eng.R[o:o + S[k].size].cpu().numpy() - S[k]).max() <= 1e-5, k
@@ -211,11 +215,12 @@ def test_step_reference_init_vs_reference_fp64(golden_dir):
         assert d_hip <= max(1e-3 * abs(float(S["f64::" + k])), 2 * d_ref, 1e-5), (k, d_hip, d_ref)
     names = [str(x) for x in S["grad_names"]]
     n32, n64 = dict(zip(names, S["grad_norms"])), dict(zip(names, S["f64::grad_norms"]))
-    worst = []
+    worst, fails = [], []
     for n in names:
         d_hip, d_ref = abs(float(eng.grad(n).norm()) - n64[n]), abs(n32[n] - n64[n])
         worst.append((d_hip / max(n64[n], 1e-30), d_ref / max(n64[n], 1e-30), n))
-        assert d_hip <= max(2 * d_ref, 2e-2 * n64[n]) + 1e-9, (n, d_hip, d_ref, n64[n])
+        if not d_hip <= max(2 * d_ref, 2e-2 * n64[n]) + 1e-9:
+            fails.append(("norm", n, d_hip, d_ref, n64[n]))
     for k in S.files:
         if k.startswith("f64::grad::") or k.startswith("f64::gsample::"):
             name = k.split("::")[2]
@@ -224,12 +229,14 @@ def test_step_reference_init_vs_reference_fp64(golden_dir):
                 g = g[::GSAMPLE_STRIDE[name]]
             r_hip, r_ref = _rel(g.cpu().numpy(), S[k].reshape(-1)), _rel(S[k[5:]].reshape(-1), S[k].reshape(-1))
             lines.append("%-44s grad rel-L2 vs fp64 reference: hip %.3e   fp32 reference %.3e" % (name, r_hip, r_ref))
-            assert r_hip <= max(2 * r_ref, 5e-3), (name, r_hip, r_ref)
+            if not r_hip <= max(2 * r_ref, 5e-3):
+                fails.append(("tensor", name, r_hip, r_ref))
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/step_refinit.txt", "w") as f:
         f.write("\n".join(lines) + "\n")
-        for w in sorted(worst, reverse=True)[:12]:
+        for w in sorted(worst, reverse=True)[:40]:
             f.write("|g| rel. error vs fp64: hip %.3e  fp32 reference %.3e  %s\n" % w)
+    assert not fails, fails[:10]
 
 
 def test_smoke_entry():
@@ -257,7 +264,7 @@ def test_segmented_backward_matches_unsegmented():
             self.buckets = buckets
             self.launched = []
 
-        def launch(self, i):
+        def launch(self, i, streams=()):
             self.launched.append(i)
 
         def wait(self):
