@@ -199,45 +199,61 @@ def validate(model, val_data_loader, epoch):
     return float(np.mean(total_loss))
 
 
+# (flag, type or None for a switch, default, what it does) -- names, types and defaults are the reference's CLI
+# (main_ucf101.py:285-315, main_jhmdb.py:283-310); the descriptions are this project's.
+_COMMON_FLAGS = [
+    ("bs", int, 16, "clips per step; half of them labeled, half unlabeled"),
+    ("epochs", int, 1, "passes over the unlabeled set; also the length of the consistency ramp-up"),
+    ("model_name", str, "i3d", "accepted for compatibility, not used"),
+    ("lr", float, 0.001, "Adam step size at the start (ReduceLROnPlateau lowers it)"),
+    ("pf", int, 50, "print running means every this many steps"),
+    ("exp_id", str, "debug", "sub-directory of train_log_wts/ for checkpoints"),
+    ("const_loss", str, "l2", "must be one of jsd / l2 / l1; the step always uses the L2 form, as the reference does"),
+    ("wt_cls", float, 1, "weight of the spread (classification) loss"),
+    ("wt_cons", float, 1, "weight of the flip-consistency loss"),
+    ("seed", int, 47, "seeds python / numpy / torch RNGs"),
+    ("thresh_epoch", int, 11, "from this epoch on unlabeled clips are masked with their predicted class instead of all classes"),
+    ("n_frames", int, 3, "temporal window (3 or 5 frames) of the variance attention mask"),
+    ("bv", None, False, "weight the consistency loss with the temporal-variance attention mask"),
+    ("predict_maps", None, False, "take the variance of sigmoid(logits) instead of the logits"),
+    ("cyclic", None, False, "accepted for compatibility, not used"),
+    ("gv", None, False, "weight the consistency loss with the second-order temporal-gradient mask"),
+    ("lower_thresh", float, None, "gradient mask: probabilities below this count as 0"),
+    ("upper_thresh", float, None, "gradient mask: probabilities above this count as 1"),
+]
+
+
+def build_parser(extra):
+    parser = argparse.ArgumentParser(description="semi-supervised action detection: flip consistency with variance / gradient attention")
+    for name, typ, default, text in _COMMON_FLAGS + extra:
+        if typ is None:
+            parser.add_argument("--" + name, action="store_true", help=text)
+        else:
+            parser.add_argument("--" + name, type=typ, default=default, help=text)
+    return parser
+
+
 def parse_args(argv=None):
-    """Flag names, types and defaults of main_ucf101.py:285-315."""
-    parser = argparse.ArgumentParser(description='loc var const')
-    parser.add_argument('--bs', type=int, default=16, help='mini-batch size')
-    parser.add_argument('--epochs', type=int, default=1, help='number of total epochs to run')
-    parser.add_argument('--model_name', type=str, default='i3d', help='model name')
-    parser.add_argument('--lr', type=float, default=0.001, help='learning rate')
-    parser.add_argument('--pf', type=int, default=50, help='print frequency every batch')
-    parser.add_argument('--pretrained', type=str, default="i3d", help='loading pretrained model')
-    parser.add_argument('--loc_loss', type=str, default='dice', help='dice or iou loss')
-    parser.add_argument('--exp_id', type=str, default='debug', help='experiment name')
-    parser.add_argument('--pkl_file_label', type=str, default='train_annots_20_labeled.pkl', help='label subset')
-    parser.add_argument('--pkl_file_unlabel', type=str, default='train_annots_80_unlabeled.pkl', help='unlabele subset')
-    parser.add_argument('--const_loss', type=str, default='l2', help='consistency loss type')
-    parser.add_argument('--wt_loc', type=float, default=1, help='segmentation loss weight')
-    parser.add_argument('--wt_cls', type=float, default=1, help='Classification loss weight')
-    parser.add_argument('--wt_cons', type=float, default=1, help='class consistency loss weight')
-    parser.add_argument('--seed', type=int, default=47, help='seed for initializing training.')
-    parser.add_argument('--thresh_epoch', type=int, default=11, help='thresh epoch to introduce pseudo labels')
-    parser.add_argument('--workers', type=int, default=8, help='num workers')
-    parser.add_argument('--n_frames', type=int, default=3, help='batch variance frames number.')
-    parser.add_argument('--bv', action='store_true', help='use batch variance')
-    parser.add_argument('--predict_maps', action='store_true', help='use sigmoid outputs')
-    parser.add_argument('--bv_wt', type=float, default=0.5, help='batch variance weight')
-    parser.add_argument('--cyclic', action='store_true', help='use batch variance')
-    parser.add_argument('--gv', action='store_true', help='use grad variance')
-    parser.add_argument('--lower_thresh', type=float, default=None, help='lower conf thresh')
-    parser.add_argument('--upper_thresh', type=float, default=None, help='upper conf thresh')
-    parser.add_argument('--gv_wt', type=float, default=0.5, help='grad variance weight')
-    return parser.parse_args(argv)
+    """The flag set of main_ucf101.py:285-315."""
+    return build_parser([
+        ("pretrained", str, "i3d", "accepted for compatibility, not used"),
+        ("loc_loss", str, "dice", "localisation loss next to BCE; only 'dice' exists"),
+        ("pkl_file_label", str, "train_annots_20_labeled.pkl", "annotation file of the labeled split"),
+        ("pkl_file_unlabel", str, "train_annots_80_unlabeled.pkl", "annotation file of the unlabeled split"),
+        ("wt_loc", float, 1, "weight of the localisation (BCE + Dice) loss"),
+        ("workers", int, 8, "DataLoader worker processes"),
+        ("bv_wt", float, 0.5, "share of the variance-mask term when --bv and --gv are both given"),
+        ("gv_wt", float, 0.5, "share of the gradient-mask term when --bv and --gv are both given"),
+    ]).parse_args(argv)
 
 
 def run(args):
     global model, criterion_cls, criterion_seg_1, criterion_seg_2
     if args.loc_loss != 'dice':
-        print("wrong parameter recheck. Exiting the code !!!!")      # 'iou' is a NameError in the reference (:396)
+        print("--loc_loss %r is not available (only 'dice'); stopping" % args.loc_loss)      # 'iou' is a NameError in the reference (:396)
         sys.exit(1)
     if args.const_loss not in ('jsd', 'l2', 'l1'):
-        print("no consistency criterion found. Exiting the code!!!")
+        print("--const_loss %r is not one of jsd / l2 / l1; stopping" % args.const_loss)
         sys.exit(1)
     rank, world, local = pdist.init_from_env()
     torch.cuda.set_device(local)
@@ -287,7 +303,7 @@ def run(args):
         # train at different learning rates from then on
         train_loss, val_loss = pdist.mean_over_ranks([train_loss, val_loss], device="cuda:%d" % local)
         if rank == 0 and val_loss < prev_best_val_loss:           # checkpoint policy of main_ucf101.py:439-455
-            print("Yay!!! Got the val loss down...")
+            print("validation loss improved: %.4f -> %.4f, checkpoint written" % (prev_best_val_loss, val_loss))
             p = os.path.join(model_save_dir, f'best_model_val_loss_{e}.pth')
             torch.save(model.state_dict(), p)
             prev_best_val_loss = val_loss
@@ -295,7 +311,7 @@ def run(args):
                 os.remove(prev_val_path)
             prev_val_path = p
         if rank == 0 and train_loss < prev_best_train_loss:
-            print("Yay!!! Got the train loss down...")
+            print("training loss improved: %.4f -> %.4f, checkpoint written" % (prev_best_train_loss, train_loss))
             p = os.path.join(model_save_dir, f'best_model_train_loss_{e}.pth')
             torch.save(model.state_dict(), p)
             prev_best_train_loss = train_loss

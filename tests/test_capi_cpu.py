@@ -63,3 +63,17 @@ def test_tools_and_dropin_scripts_compile():
     assert len(files) > 15
     for f in files:
         compile(open(f).read(), f, "exec")
+
+
+def test_host_side_of_the_abi_under_asan_ubsan():
+    """the host side of the C-ABI under AddressSanitizer + UBSan in the CPU container (GPU ASan needs XNACK, which
+    the pool does not offer).  `make asan` builds libpicons_asan.so (host code instrumented, device code as usual) and
+    tests/capi_host_driver.cpp, which walks every argument-checking path and the host arithmetic (workspace sizes, the
+    cv2.resize tables written into caller memory) without a GPU; a sanitizer report or a failed expectation fails the run."""
+    import subprocess
+    csrc = os.path.join(ROOT, "pi-consistency-activity-detection_amd", "csrc")
+    subprocess.run(["make", "-C", csrc, "-j8", "asan"], check=True, capture_output=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0:halt_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1")
+    r = subprocess.run([os.path.join(csrc, "asan", "capi_host_driver")], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "all checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

@@ -348,3 +348,34 @@ def test_stacked_1x1_units_match_separate_units(monkeypatch):
         if ".bn." in k:          # BN gradients: sums over the same rows, reduced in the same order
             assert torch.allclose(g0, g1, rtol=2e-4, atol=1e-6), k
     assert (num / den) ** 0.5 < 2e-4
+
+
+def test_step_is_deterministic_run_to_run():
+    """SURVEY 5 determinism check (catches races in the reductions): the same step twice from the same state.  No forward
+    kernel uses float atomics, so outputs, logits, loss scalars and BN running statistics must be BIT-identical, and so must
+    every gradient that is reduced without atomics (BatchNorm, biases of conv / transposed-conv layers, all of ConvCaps:
+    em_bwd's partials have one owner thread per element and a fixed-order final sum).  The split-K weight-gradient kernels and
+    the tail's bias / smooth sums add fp32 partials with atomics in arrival order: bounded at 1e-5 rel-L2 per tensor."""
+    args = pstep.default_args(bv=True, gv=True, n_frames=5, wt_cons=0.1)
+    eng = pstep.StepEngine(args, bs=2, hw=112)
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, step=2, hw=112)
+    runs = []
+    for _ in range(3):
+        eng.load_state(synthetic.init_state(47, 24))
+        eng.stage(lab, unl, perm, drops)
+        eng.forward_backward(1, 0.01)
+        torch.cuda.synchronize()
+        runs.append(([t.clone() for t in eng.outputs()], eng.aview(eng.plan.scalars, 20).clone(), eng.R.clone(), eng.G.clone()))
+    atomic = lambda n: (n.endswith("conv3d.weight") or n in ("upsample4.bias", "smooth.bias", "smooth.weight")
+                        or (n.endswith(".weight") and ".bn." not in n and not n.startswith("conv_caps")))
+    for other in runs[1:]:
+        for a, b in zip(runs[0][0], other[0]):
+            assert torch.equal(a, b)
+        assert torch.equal(runs[0][1], other[1]) and torch.equal(runs[0][2], other[2])
+        for name in eng.plan.pshape:
+            o = eng.plan.poff[name]; n = int(np.prod(eng.plan.pshape[name]))
+            g0, g1 = runs[0][3][o:o + n], other[3][o:o + n]
+            if atomic(name):
+                assert ((g0 - g1).norm() / (g0.norm() + 1e-30)).item() <= 1e-5, name
+            else:
+                assert torch.equal(g0, g1), name
