@@ -55,6 +55,14 @@ class Plan:
             raise ValueError("lanes must be 1..%d" % capi.MAX_LANES)
         self.lanes = lanes
         self.lane = 0
+        # With >= 3 lanes (PICONS_SKIP_LANE=0 turns it off) the last lane carries the decoder's skip convs conv56 / conv112 -- big,
+        # chip-filling GEMMs that depend on nothing but out56 / out112 -- beside the trunk: forward behind Conv3d_2c / Conv3d_1a,
+        # backward from the decoder's gradient until the trunk's backward first touches d(out56).  Their blocks fill the slots the
+        # under-filled 28x28 launches of the Inception modules leave idle.  The Inception branches then use lanes 0..lanes-2.
+        self.skip_lane = lanes - 1 if (os.environ.get("PICONS_SKIP_LANE", "1") != "0" and lanes >= 3) else 0
+        self.branch_lanes = lanes - 1 if self.skip_lane else lanes
+        self.skip_bwd = {}
+        self.final_lane = {}      # param name -> lane of the op that finalises its gradient
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
         self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
@@ -166,15 +174,18 @@ class Plan:
             lane = self.lane if lst in (None, self.cur) else 0
         self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l), lane))
 
-    def fork(self):
-        """Side lanes wait for everything enqueued on lane 0 so far (no-op for a single-lane plan)."""
-        if self.lanes > 1:
-            self.lists[self.cur].append((capi.OP_FORK, [(1 << self.lanes) - 2], [], [], [], 0))
+    def fork(self, mask=None):
+        """The side lanes in `mask` (default: the branch lanes) wait for everything enqueued on lane 0 so far (no-op for a
+        single-lane plan)."""
+        mask = (1 << self.branch_lanes) - 2 if mask is None else mask
+        if self.lanes > 1 and mask:
+            self.lists[self.cur].append((capi.OP_FORK, [mask], [], [], [], 0))
 
-    def join(self):
-        """Lane 0 waits for everything enqueued on the side lanes."""
-        if self.lanes > 1:
-            self.lists[self.cur].append((capi.OP_JOIN, [(1 << self.lanes) - 2], [], [], [], 0))
+    def join(self, mask=None):
+        """Lane 0 waits for everything enqueued so far on the side lanes in `mask` (default: the branch lanes)."""
+        mask = (1 << self.branch_lanes) - 2 if mask is None else mask
+        if self.lanes > 1 and mask:
+            self.lists[self.cur].append((capi.OP_JOIN, [mask], [], [], [], 0))
 
     def grad_for_write(self, x):
         """Gradient buffer of x's (whole) buffer for a consumer's backward: (TR, accumulate?)."""
@@ -271,6 +282,7 @@ class Plan:
     def mark_final(self, *names):
         for nm in names:
             self.final_at[nm] = len(self.lists["bwd"])
+            self.final_lane[nm] = self.lane
 
     # ------------------------------------------------------------------ layers
     def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None):
@@ -376,7 +388,7 @@ class Plan:
         each branch's last BN-apply writes its slice of `out`).  The branches share nothing but x, so a
         multi-lane plan puts each on its own stream, forward and backward."""
         c1, c2, c3 = oc[0], oc[0] + oc[2], oc[0] + oc[2] + oc[4]
-        L = lambda j: j % self.lanes
+        L = lambda j: j % self.branch_lanes
         one = (1, 1, 1)
         if self.fuse_1x1:
             # b1a, b2a and b0 (the 1x1x1 Unit3Ds reading x) as ONE conv + BN + ReLU.  Its output [b1a | b2a | b0] is
@@ -470,6 +482,24 @@ class Plan:
                 for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
                     self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
         self.tape.append(bwd)
+
+    def _skip_conv(self, name, x, cat):
+        """Forward of a decoder skip conv on the skip lane, right behind its input; its backward closure is kept aside and
+        re-enters the tape at the decoder position it always had (build_forward)."""
+        self.fork(1 << self.skip_lane)
+        self.lane = self.skip_lane
+        self.conv_layer(name, x, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat.slice(64, 64))
+        self.lane = 0
+        self.skip_bwd[name] = self.tape.pop()
+
+    def _on_skip_lane(self, fn):
+        def g():
+            self.fork(1 << self.skip_lane)        # behind the decoder gradient it consumes
+            self.lane = self.skip_lane
+            fn()
+            self.flush_unprep()
+            self.lane = 0
+        return g
 
     def convT_layer(self, name, x, cout, k, stride, pad, opad, act, out, cscale=None):
         """nn.ConvTranspose2d/3d + bias (+ReLU) (+Dropout3d scale) into `out` (channel slice)."""
@@ -569,6 +599,10 @@ class Plan:
             self.emit(capi.OP_TO_NDHWC, i=[0, self.n, 3, hw, 4, 0], l=[T * hw * hw], p=[src, off(x.ref, g * self.n * T * hw * hw * 4)])
         out56 = out112 = None
         first = True
+        s28e = hw // 8
+        if self.skip_lane:       # the decoder's concat buffers exist before the trunk so the skip convs can write into them early
+            cat56 = self.tensor(N, (2, 2 * s28e, 2 * s28e), 128, "cat56")
+            cat112 = self.tensor(N, (4, 4 * s28e, 4 * s28e), 128, "cat112")
         for ent in spec.TRUNK:
             name = "conv1." + ent[0]
             if ent[1] == "conv":
@@ -580,8 +614,16 @@ class Plan:
                 x = self.inception(name, x, ent[3])
             if ent[0] == "Conv3d_2c_3x3":
                 out56 = x
+                if self.skip_lane:
+                    self._skip_conv("conv56", out56, cat56)
             if ent[0] == "Conv3d_1a_7x7":
                 out112 = x
+                if self.skip_lane:
+                    self._skip_conv("conv112", out112, cat112)
+            if ent[0] == "MaxPool3d_3a_3x3" and self.skip_lane:
+                # first trunk op whose backward touches a gradient the skip lane writes (d out56; d out112 comes later still)
+                inner = self.tape.pop()
+                self.tape.append(lambda inner=inner: (self.join(1 << self.skip_lane), inner()))
         self.named["trunk_out"] = x
         s28 = x.thw[1]
         # Dropout3d #1 (capsules_ucf101.py:428)
@@ -705,12 +747,20 @@ class Plan:
         cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")
         self.convT_layer("upsample1", masked, 64, (1, KP, KP), (1, 1, 1), (0, 0, 0), (0, 0, 0), capi.ACT_RELU, cat28.slice(0, 64))
         self.conv_layer("conv28", xd, 64, (1, 3, 3), (0, 1, 1), capi.ACT_RELU, cat28.slice(64, 64))
-        cat56 = self.tensor(N, (2, 2 * s28, 2 * s28), 128, "cat56")
+        if not self.skip_lane:
+            cat56 = self.tensor(N, (2, 2 * s28, 2 * s28), 128, "cat56")
         self.convT_layer("upsample2", cat28, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), capi.ACT_RELU, cat56.slice(0, 64))
-        self.conv_layer("conv56", out56, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat56.slice(64, 64))
-        cat112 = self.tensor(N, (4, 4 * s28, 4 * s28), 128, "cat112")
+        if self.skip_lane:
+            self.tape.append(self._on_skip_lane(self.skip_bwd["conv56"]))
+            self.join(1 << self.skip_lane)        # conv56 / conv112 forward (enqueued behind the stem) before the decoder reads them
+        else:
+            self.conv_layer("conv56", out56, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat56.slice(64, 64))
+            cat112 = self.tensor(N, (4, 4 * s28, 4 * s28), 128, "cat112")
         self.convT_layer("upsample3", cat56, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), capi.ACT_RELU, cat112.slice(0, 64))
-        self.conv_layer("conv112", out112, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat112.slice(64, 64))
+        if self.skip_lane:
+            self.tape.append(self._on_skip_lane(self.skip_bwd["conv112"]))
+        else:
+            self.conv_layer("conv112", out112, 64, (3, 3, 3), (1, 1, 1), capi.ACT_RELU, cat112.slice(64, 64))
         # upsample4 -> Dropout3d -> smooth are linear: collapsed into ONE 128->27 transposed conv with per-sample combined
         # weights + the 27-tap shifted sum (csrc/tail.hip; capsules_ucf101.py:504-509).  u4 (205 MB/clip) never exists.
         othw = (8, 8 * s28, 8 * s28)
@@ -776,7 +826,7 @@ class Plan:
         # launches and run beside it on lane 1 (each class writes its own sub-lattice of cols)
         self.fork()
         for q, (z, d) in enumerate(tail6.conv_descs(N, cat112.thw, 128, cat112.ld)):
-            self.lane = 0 if z == 0 else 1 % self.lanes
+            self.lane = 0 if z == 0 else 1 % self.branch_lanes
             self.conv_op(d, cat112.ref, off(w5f, z * SP * 128), cols, alg=F_t6 if q == 0 else 0)
         self.lane = 0
         self.join()
@@ -794,10 +844,10 @@ class Plan:
             dx, acc = self.grad_for_write(cat112)
             self.fork()
             for z, wd in tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld):
-                self.lane = 0 if z == 0 else 1 % self.lanes
+                self.lane = 0 if z == 0 else 1 % self.branch_lanes
                 self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, z * 128 * SP)])
             for q, (z, dd) in enumerate(tail6.dgrad_descs(N, cat112.thw, 128, dx.ld, acc)):
-                self.lane = 0 if z == 0 else 1 % self.lanes
+                self.lane = 0 if z == 0 else 1 % self.branch_lanes
                 self.conv_op(dd, dcols, off(w5t, z * 128 * SP), dx.ref, alg=F_t6 if q == 0 else 0)
             self.lane = 0
             self.join()
@@ -854,26 +904,47 @@ class Plan:
         if missing:
             raise RuntimeError("no backward op finalises %s" % missing[:4])
         names = sorted(self.pshape, key=self.poff.get)       # flat-buffer order
-        # inside a FORK..JOIN region the side lanes may still be writing: a bucket is ready after the JOIN
-        snap, open_at = list(range(len(self.lists["bwd"]) + 1)), None
-        for idx, op in enumerate(self.lists["bwd"]):
-            if op[0] == capi.OP_FORK:
+        # a gradient finalised by an op on a side lane is ready once lane 0 has JOINed that lane; one finalised on lane 0 inside a
+        # branch region is snapped to the region's JOIN as well (its neighbours in the bucket live on the side lanes)
+        bwd = self.lists["bwd"]
+        next_join = {}                                   # lane -> index + 1 of the next JOIN covering it, per op index (filled backwards)
+        cover = [dict() for _ in range(len(bwd) + 1)]
+        cur = {}
+        for idx in range(len(bwd) - 1, -1, -1):
+            if bwd[idx][0] == capi.OP_JOIN:
+                for q in range(1, self.lanes):
+                    if (bwd[idx][1][0] >> q) & 1:
+                        cur[q] = idx + 1
+            cover[idx] = dict(cur)
+        branch_mask = (1 << self.branch_lanes) - 2
+        snap, open_at = list(range(len(bwd) + 1)), None
+        for idx, op in enumerate(bwd):
+            if op[0] == capi.OP_FORK and op[1][0] == branch_mask:
                 open_at = idx
-            elif op[0] == capi.OP_JOIN:
+            elif op[0] == capi.OP_JOIN and op[1][0] == branch_mask and open_at is not None:
                 for r in range(open_at + 1, idx + 1):
                     snap[r] = idx + 1
                 open_at = None
         if open_at is not None:
             raise RuntimeError("backward list ends with an open FORK")
+
+        def ready_of(nm):
+            k, lane = self.final_at[nm], self.final_lane.get(nm, 0)
+            if lane == 0:
+                return snap[k]
+            j = cover[min(k, len(bwd))].get(lane) if k < len(bwd) else None
+            if j is None:
+                raise RuntimeError("gradient of %s is finalised on lane %d and never joined" % (nm, lane))
+            return j
         buckets, cur_end, cur_ready, cur_size = [], self.nparams, 0, 0
         for nm in reversed(names):              # backward finalises parameters roughly in reverse flat order
-            cur_ready = max(cur_ready, snap[self.final_at[nm]])
+            cur_ready = max(cur_ready, ready_of(nm))
             cur_size = cur_end - self.poff[nm]
             if cur_size >= target_floats:
                 buckets.append((cur_ready, self.poff[nm], cur_end))
                 cur_end, cur_ready = self.poff[nm], 0
         if cur_end > 0:
-            buckets.append((max(cur_ready, max(self.final_at.values()) if cur_ready == 0 else cur_ready), 0, cur_end))
+            buckets.append((max(cur_ready, max(ready_of(nm) for nm in names) if cur_ready == 0 else cur_ready), 0, cur_end))
         buckets.sort(key=lambda b: b[0])
         return buckets
 

@@ -48,7 +48,8 @@ class StepEngine:
         self.hw = hw
         self.jhmdb = jhmdb
         if lanes is None:
-            lanes = int(os.environ.get("PICONS_LANES", "2"))   # measured best on MI355X
+            # measured best on MI355X: lane 1 for the second Inception branch, lane 2 for the decoder's skip convs
+            lanes = int(os.environ.get("PICONS_LANES", "3"))
         p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         p.build_forward()
@@ -154,7 +155,9 @@ class StepEngine:
             if timed_kind is None or len(arr) == 0:
                 ops.run_ops(arr, side=self.side)
             else:
-                ops.run_ops_timed(arr, timed_kind, side=self.side, defer=True)    # read after the step's own sync
+                # a timed step is replayed on ONE stream (FORK / JOIN are no-ops then): kernels that overlap on two lanes stretch
+                # each other's event-timed duration, and the roofline leg wants every kernel's own duration
+                ops.run_ops_timed(arr, timed_kind, side=None, defer=True)    # read after the step's own sync
         run(o["prep"])
         run(o["fwd"])
         run(o["loss"])

@@ -10,10 +10,15 @@ import pytest
 from picons_amd import capi, step as pstep
 from picons_amd.plan import Plan
 
-# p[] slots each op kind writes (the kinds that may appear inside a FORK..JOIN region)
-WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4, 5), capi.OP_BN_APPLY: (2,),
-          capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_TRANSPOSE: (1,),
-          capi.OP_FILL: (0,), capi.OP_BN_EVAL_STAT: (4,), capi.OP_WGRAD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3)}
+# p[] slots each op kind WRITES (every other non-null slot is read); kinds are those plan.py emits into fwd / loss / bwd
+WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4, 5), capi.OP_BN_APPLY: (2,), capi.OP_BN_EVAL_STAT: (4,),
+          capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_CHSCALE: (2,), capi.OP_ACT_BWD: (2, 3, 4),
+          capi.OP_TO_NDHWC: (1,), capi.OP_TRANSPOSE: (1,), capi.OP_FILL: (0,), capi.OP_EM_FWD: (4,), capi.OP_EM_BWD: (5, 6, 7, 8, 9),
+          capi.OP_CMASK_FWD: (3, 4, 5), capi.OP_CMASK_BWD: (3,), capi.OP_TAIL_COMBINE: (4, 5, 6), capi.OP_TAIL6_WEIGHTS: (1, 2),
+          capi.OP_TAIL6_GATHER: (3,), capi.OP_TAIL6_SCATTER: (1,), capi.OP_TAIL6_BIAS_SUMS: (1,), capi.OP_TAIL6_WGRAD_MAP: (1,),
+          capi.OP_TAIL_GRADS: (6, 7, 8, 9), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
+          capi.OP_WSPEC_MASTER_BWD: (2,), capi.OP_LOSS: (4, 5, 6, 7, 8, 9), capi.OP_SPREAD: (3, 4), capi.OP_ADAM: (0, 2, 3), capi.OP_COL2IM: (1,),
+          capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,)}
 
 
 def _plan(lanes, bs=1, hw=112):
@@ -25,58 +30,103 @@ def _plan(lanes, bs=1, hw=112):
 
 
 def _regions(lst):
-    """-> [(fork_idx, join_idx)], asserting balance and that lane tags only occur inside regions."""
+    """-> [(fork_idx, join_idx)] of a list whose regions do not nest (the prep list)."""
     out, open_at = [], None
     for idx, op in enumerate(lst):
-        kind, lane = op[0], op[5]
-        if kind == capi.OP_FORK:
+        if op[0] == capi.OP_FORK:
             assert open_at is None, "nested FORK at %d" % idx
             open_at = idx
-        elif kind == capi.OP_JOIN:
+        elif op[0] == capi.OP_JOIN:
             assert open_at is not None, "JOIN without FORK at %d" % idx
             out.append((open_at, idx)); open_at = None
         else:
-            assert lane == 0 or open_at is not None, "op %d on lane %d outside a FORK..JOIN region" % (idx, lane)
+            assert op[5] == 0 or open_at is not None, "op %d on lane %d outside a FORK..JOIN region" % (idx, op[5])
     assert open_at is None, "list ends with an open FORK"
     return out
 
 
-@pytest.mark.parametrize("lanes", [2, 4])
-def test_regions_balanced_and_private(lanes):
+def _accesses(p, op):
+    """-> [(buffer key, is_write)] of one op.  Keys are the start references the plan handed out (channel slices of one buffer
+    have different keys and never overlap); a conv's output key carries its sub-lattice (the merged tail's position classes tile
+    one buffer with disjoint sub-lattices)."""
+    kind, ints, ptrs = op[0], op[1], op[3]
+    out = []
+    if kind == capi.OP_TRANSPOSE_MULTI:
+        for job in p.multi_jobs[ptrs[0][1]]:
+            out += [(job[3][0], False), (job[3][1], True)]
+        return out
+    assert kind in WRITES, "op kind %d has no write map" % kind
+    for q, r in enumerate(ptrs):
+        if r is None:
+            continue
+        key = (r, tuple(ints[6:9]), tuple(ints[17:20])) if (kind == capi.OP_CONV and q == 4) else r
+        out.append((key, q in WRITES[kind]))
+    return out
+
+
+def _check_list(p, lst, lanes):
+    """Happens-before over one op list with vector clocks: ops of a lane are ordered; FORK(mask) orders everything lane 0 has
+    enqueued before the lanes in mask; JOIN(mask) orders everything those lanes have enqueued before lane 0's next op.  Two ops
+    that touch the same buffer, at least one writing it, must be ordered; every side lane must be joined before the list ends."""
+    clock = [[0] * lanes for _ in range(lanes)]
+    unjoined = set()
+    last = {}                                  # key -> [(stamp, lane, idx, is_write)]
+    nregions = 0
+    for idx, op in enumerate(lst):
+        kind, lane = op[0], op[5]
+        if kind == capi.OP_FORK:
+            nregions += 1
+            for q in range(1, lanes):
+                if (op[1][0] >> q) & 1:
+                    clock[q] = [max(a, b) for a, b in zip(clock[q], clock[0])]
+            continue
+        if kind == capi.OP_JOIN:
+            for q in range(1, lanes):
+                if (op[1][0] >> q) & 1:
+                    clock[0] = [max(a, b) for a, b in zip(clock[0], clock[q])]
+                    unjoined.discard(q)
+            continue
+        assert 0 <= lane < lanes
+        clock[lane][lane] += 1
+        stamp = list(clock[lane])
+        if lane:
+            unjoined.add(lane)
+        for key, wr in _accesses(p, op):
+            for st2, lane2, idx2, wr2 in last.get(key, ()):
+                if (wr or wr2) and lane2 != lane:
+                    assert st2[lane2] <= stamp[lane2], "ops %d (lane %d) and %d (lane %d) touch %s unordered" % (idx2, lane2, idx, lane, key)
+            last.setdefault(key, []).append((stamp, lane, idx, wr))
+    assert not unjoined, "lanes %s still have unjoined work at the end of the list" % sorted(unjoined)
+    return nregions
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
     p = _plan(lanes)
-    for name in ("prep", "fwd", "loss", "bwd", "adam"):
-        lst = p.lists[name]
-        regs = _regions(lst)
+    skip = 1 if p.skip_lane else 0
+    assert bool(p.skip_lane) == (lanes >= 3)
+    for name in ("fwd", "loss", "bwd", "adam"):
+        n = _check_list(p, p.lists[name], lanes)
         if name in ("fwd", "bwd"):
-            assert len(regs) == 8, "one region per Inception module (Mixed_3b..4f) + the merged tail's position classes"
-        elif name == "prep":
-            assert len(regs) == 1, "weight-layout prep: one region"
+            # one FORK per Inception module (Mixed_3b..4f) + the merged tail's position classes, + two for the skip convs
+            assert n == 8 + 2 * skip, (name, n)
         else:
-            assert not regs
-        for a, b in regs:
-            touched = collections.defaultdict(set)   # ref -> lanes that touch it
-            written = collections.defaultdict(set)   # ref -> lanes that write it
-            for op in lst[a + 1:b]:
-                kind, ptrs, lane = op[0], op[3], op[5]
-                assert kind in WRITES, "op kind %d inside a lane region has no write map" % kind
-                for q, r in enumerate(ptrs):
-                    if r is None:
-                        continue
-                    if kind == capi.OP_CONV and q == 4:
-                        # a conv writes the sub-lattice (ooff, extents) of its output tensor: the merged tail's position classes
-                        # tile one buffer with disjoint sub-lattices on two lanes
-                        i = op[1]
-                        r = (r, tuple(i[6:9]), tuple(i[17:20]))
-                    touched[r].add(lane)
-                    if q in WRITES[kind]:
-                        written[r].add(lane)
-            for r, wl in written.items():
-                assert len(touched[r]) == 1, "buffer %s written on lane(s) %s but touched on %s" % (r, wl, touched[r])
+            assert n == 0
+    if skip:
+        on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
+        assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4 and sum(1 for op in on_skip if op[0] == capi.OP_WGRAD) == 2
+
+
+def test_skip_lane_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("PICONS_SKIP_LANE", "0")
+    p = _plan(3)
+    assert not p.skip_lane and p.branch_lanes == 3
+    assert all(op[5] < 3 for lst in p.lists.values() for op in lst)
+    assert _check_list(p, p.lists["bwd"], 3) == 8
 
 
 def test_same_ops_as_single_lane_plan():
     p1, p4 = _plan(1), _plan(4)
-    assert p1.arena_bytes == p4.arena_bytes
     for name in ("prep", "fwd", "loss", "bwd", "adam"):
         strip = lambda lst: collections.Counter((op[0], tuple(op[1]), tuple(op[2]), tuple(op[4])) for op in lst
                                                 if op[0] not in (capi.OP_FORK, capi.OP_JOIN))
@@ -84,16 +134,45 @@ def test_same_ops_as_single_lane_plan():
     assert all(op[5] == 0 for lst in p1.lists.values() for op in lst)
 
 
-def test_buckets_ready_only_at_joined_points():
-    p = _plan(4)
-    regs = _regions(p.lists["bwd"])
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_buckets_ready_only_at_joined_points(lanes):
+    """A bucket may be all-reduced once every gradient in it is final AND ordered before lane 0's position `ready` in the
+    backward list: replay the list up to `ready` with vector clocks and check the finalising op of every parameter of the
+    bucket happens-before lane 0's clock there."""
+    p = _plan(lanes)
+    bwd = p.lists["bwd"]
     b = p.grad_buckets(500_000)
     assert len(b) > 8
-    for ready, _a, _e in b:
-        assert not any(f < ready <= j for f, j in regs), "bucket ready inside an open region (%d)" % ready
     spans = sorted((a, e) for _r, a, e in b)
     assert spans[0][0] == 0 and spans[-1][1] == p.nparams
     assert all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    # clocks after every prefix of the list, and the stamp of every op
+    clock = [[0] * lanes for _ in range(lanes)]
+    stamp_of, lane0_after = {}, []
+    for idx, op in enumerate(bwd):
+        kind, lane = op[0], op[5]
+        if kind == capi.OP_FORK:
+            for q in range(1, lanes):
+                if (op[1][0] >> q) & 1:
+                    clock[q] = [max(x, y) for x, y in zip(clock[q], clock[0])]
+        elif kind == capi.OP_JOIN:
+            for q in range(1, lanes):
+                if (op[1][0] >> q) & 1:
+                    clock[0] = [max(x, y) for x, y in zip(clock[0], clock[q])]
+        else:
+            clock[lane][lane] += 1
+            stamp_of[idx] = (lane, clock[lane][lane])
+        lane0_after.append(list(clock[0]))
+    for ready, a, e in b:
+        assert 0 < ready <= len(bwd)
+        seen = lane0_after[ready - 1]
+        for nm, off in p.poff.items():
+            if a <= off < e:
+                k = p.final_at[nm]                       # ops [0, k) finalise it; the last of them on its lane is the one that counts
+                last = max((i for i in range(k) if i in stamp_of and stamp_of[i][0] == p.final_lane.get(nm, 0)), default=None)
+                assert last is not None and last < ready, nm
+                lane, t = stamp_of[last]
+                assert t <= seen[lane], "bucket [%d, %d) ready at %d but %s (lane %d) is not ordered before it" % (a, e, ready, nm, lane)
 
 
 def test_prep_list_is_spread_over_lanes_at_resolve():
