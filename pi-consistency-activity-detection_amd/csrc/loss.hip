@@ -4,6 +4,8 @@
 // utils/helpers.py:8-67 (bv mask), :70-95 (gv mask), utils/losses.py:44-57,74-76.
 // Thread = one (clip, h, w) column of the 8 frames; block partials -> tiny finalize kernels.
 #include "common.h"
+#include <stdlib.h>
+#include <utility>
 
 namespace {
 
@@ -24,35 +26,45 @@ struct LossK {
     int nbx, nbx2;
 };
 
-__device__ __forceinline__ float np_var(const float* x, const int* idx, int n) {
-    float s = x[idx[0]];
-    for (int k = 1; k < n; ++k) s += x[idx[k]];
-    const float mean = s / (float)n;
-    float d = x[idx[0]] - mean, acc = d * d;
-    for (int k = 1; k < n; ++k) { d = x[idx[k]] - mean; acc += d * d; }
-    return acc / (float)n;
+// np.var of the N = 2*HALF+1 cyclic neighbours of element T of a 14-frame sequence, in numpy's float32 order (sequential sum,
+// mean, sequential sum of squared deviations).  Every index is a compile-time constant: the sequence stays in registers.
+template <int HALF, int T>
+__device__ __forceinline__ float np_var14(const float (&x)[14]) {
+    constexpr int N = 2 * HALF + 1;
+    float s = x[(T - HALF + 14) % 14];
+#pragma unroll
+    for (int k = 1; k < N; ++k) s += x[(T + k - HALF + 14) % 14];
+    const float mean = s / (float)N;
+    float d = x[(T - HALF + 14) % 14] - mean, acc = d * d;
+#pragma unroll
+    for (int k = 1; k < N; ++k) { d = x[(T + k - HALF + 14) % 14] - mean; acc += d * d; }
+    return acc / (float)N;
+}
+template <int HALF, int... T>
+__device__ __forceinline__ void var14_all(const float (&x)[14], float (&V)[14], std::integer_sequence<int, T...>) {
+    ((V[T] = np_var14<HALF, T>(x)), ...);
 }
 
 // raw (un-normalised) folded cyclic variance of helpers.py:25-57 for both call sites of
 // main_ucf101.py:114-115.  o[8], fp[8] -> Mc[8] (clockwise), Ma[8] (anticlockwise, NOT yet time-flipped)
-__device__ __forceinline__ void var_raw(const float* o, const float* fp, int half, double* Mc, double* Ma) {
+template <int HALF>
+__device__ __forceinline__ void var_raw_t(const float* o, const float* fp, double* Mc, double* Ma) {
     float cyc[14], cya[14];
 #pragma unroll
     for (int t = 0; t < 8; ++t) { cyc[t] = o[t]; cya[t] = o[7 - t]; }
 #pragma unroll
     for (int m = 0; m < 6; ++m) { cyc[8 + m] = fp[6 - m]; cya[8 + m] = fp[1 + m]; }
     float Vc[14], Va[14];
-    const int n = 2 * half + 1;
-    for (int t = 0; t < 14; ++t) {
-        int idx[5];
-        for (int k = 0; k < n; ++k) idx[k] = (t + k - half + 14) % 14;
-        Vc[t] = np_var(cyc, idx, n);
-        Va[t] = np_var(cya, idx, n);
-    }
+    var14_all<HALF>(cyc, Vc, std::make_integer_sequence<int, 14>{});
+    var14_all<HALF>(cya, Va, std::make_integer_sequence<int, 14>{});
     Mc[0] = 2.0 * (double)Vc[0]; Mc[7] = 2.0 * (double)Vc[7];
     Ma[0] = 2.0 * (double)Va[0]; Ma[7] = 2.0 * (double)Va[7];
 #pragma unroll
     for (int k = 1; k < 7; ++k) { Mc[k] = (double)Vc[k] + (double)Vc[14 - k]; Ma[k] = (double)Va[k] + (double)Va[14 - k]; }
+}
+__device__ __forceinline__ void var_raw(const float* o, const float* fp, int half, double* Mc, double* Ma) {
+    if (half == 2) var_raw_t<2>(o, fp, Mc, Ma);       // --n_frames 5
+    else var_raw_t<1>(o, fp, Mc, Ma);                 // --n_frames 3
 }
 
 __device__ __forceinline__ void grad2_raw(const float* o, float lower, float upper, float* g) {
@@ -101,78 +113,146 @@ __device__ __forceinline__ void load_col(const LossK& p, int b, int hw, float* o
     }
 }
 
-// ---- pass 1: per-clip partial statistics
+// NC adjacent columns (w0 .. w0+NC-1 of one image row) per thread: NC = 4 moves 16 bytes per lane and load / store
+// instruction (W % 4 == 0 and 16-byte aligned tensors), NC = 1 is the general form.  The flipped operand's columns
+// W-1-w0 .. W-NC-w0 are one aligned vector too, read in reverse.
+template <int NC>
+__device__ __forceinline__ void load_cols(const LossK& p, int b, int hw0, float (&o)[NC][8], float (&fp)[NC][8], float (&sg)[NC][8], bool need_fp, bool need_seg) {
+    if (NC == 1) {
+        float fdummy[8];
+        load_col(p, b, hw0, o[0], need_fp ? fp[0] : fdummy, sg[0], need_seg);
+        return;
+    }
+    typedef float vecT __attribute__((ext_vector_type(NC)));
+    const int h = hw0 / p.W, w0 = hw0 - h * p.W;
+    const size_t base = (size_t)b * T8 * p.HW;
+    const int fl = h * p.W + (p.W - NC - w0);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const vecT v = *(const vecT*)(p.O + base + (size_t)t * p.HW + hw0);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) o[c][t] = v[c];
+        if (need_fp) {
+            const vecT f = *(const vecT*)(p.F + base + (size_t)t * p.HW + fl);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) fp[c][t] = f[NC - 1 - c];
+        }
+        if (need_seg) {
+            const vecT g = *(const vecT*)(p.seg + base + (size_t)t * p.HW + hw0);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) sg[c][t] = g[c];
+        }
+    }
+}
+
+template <int NC> struct LossGeom { static constexpr int BT = NC == 1 ? 256 : 128; };   // threads per block
+
+// ---- pass 1: per-clip partial statistics.  One wave-level reduction per quantity, ONE block barrier for all thirteen.
+template <int NC>
 __global__ __launch_bounds__(256) void loss_pass1(const LossK p) {
-    __shared__ double sh[4];
-    const int b = blockIdx.y, hw = blockIdx.x * 256 + threadIdx.x;
-    const bool act = hw < p.HW;
+    constexpr int BT = LossGeom<NC>::BT, NW = BT / 64;
+    __shared__ double sh[NW][Q_N];
+    const int b = blockIdx.y, hw0 = (blockIdx.x * BT + threadIdx.x) * NC;
+    const bool act = hw0 < p.HW;
     const bool lab = p.labeled[b] != 0;
     double q[Q_N];
     q[Q_MINC] = q[Q_MINA] = q[Q_MING] = 1e300; q[Q_MAXC] = q[Q_MAXA] = q[Q_MAXG] = -1e300;
     for (int k = Q_SSQ; k < Q_N; ++k) q[k] = 0.0;
     if (act) {
-        float o[8], fp[8], sg[8];
-        load_col(p, b, hw, o, fp, sg, lab);
-        float sq[8];
+        float oa[NC][8], fa[NC][8], sa[NC][8];
+        load_cols<NC>(p, b, hw0, oa, fa, sa, true, lab);
 #pragma unroll
-        for (int t = 0; t < 8; ++t) { const float d = fp[t] - o[t]; sq[t] = d * d; q[Q_SSQ] += (double)sq[t]; }
-        if (p.bv) {
-            float oo[8], ff[8];
+        for (int c = 0; c < NC; ++c) {
+            const float* o = oa[c]; const float* fp = fa[c]; const float* sg = sa[c];
+            float sq[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { oo[t] = p.predict_maps ? 1.0f / (1.0f + expf(-o[t])) : o[t]; ff[t] = p.predict_maps ? 1.0f / (1.0f + expf(-fp[t])) : fp[t]; }
-            double Mc[8], Ma[8];
-            var_raw(oo, ff, p.n_frames / 2, Mc, Ma);
+            for (int t = 0; t < 8; ++t) { const float d = fp[t] - o[t]; sq[t] = d * d; q[Q_SSQ] += (double)sq[t]; }
+            if (p.bv) {
+                float oo[8], ff[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                q[Q_MINC] = fmin(q[Q_MINC], Mc[t]); q[Q_MAXC] = fmax(q[Q_MAXC], Mc[t]);
-                q[Q_MINA] = fmin(q[Q_MINA], Ma[t]); q[Q_MAXA] = fmax(q[Q_MAXA], Ma[t]);
-                q[Q_AC] += (double)sq[t] * Mc[t];
-                q[Q_AA] += (double)sq[t] * Ma[7 - t];      // torch.flip(batch_variance_anticlck,[2]), main_ucf101.py:121
+                for (int t = 0; t < 8; ++t) { oo[t] = p.predict_maps ? 1.0f / (1.0f + expf(-o[t])) : o[t]; ff[t] = p.predict_maps ? 1.0f / (1.0f + expf(-fp[t])) : fp[t]; }
+                double Mc[8], Ma[8];
+                var_raw(oo, ff, p.n_frames / 2, Mc, Ma);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    q[Q_MINC] = fmin(q[Q_MINC], Mc[t]); q[Q_MAXC] = fmax(q[Q_MAXC], Mc[t]);
+                    q[Q_MINA] = fmin(q[Q_MINA], Ma[t]); q[Q_MAXA] = fmax(q[Q_MAXA], Ma[t]);
+                    q[Q_AC] += (double)sq[t] * Mc[t];
+                    q[Q_AA] += (double)sq[t] * Ma[7 - t];      // torch.flip(batch_variance_anticlck,[2]), main_ucf101.py:121
+                }
             }
-        }
-        if (p.gv) {
-            float g[8];
-            grad2_raw(o, p.lower, p.upper, g);
+            if (p.gv) {
+                float g[8];
+                grad2_raw(o, p.lower, p.upper, g);
 #pragma unroll
-            for (int t = 0; t < 8; ++t) { q[Q_MING] = fmin(q[Q_MING], (double)g[t]); q[Q_MAXG] = fmax(q[Q_MAXG], (double)g[t]); }
-        }
-        if (lab) {
+                for (int t = 0; t < 8; ++t) { q[Q_MING] = fmin(q[Q_MING], (double)g[t]); q[Q_MAXG] = fmax(q[Q_MAXG], (double)g[t]); }
+            }
+            if (lab) {
 #pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float x = o[t], y = sg[t];
-                const float s = 1.0f / (1.0f + expf(-x));
-                // BCEWithLogits: max(x,0) - x*y + log(1+exp(-|x|))
-                q[Q_BCE] += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
-                q[Q_INTER] += (double)(s * y); q[Q_SSIG] += (double)s; q[Q_SSEG] += (double)y;
+                for (int t = 0; t < 8; ++t) {
+                    const float x = o[t], y = sg[t];
+                    const float s = 1.0f / (1.0f + expf(-x));
+                    // BCEWithLogits: max(x,0) - x*y + log(1+exp(-|x|))
+                    q[Q_BCE] += (double)(fmaxf(x, 0.f) - x * y + log1pf(expf(-fabsf(x))));
+                    q[Q_INTER] += (double)(s * y); q[Q_SSIG] += (double)s; q[Q_SSEG] += (double)y;
+                }
             }
         }
     }
-    double* out = p.part + ((size_t)blockIdx.x * p.B + b) * Q_N;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
     for (int k = 0; k < Q_N; ++k) {
-        double r;
-        if (k == Q_MINC || k == Q_MINA || k == Q_MING) r = block_min(q[k], sh);
-        else if (k == Q_MAXC || k == Q_MAXA || k == Q_MAXG) r = -block_min(-q[k], sh);
-        else r = block_sum(q[k], sh);
-        if (threadIdx.x == 0) out[k] = r;
+        double v = q[k];
+        const bool is_min = k == Q_MINC || k == Q_MINA || k == Q_MING, is_max = k == Q_MAXC || k == Q_MAXA || k == Q_MAXG;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double u = __shfl_xor(v, o, 64);
+            v = is_min ? fmin(v, u) : (is_max ? fmax(v, u) : v + u);
+        }
+        if (lane == 0) sh[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < Q_N) {
+        const int k = threadIdx.x;
+        const bool is_min = k == Q_MINC || k == Q_MINA || k == Q_MING, is_max = k == Q_MAXC || k == Q_MAXA || k == Q_MAXG;
+        double v = sh[0][k];
+        for (int w = 1; w < NW; ++w) v = is_min ? fmin(v, sh[w][k]) : (is_max ? fmax(v, sh[w][k]) : v + sh[w][k]);
+        p.part[((size_t)blockIdx.x * p.B + b) * Q_N + k] = v;
     }
 }
 
-// ---- mid: reduce partials to per-clip stats and global sums (one block)
-__global__ __launch_bounds__(64) void loss_mid(const LossK p) {
-    const int b = threadIdx.x;
-    __shared__ double g_sh[64][8];
-    double ssq = 0, wc = 0, wa = 0, bce = 0, inter = 0, ssig = 0, sseg = 0, nl = 0;
-    if (b < p.B) {
-        double q[Q_N];
-        q[Q_MINC] = q[Q_MINA] = q[Q_MING] = 1e300; q[Q_MAXC] = q[Q_MAXA] = q[Q_MAXG] = -1e300;
-        for (int k = Q_SSQ; k < Q_N; ++k) q[k] = 0.0;
-        for (int x = 0; x < p.nbx; ++x) {
-            const double* in = p.part + ((size_t)x * p.B + b) * Q_N;
-            q[Q_MINC] = fmin(q[Q_MINC], in[Q_MINC]); q[Q_MAXC] = fmax(q[Q_MAXC], in[Q_MAXC]);
-            q[Q_MINA] = fmin(q[Q_MINA], in[Q_MINA]); q[Q_MAXA] = fmax(q[Q_MAXA], in[Q_MAXA]);
-            q[Q_MING] = fmin(q[Q_MING], in[Q_MING]); q[Q_MAXG] = fmax(q[Q_MAXG], in[Q_MAXG]);
-            for (int k = Q_SSQ; k < Q_N; ++k) q[k] += in[k];
+// ---- mid: reduce the partials of ONE clip per block to its statistics.  The partials come from other CUs (memory latency ~2 us
+// per dependent round trip), so every thread owns one quantity and a slice of the x blocks and issues its loads together.
+// clip[b][0..5]: min / 1/range of the two variance masks, min / range of the gradient mask; clip[b][8..15]: the clip's share of
+// the eight global sums (read back by loss_globals in pass 2 and the final kernel).
+constexpr int MID_SL = 16;           // x slices per quantity: 13 * 16 = 208 of the 256 threads
+__global__ __launch_bounds__(256) void loss_mid(const LossK p) {
+    __shared__ double qs[MID_SL][Q_N];
+    const int b = blockIdx.x;
+    const int k = threadIdx.x % Q_N, sl = threadIdx.x / Q_N;
+    const bool is_min = k == Q_MINC || k == Q_MINA || k == Q_MING, is_max = k == Q_MAXC || k == Q_MAXA || k == Q_MAXG;
+    if (sl < MID_SL) {
+        double v = is_min ? 1e300 : (is_max ? -1e300 : 0.0);
+        const double* src = p.part + (size_t)b * Q_N + k;
+        const size_t stride = (size_t)p.B * Q_N;
+        int x = sl;
+        for (; x + 3 * MID_SL < p.nbx; x += 4 * MID_SL) {
+            const double u0 = src[(size_t)x * stride], u1 = src[(size_t)(x + MID_SL) * stride], u2 = src[(size_t)(x + 2 * MID_SL) * stride],
+                         u3 = src[(size_t)(x + 3 * MID_SL) * stride];
+            v = is_min ? fmin(fmin(v, u0), fmin(u1, fmin(u2, u3))) : (is_max ? fmax(fmax(v, u0), fmax(u1, fmax(u2, u3))) : (((v + u0) + u1) + u2) + u3);
         }
+        for (; x < p.nbx; x += MID_SL) { const double u = src[(size_t)x * stride]; v = is_min ? fmin(v, u) : (is_max ? fmax(v, u) : v + u); }
+        qs[sl][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < Q_N) {
+        double v = qs[0][k];
+        for (int i = 1; i < MID_SL; ++i) v = is_min ? fmin(v, qs[i][k]) : (is_max ? fmax(v, qs[i][k]) : v + qs[i][k]);
+        qs[0][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double* q = qs[0];
         double* cs = p.clip + b * 16;
         // helpers.py:59-61: M -= min; M /= (max(M) - min(M) + 1e-7) on the shifted array (min = 0)
         const double rc = (q[Q_MAXC] - q[Q_MINC]) + 1e-7, ra = (q[Q_MAXA] - q[Q_MINA]) + 1e-7;
@@ -181,52 +261,71 @@ __global__ __launch_bounds__(64) void loss_mid(const LossK p) {
         const float mg = (float)q[Q_MING], xg = (float)q[Q_MAXG];
         const float rg = ((xg - mg) - 0.0f) + 1e-7f;
         cs[4] = (double)mg; cs[5] = (double)rg;
-        ssq = q[Q_SSQ];
-        if (p.bv) { wc = (q[Q_AC] - q[Q_MINC] * q[Q_SSQ]) / rc; wa = (q[Q_AA] - q[Q_MINA] * q[Q_SSQ]) / ra; }
-        if (p.labeled[b]) { bce = q[Q_BCE]; inter = q[Q_INTER]; ssig = q[Q_SSIG]; sseg = q[Q_SSEG]; nl = 1.0; }
-    }
-    g_sh[threadIdx.x][0] = ssq; g_sh[threadIdx.x][1] = wc; g_sh[threadIdx.x][2] = wa; g_sh[threadIdx.x][3] = bce;
-    g_sh[threadIdx.x][4] = inter; g_sh[threadIdx.x][5] = ssig; g_sh[threadIdx.x][6] = sseg; g_sh[threadIdx.x][7] = nl;
-    __syncthreads();
-    if (threadIdx.x < 8) {
-        double s = 0;
-        for (int i = 0; i < p.B; ++i) s += g_sh[i][threadIdx.x];
-        p.glob[threadIdx.x] = s;
+        const bool lab = p.labeled[b] != 0;
+        cs[8] = q[Q_SSQ];
+        cs[9] = p.bv ? (q[Q_AC] - q[Q_MINC] * q[Q_SSQ]) / rc : 0.0;
+        cs[10] = p.bv ? (q[Q_AA] - q[Q_MINA] * q[Q_SSQ]) / ra : 0.0;
+        cs[11] = lab ? q[Q_BCE] : 0.0; cs[12] = lab ? q[Q_INTER] : 0.0; cs[13] = lab ? q[Q_SSIG] : 0.0; cs[14] = lab ? q[Q_SSEG] : 0.0;
+        cs[15] = lab ? 1.0 : 0.0;
     }
 }
 
-// ---- pass 2: gradients (+ optional mask outputs, gv cross-sample sum)
+// the eight global sums (ssq, var-weighted clockwise / anticlockwise, bce, inter, ssig, sseg, labeled clips) from the clips' shares,
+// summed in clip order by every caller
+__device__ __forceinline__ double loss_global(const LossK& p, int which) {
+    double s = 0.0;
+    for (int i = 0; i < p.B; ++i) s += p.clip[i * 16 + 8 + which];
+    return s;
+}
+
+// ---- pass 2: gradients (+ optional mask outputs, gv cross-sample sum).  Thread = NC columns of ONE clip; under --gv the
+// cross-sample weight sum_j (g_j - min_j) / range_j of utils/losses.py:74-76's (B, B, ...) broadcast is rebuilt per thread from
+// the B clips' columns (they sit in L2 / Infinity Cache: 12.8 MB), in the same j order as a serial loop.
+template <int NC>
 __global__ __launch_bounds__(256) void loss_pass2(const LossK p) {
-    __shared__ double sh[4];
-    const int hw = blockIdx.x * 256 + threadIdx.x;
-    const bool act = hw < p.HW;
+    constexpr int BT = LossGeom<NC>::BT, NW = BT / 64;
+    __shared__ double sh[NW];
+    const int b = blockIdx.y, hw0 = (blockIdx.x * BT + threadIdx.x) * NC;
+    const bool act = hw0 < p.HW;
     const double NT = (double)T8 * p.HW;
     const double BN = (double)p.B * NT;
-    const double nl = p.glob[7];
-    const double inter = p.glob[4], ssig = p.glob[5], sseg = p.glob[6];
+    const double nl = loss_global(p, 7);
+    const double inter = loss_global(p, 4), ssig = loss_global(p, 5), sseg = loss_global(p, 6);
     const double den = ssig + sseg + 1.0;
     double gvacc = 0.0;
     if (act) {
-        const int h = hw / p.W, w = hw - h * p.W;
-        float gsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const bool lab = p.labeled[b] != 0;
+        float gsum[NC][8];
+#pragma unroll
+        for (int c = 0; c < NC; ++c)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) gsum[c][t] = 0.f;
         if (p.gv) {
             for (int j = 0; j < p.B; ++j) {
-                float o[8], fp[8], sg[8], g[8];
-                load_col(p, j, hw, o, fp, sg, false);
-                grad2_raw(o, p.lower, p.upper, g);
+                float oj[NC][8], fj[NC][8], sj[NC][8];
+                load_cols<NC>(p, j, hw0, oj, fj, sj, false, false);
                 const float mg = (float)p.clip[j * 16 + 4], rg = (float)p.clip[j * 16 + 5];
 #pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    const float gn = (g[t] - mg) / rg;
-                    gsum[t] += gn;
-                    if (p.mask_gv) p.mask_gv[((size_t)j * T8 + t) * p.HW + hw] = gn;
+                for (int c = 0; c < NC; ++c) {
+                    float g[8];
+                    grad2_raw(oj[c], p.lower, p.upper, g);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        const float gn = (g[t] - mg) / rg;
+                        gsum[c][t] += gn;
+                        if (p.mask_gv && j == b) p.mask_gv[((size_t)j * T8 + t) * p.HW + hw0 + c] = gn;
+                    }
                 }
             }
         }
-        for (int b = 0; b < p.B; ++b) {
-            const bool lab = p.labeled[b] != 0;
-            float o[8], fp[8], sg[8];
-            load_col(p, b, hw, o, fp, sg, lab);
+        float oa[NC][8], fa[NC][8], sa[NC][8];
+        load_cols<NC>(p, b, hw0, oa, fa, sa, true, lab);
+        float goa[NC][8], gca[NC][8];
+        const double* cs = p.clip + b * 16;
+        const size_t base = (size_t)b * T8 * p.HW;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const float* o = oa[c]; const float* fp = fa[c]; const float* sg = sa[c];
             double Mc[8], Ma[8];
             if (p.bv) {
                 float oo[8], ff[8];
@@ -234,8 +333,6 @@ __global__ __launch_bounds__(256) void loss_pass2(const LossK p) {
                 for (int t = 0; t < 8; ++t) { oo[t] = p.predict_maps ? 1.0f / (1.0f + expf(-o[t])) : o[t]; ff[t] = p.predict_maps ? 1.0f / (1.0f + expf(-fp[t])) : fp[t]; }
                 var_raw(oo, ff, p.n_frames / 2, Mc, Ma);
             }
-            const double* cs = p.clip + b * 16;
-            const size_t base = (size_t)b * T8 * p.HW;
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const float d = fp[t] - o[t];
@@ -244,11 +341,11 @@ __global__ __launch_bounds__(256) void loss_pass2(const LossK p) {
                     const float mc = (float)((Mc[t] - cs[0]) * cs[1]);
                     const float ma = (float)((Ma[7 - t] - cs[2]) * cs[3]);
                     wgt += (double)p.c_bv * ((double)mc + (double)ma) / BN;
-                    if (p.mask_bv) p.mask_bv[base + (size_t)t * p.HW + hw] = mc;
+                    if (p.mask_bv) p.mask_bv[base + (size_t)t * p.HW + hw0 + c] = mc;
                 }
                 if (p.gv) {
-                    wgt += (double)p.c_gv * (double)gsum[t] / (BN * p.B);
-                    gvacc += (double)gsum[t] * (double)(d * d);
+                    wgt += (double)p.c_gv * (double)gsum[c][t] / (BN * p.B);
+                    gvacc += (double)gsum[c][t] * (double)(d * d);
                 }
                 const float gc = (float)(2.0 * (double)d * wgt * (double)p.wt_cons);
                 float go = -gc;
@@ -259,26 +356,52 @@ __global__ __launch_bounds__(256) void loss_pass2(const LossK p) {
                     const double ddice = -(2.0 * (double)y * den - (2.0 * inter + 1.0)) / (den * den) * (double)(s * (1.f - s));
                     go += (float)((double)p.wt_loc * (dbce + ddice));
                 }
-                p.dO[base + (size_t)t * p.HW + hw] = go;
-                p.dF[base + (size_t)t * p.HW + h * p.W + (p.W - 1 - w)] = gc;
+                goa[c][t] = go; gca[c][t] = gc;
+            }
+        }
+        const int h = hw0 / p.W, w0 = hw0 - h * p.W;
+        if (NC == 1) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                p.dO[base + (size_t)t * p.HW + hw0] = goa[0][t];
+                p.dF[base + (size_t)t * p.HW + h * p.W + (p.W - 1 - w0)] = gca[0][t];
+            }
+        } else {
+            typedef float vecT __attribute__((ext_vector_type(NC)));
+            const int fl = h * p.W + (p.W - NC - w0);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                vecT vo, vf;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) { vo[c] = goa[c][t]; vf[NC - 1 - c] = gca[c][t]; }
+                *(vecT*)(p.dO + base + (size_t)t * p.HW + hw0) = vo;
+                *(vecT*)(p.dF + base + (size_t)t * p.HW + fl) = vf;
             }
         }
     }
-    const double r = block_sum(gvacc, sh);
-    if (threadIdx.x == 0) p.gvpart[blockIdx.x] = r;
+    gvacc = wave_sum_d(gvacc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = gvacc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r = 0.0;
+        for (int w = 0; w < NW; ++w) r += sh[w];
+        p.gvpart[(size_t)b * p.nbx + blockIdx.x] = r;
+    }
 }
 
-__global__ void loss_final(const LossK p) {
+__global__ __launch_bounds__(256) void loss_final(const LossK p) {
+    __shared__ double sh[4];
+    double gv = 0.0;
+    for (int i = threadIdx.x; i < p.nbx2; i += 256) gv += p.gvpart[i];
+    gv = block_sum(gv, sh);
     if (threadIdx.x != 0) return;
     const double NT = (double)T8 * p.HW, BN = (double)p.B * NT;
-    const double nl = p.glob[7];
-    double gv = 0.0;
-    for (int i = 0; i < p.nbx2; ++i) gv += p.gvpart[i];
-    const double l2 = p.glob[0] / BN;
-    const double lv = (p.glob[1] + p.glob[2]) / BN;
+    const double nl = loss_global(p, 7);
+    const double l2 = loss_global(p, 0) / BN;
+    const double lv = (loss_global(p, 1) + loss_global(p, 2)) / BN;
     const double lg = gv / (BN * p.B);
-    const double bce = nl > 0 ? p.glob[3] / (nl * NT) : 0.0;
-    const double dice = 1.0 - (2.0 * p.glob[4] + 1.0) / (p.glob[5] + p.glob[6] + 1.0);
+    const double bce = nl > 0 ? loss_global(p, 3) / (nl * NT) : 0.0;
+    const double dice = 1.0 - (2.0 * loss_global(p, 4) + 1.0) / (loss_global(p, 5) + loss_global(p, 6) + 1.0);
     const double cons = (double)p.c_l2 * l2 + (double)p.c_bv * lv + (double)p.c_gv * lg;
     p.scalars[0] = (float)(bce + dice); p.scalars[1] = (float)cons; p.scalars[2] = (float)bce; p.scalars[3] = (float)dice;
     p.scalars[4] = (float)l2; p.scalars[5] = (float)lv; p.scalars[6] = (float)lg; p.scalars[7] = (float)nl;
@@ -419,21 +542,21 @@ inline void fill_lossk(LossK& k, const pc_loss_desc* d) {
     k.B = d->B; k.H = d->H; k.W = d->W; k.HW = d->H * d->W;
     k.bv = d->bv; k.gv = d->gv; k.n_frames = d->n_frames; k.predict_maps = d->predict_maps;
     k.lower = d->lower_thresh; k.upper = d->upper_thresh;
-    k.nbx = cdiv(k.HW, 256); k.nbx2 = k.nbx;
+    k.nbx = cdiv(k.HW, 256); k.nbx2 = k.nbx * k.B;
 }
 inline void carve_ws(LossK& k, float* ws) {
     double* w = (double*)ws;
     k.part = w; w += (size_t)k.nbx * k.B * Q_N;
     k.clip = w; w += (size_t)k.B * 16;
     k.glob = w; w += 16;
-    k.gvpart = w;   // nbx + 32 doubles (the standalone mask entries borrow it as a zeroed labeled[] array)
+    k.gvpart = w;   // nbx * B + 32 doubles (the standalone mask entries borrow it as a zeroed labeled[] array)
 }
 
 }  // namespace
 
 extern "C" int64_t pc_loss_ws_floats(const pc_loss_desc* d) {
     const int64_t nbx = cdiv((int64_t)d->H * d->W, 256);
-    return 2 * (nbx * d->B * Q_N + d->B * 16 + 16 + nbx + 32) + 64;
+    return 2 * (nbx * d->B * Q_N + d->B * 16 + 16 + nbx * d->B + 32) + 64;
 }
 
 extern "C" int pc_consistency_loss(const pc_loss_desc* d, const float* output, const float* flip_op, const float* seg,
@@ -461,10 +584,26 @@ extern "C" int pc_consistency_loss(const pc_loss_desc* d, const float* output, c
     else if (d->gv) { k.c_l2 = 0; k.c_bv = 0; k.c_gv = 1; }
     else if (d->bv) { k.c_l2 = 1 - r; k.c_bv = r; k.c_gv = 0; }
     else { k.c_l2 = 1; k.c_bv = 0; k.c_gv = 0; }
-    hipLaunchKernelGGL(loss_pass1, dim3(k.nbx, k.B), dim3(256), 0, s, k);
-    hipLaunchKernelGGL(loss_mid, dim3(1), dim3(64), 0, s, k);
-    hipLaunchKernelGGL(loss_pass2, dim3(k.nbx2), dim3(256), 0, s, k);
-    hipLaunchKernelGGL(loss_final, dim3(1), dim3(64), 0, s, k);
+    // four columns per thread (16-byte loads / stores) when a row is a whole number of them and every tensor is 16-byte aligned
+    static const int nc_env = getenv("PICONS_LOSS_NC") ? atoi(getenv("PICONS_LOSS_NC")) : 1;      // columns per thread: 1 measured fastest (89 / 101 / 116 us for 1 / 2 / 4: the passes are bound by the variance arithmetic, not by bytes, and wider threads cost occupancy)
+    const int nc_env2 = nc_env;
+    const bool vec4 = nc_env >= 2 && d->W % 4 == 0 && (((uintptr_t)output | (uintptr_t)flip_op | (uintptr_t)seg | (uintptr_t)d_output | (uintptr_t)d_flip_op) & 15) == 0;
+    if (vec4 && nc_env2 == 2) {
+        k.nbx = cdiv(k.HW / 2, LossGeom<2>::BT); k.nbx2 = k.nbx * k.B;         // = the cdiv(HW, 256) the workspace is sized for
+        hipLaunchKernelGGL(loss_pass1<2>, dim3(k.nbx, k.B), dim3(LossGeom<2>::BT), 0, s, k);
+        hipLaunchKernelGGL(loss_mid, dim3(k.B), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(loss_pass2<2>, dim3(k.nbx, k.B), dim3(LossGeom<2>::BT), 0, s, k);
+    } else if (vec4) {
+        k.nbx = cdiv(k.HW / 4, LossGeom<4>::BT); k.nbx2 = k.nbx * k.B;         // <= the cdiv(HW, 256) the workspace is sized for
+        hipLaunchKernelGGL(loss_pass1<4>, dim3(k.nbx, k.B), dim3(LossGeom<4>::BT), 0, s, k);
+        hipLaunchKernelGGL(loss_mid, dim3(k.B), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(loss_pass2<4>, dim3(k.nbx, k.B), dim3(LossGeom<4>::BT), 0, s, k);
+    } else {
+        hipLaunchKernelGGL(loss_pass1<1>, dim3(k.nbx, k.B), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(loss_mid, dim3(k.B), dim3(256), 0, s, k);
+        hipLaunchKernelGGL(loss_pass2<1>, dim3(k.nbx, k.B), dim3(256), 0, s, k);
+    }
+    hipLaunchKernelGGL(loss_final, dim3(1), dim3(256), 0, s, k);
     PC_CHECK_LAUNCH("consistency_loss");
     return PC_OK;
 }
@@ -481,7 +620,7 @@ extern "C" int pc_var_mask(const float* pred, const float* flip_pred, int B, int
     // reuse loss_mid for the reduction: it reads labeled[] -> give it a zeroed region of ws (clip area is written after reads)
     k.labeled = (const int*)(k.gvpart);   // gvpart is unused here; zero it first
     (void)hipMemsetAsync((void*)k.gvpart, 0, sizeof(double) * (k.nbx + 32), s);
-    hipLaunchKernelGGL(loss_mid, dim3(1), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(loss_mid, dim3(k.B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(var_mask_write, dim3(k.nbx, B), dim3(256), 0, s, k, mask, 0);
     PC_CHECK_LAUNCH("var_mask");
     return PC_OK;
@@ -495,7 +634,7 @@ extern "C" int pc_grad_mask(const float* pred, int B, int T, int H, int W, float
     hipLaunchKernelGGL(grad_mask_stats, dim3(k.nbx, B), dim3(256), 0, s, k);
     k.labeled = (const int*)(k.gvpart);
     (void)hipMemsetAsync((void*)k.gvpart, 0, sizeof(double) * (k.nbx + 32), s);
-    hipLaunchKernelGGL(loss_mid, dim3(1), dim3(64), 0, s, k);
+    hipLaunchKernelGGL(loss_mid, dim3(k.B), dim3(256), 0, s, k);
     hipLaunchKernelGGL(grad_mask_write, dim3(k.nbx, B), dim3(256), 0, s, k, mask);
     PC_CHECK_LAUNCH("grad_mask");
     return PC_OK;

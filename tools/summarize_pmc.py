@@ -1,49 +1,101 @@
 #!/usr/bin/env python3
-"""Turn rocprofv3 --pmc counter CSVs into the per-launch HBM traffic figure bench.py reports.
+"""rocprofv3 evidence -> the per-kernel tables kept under profiles/ (HBM GB/s for the HBM-bound kernels, MFMA utilisation for the
+GEMM kernels) and the per-launch HBM traffic figure bench.py reports.
 
     export TMPDIR=/tmp
-    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -o f -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
-    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -o w -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-kernel-timing
-    python tools/summarize_pmc.py gpurun_out/pmc_fetch/f_counter_collection.csv gpurun_out/pmc_write/w_counter_collection.csv profiles/r01_traffic.json
+    B="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing"
+    rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_X -o X -- $B            # durations (own run)
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_f -o f -- $B      # separate passes:
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_w -o w -- $B      # TCC has 4 slots, FETCH_SIZE
+    rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES \\
+              SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d gpurun_out/pmc_sq -o sq -- $B
+    python tools/summarize_pmc.py --stats gpurun_out/prof_X/X_kernel_stats.csv --fetch gpurun_out/pmc_f/f_counter_collection.csv \\
+        --write gpurun_out/pmc_w/w_counter_collection.csv --sq gpurun_out/pmc_sq/sq_counter_collection.csv --steps 3 --tag r02
 
-(separate passes: TCC has 4 counter slots, FETCH_SIZE costs 3 and WRITE_SIZE 2.)  gfx950 corrections per
-/opt/skills/guides/MI355X_MICROARCH.md §HBM: FETCH_SIZE counts 128-B requests as 64 B for 16-B-per-lane streams,
-so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores.  Both counters are in KiB.
-"""
+(steps = launches of adam_kernel in the traced run = warm-up + timed steps.)  Writes profiles/<tag>_traffic.json (read by
+bench.py), profiles/<tag>_hbm_table.md and profiles/<tag>_pmc_sq_gemm.csv.
+
+gfx950 corrections per /opt/skills/guides/MI355X_MICROARCH.md (HBM): FETCH_SIZE tallies the 128-byte requests of 16-B-per-lane
+streams as 64 B, so the read side is doubled; WRITE_SIZE is exact for 16-B-per-lane stores and float atomics.  Both are in KiB.
+HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE; Infinity-Cache hits are counted, so this is fabric-side traffic, an upper bound on DRAM
+traffic.  MFMA utilisation = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs over SQ_BUSY_CYCLES / 32 shader engines (rocprofv3 sums a
+counter over its instances)."""
+import argparse
 import collections
 import csv
 import json
-import sys
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HBM_PEAK, HBM_ACHIEVABLE = 8.0e12, 6.3e12
 
 
-def load(path, counter):
-    per = collections.defaultdict(lambda: [0, 0.0])
+def clean(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
+
+
+def load_counter(path, counters):
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.defaultdict(set)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] != counter:
+        if r["Counter_Name"] not in counters:
             continue
-        name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].strip()
-        per[name][0] += 1
-        per[name][1] += float(r["Counter_Value"])
-    return per
+        k = clean(r["Kernel_Name"])
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k].add(r["Dispatch_Id"])
+    return per, {k: len(v) for k, v in cnt.items()}
 
 
 def main():
-    fetch = load(sys.argv[1], "FETCH_SIZE")
-    write = load(sys.argv[2], "WRITE_SIZE")
-    out = {"note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md; per launch, bench.py workload (bs=8)",
-           "kernels": {}}
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--sq")
+    ap.add_argument("--steps", type=int, required=True); ap.add_argument("--tag", default="r02")
+    a = ap.parse_args()
+    stats = {}
+    for r in csv.DictReader(open(a.stats)):
+        stats[clean(r["Name"])] = (int(r["Calls"]), float(r["AverageNs"]))
+    fetch, nf = load_counter(a.fetch, {"FETCH_SIZE"})
+    write, nw = load_counter(a.write, {"WRITE_SIZE"})
+    out = {"note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md; per launch, bench.py workload (bs=8); "
+                   "offline rocprofv3 --pmc passes of the committed code, not a measurement of a bench run", "kernels": {}}
     conv = [0, 0.0]
+    rows = []
     for k in sorted(set(fetch) | set(write)):
-        nl = max(fetch[k][0], write[k][0])
-        b = (2.0 * fetch[k][1] + write[k][1]) * 1024.0
-        out["kernels"][k] = {"launches": nl, "fetch_kib": fetch[k][1], "write_kib": write[k][1], "hbm_bytes_per_launch": b / max(nl, 1)}
+        nl = max(nf.get(k, 0), nw.get(k, 0))
+        b = (2.0 * fetch[k]["FETCH_SIZE"] + write[k]["WRITE_SIZE"]) * 1024.0
+        per_launch = b / max(nl, 1)
+        out["kernels"][k] = {"launches": nl, "fetch_kib": fetch[k]["FETCH_SIZE"], "write_kib": write[k]["WRITE_SIZE"], "hbm_bytes_per_launch": per_launch}
         if k.startswith("conv_gemm"):
-            conv[0] += nl
-            conv[1] += b
+            conv[0] += nl; conv[1] += b
+        if k in stats:
+            calls, avg_ns = stats[k]
+            rate = per_launch / (avg_ns * 1e-9)
+            rows.append((calls * avg_ns / a.steps / 1e6, k, calls / a.steps, avg_ns / 1e3, per_launch / 1e6, rate / 1e12))
     out["conv_gemm_hbm_bytes_per_launch"] = conv[1] / max(conv[0], 1)
     out["conv_gemm_launches"] = conv[0]
-    json.dump(out, open(sys.argv[3], "w"), indent=1)
+    json.dump(out, open(os.path.join(ROOT, "profiles", a.tag + "_traffic.json"), "w"), indent=1)
+    with open(os.path.join(ROOT, "profiles", a.tag + "_hbm_table.md"), "w") as f:
+        f.write("# Per-kernel HBM traffic and rate (%s; bs = 8 bench workload; durations from the --stats run, bytes from the PMC passes)\n\n" % a.tag)
+        f.write("HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction); fabric-side, Infinity-Cache hits included.  Peak 8 TB/s, achievable ~6.3 TB/s.\n\n")
+        f.write("| kernel | ms / step | launches / step | avg us | MB / launch | TB/s | of 6.3 TB/s |\n|---|---|---|---|---|---|---|\n")
+        for ms, k, n, us, mb, tbs in sorted(rows, reverse=True):
+            f.write("| `%s` | %.3f | %.1f | %.1f | %.1f | %.2f | %.2f |\n" % (k, ms, n, us, mb, tbs, tbs * 1e12 / HBM_ACHIEVABLE))
     print("conv_gemm: %d launches, %.1f MB HBM per launch" % (conv[0], out["conv_gemm_hbm_bytes_per_launch"] / 1e6))
+    if a.sq:
+        names = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
+                 "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
+        sq, nsq = load_counter(a.sq, set(names))
+        with open(os.path.join(ROOT, "profiles", a.tag + "_pmc_sq_gemm.csv"), "w") as f:
+            f.write("kernel,launches," + ",".join(names) + ",mfma_util,wait_any_frac,wait_inst_frac,active_inst_frac\n")
+            for k in sorted(sq, key=lambda k: -sq[k]["SQ_BUSY_CYCLES"]):
+                if not ("gemm" in k or "wgrad" in k or "em_" in k):
+                    continue
+                v = sq[k]
+                busy, wave = v["SQ_BUSY_CYCLES"] / 32.0, max(v["SQ_WAVE_CYCLES"], 1.0)
+                f.write("%s,%d,%s,%.3f,%.3f,%.3f,%.3f\n" % (k.replace(",", " "), nsq[k], ",".join("%d" % v[n] for n in names),
+                                                         v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / max(busy, 1.0), v["SQ_WAIT_ANY"] / wave,
+                                                         v["SQ_WAIT_INST_ANY"] / wave, v["SQ_ACTIVE_INST_ANY"] / wave))
+        print("SQ table written")
 
 
 if __name__ == "__main__":
