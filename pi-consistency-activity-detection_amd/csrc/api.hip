@@ -177,11 +177,13 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         if (op.kind == PC_OP_FORK || op.kind == PC_OP_JOIN) {
             if (nlanes == 1) continue;
             const bool fork = op.kind == PC_OP_FORK;
-            if (fork) (void)hipEventRecord(g_ev[0], (hipStream_t)lanes[0]);
-            for (int q = 1; q < nlanes; ++q) {
-                if (!((op.i[0] >> q) & 1)) continue;
+            // FORK: the lanes in mask i[0] wait for everything enqueued so far on lane i[1] (0 unless the plan says otherwise)
+            const int src = (fork && op.i[1] > 0 && op.i[1] < nlanes) ? op.i[1] : 0;
+            if (fork) (void)hipEventRecord(g_ev[src], (hipStream_t)lanes[src]);
+            for (int q = 0; q < nlanes; ++q) {
+                if (!((op.i[0] >> q) & 1) || (fork && q == src) || (!fork && q == 0)) continue;
                 if (fork) {
-                    (void)hipStreamWaitEvent((hipStream_t)lanes[q], g_ev[0], 0);
+                    (void)hipStreamWaitEvent((hipStream_t)lanes[q], g_ev[src], 0);
                 } else {
                     (void)hipEventRecord(g_ev[q], (hipStream_t)lanes[q]);
                     (void)hipStreamWaitEvent((hipStream_t)lanes[0], g_ev[q], 0);

@@ -26,12 +26,50 @@ constexpr float HALF_LN_2PI = 0.91893853320467274178f;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); \
     } while (0)
 
-__device__ __forceinline__ float sum16(float v) {   // over h (lane bits 0..3)
-    v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+// Cross-lane sums without the LDS crossbar: `__shfl_xor` compiles to ds_bpermute_b32 (an LDS round trip of ~100 cycles plus the
+// address arithmetic), and these kernels are chains of hundreds of dependent 16-lane reductions per position.  DPP row
+// operations (quad_perm, row_half_mirror, row_mirror, row_ror) are modifiers of the add itself; rows of 16 lanes are combined
+// with gfx950's v_permlane16_swap / v_permlane32_swap.
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;                 // quad_perm [1,0,3,2] / [2,3,0,1]
+constexpr int DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140;     // lane k <-> 7-k within 8 / 15-k within 16
+constexpr int DPP_ROR4 = 0x124, DPP_ROR8 = 0x128;              // rotate right within the row of 16
+__device__ __forceinline__ float add_xor1(float v) { return v + dpp_mov<DPP_XOR1>(v); }
+__device__ __forceinline__ float add_xor2(float v) { return v + dpp_mov<DPP_XOR2>(v); }
+__device__ __forceinline__ float xor16_sum(float v) {            // v[lane] + v[lane ^ 16]
+    // inline asm: with the builtin, hipcc 7.2 adds the first result to itself (v_add v, r0, r0) when both come from one value.
+    // vdst's odd rows swap with src's even rows; the two s_nop cover the VALU-write -> permlane-read hazard
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+__device__ __forceinline__ float xor32_sum(float v) {            // v[lane] + v[lane ^ 32]
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+template <bool ROW16> __device__ __forceinline__ double swap_sum_d(double v) {   // v[lane] + v[lane ^ 16] (or ^ 32), double
+    unsigned lo = (unsigned)__double_as_longlong(v), hi = (unsigned)((unsigned long long)__double_as_longlong(v) >> 32);
+    unsigned lo2 = lo, hi2 = hi;
+    if (ROW16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(lo), "+v"(lo2), "+v"(hi), "+v"(hi2));
+    else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(lo), "+v"(lo2), "+v"(hi), "+v"(hi2));
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo)) + __longlong_as_double((long long)(((unsigned long long)hi2 << 32) | lo2));
+}
+__device__ __forceinline__ double sum_cg_d(double v) { return swap_sum_d<false>(swap_sum_d<true>(v)); }   // over cg (lane bits 4,5)
+__device__ __forceinline__ float sum16(float v) {   // over h (lane bits 0..3); every lane of the row gets the sum
+    v = add_xor1(v); v = add_xor2(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);                // quads are uniform by now: the mirror partner holds the other quad's sum
+    v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
 __device__ __forceinline__ float sum_cg(float v) {  // over cg (lane bits 4,5)
-    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    return xor32_sum(xor16_sum(v));
+}
+__device__ __forceinline__ float sum_p(float v) {   // over lane bits 2,3 (the four lanes with the same low two bits of a row)
+    v += dpp_mov<DPP_ROR4>(v);
+    v += dpp_mov<DPP_ROR8>(v);
     return v;
 }
 
@@ -93,13 +131,15 @@ __device__ __forceinline__ float vote(const float* WT, const f32x4 prow, int i, 
 // segment reductions over W consecutive lanes (W = 2 or 8, segments aligned): used to spread the per-capsule scalar
 // reductions (sum over c for one i, sum over i for one c) over all threads instead of 24-32 serial lanes
 template <int W> __device__ __forceinline__ float seg_sum(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    static_assert(W == 2 || W == 8, "segment width");
+    v = add_xor1(v);
+    if (W == 8) { v = add_xor2(v); v += dpp_mov<DPP_HALF_MIRROR>(v); }
     return v;
 }
 template <int W> __device__ __forceinline__ float seg_max(float v) {
-#pragma unroll
-    for (int o = W / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    static_assert(W == 2 || W == 8, "segment width");
+    v = fmaxf(v, dpp_mov<DPP_XOR1>(v));
+    if (W == 8) { v = fmaxf(v, dpp_mov<DPP_XOR2>(v)); v = fmaxf(v, dpp_mov<DPP_HALF_MIRROR>(v)); }
     return v;
 }
 
@@ -213,13 +253,13 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
         // arithmetic; in the reference's fp32 it is rounding noise that moves D by a few percent (SURVEY finding 4).
         // Evaluate it in double so this path sits at the noise-free value instead of adding noise of its own.
         double cs_d = csum;
-        cs_d += __shfl_xor(cs_d, 16, 64); cs_d += __shfl_xor(cs_d, 32, 64);
+        cs_d = sum_cg_d(cs_d);
         const double mean_d = cs_d / C;
         const float mean = (float)mean_d;
         double ds_d = 0.0;
 #pragma unroll
         for (int j = 0; j < CJ; ++j) if (cg + 4 * j < C) ds_d += (double)cost[j] - mean_d;
-        ds_d += __shfl_xor(ds_d, 16, 64); ds_d += __shfl_xor(ds_d, 32, 64);
+        ds_d = sum_cg_d(ds_d);
         const float D = sqrtf((float)(ds_d * ds_d / C) + EPS) + EPS;   // sum-then-square, :144
         float ao[CJ];
 #pragma unroll
@@ -546,16 +586,14 @@ __global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(con
                     // dW[i][c][k][q] = sum_p P[p][k] * dv[p,q]  (reduce over p = lane bits 2,3)
                     f32x4 tk = dv * prow;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) { tk[k] += __shfl_xor(tk[k], 4, 64); tk[k] += __shfl_xor(tk[k], 8, 64); }
+                    for (int k = 0; k < 4; ++k) tk[k] = sum_p(tk[k]);
                     const float mine = p == 0 ? tk[0] : (p == 1 ? tk[1] : (p == 2 ? tk[2] : tk[3]));
                     if (live) atomicAdd(pp + ((i * C + c) * 4 + p) * 4 + q, mine);
                 }
                 // dP[p][k]: reduce over q (lane bits 0,1) and cg (bits 4,5)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    float s = dP[k];
-                    s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-                    dP[k] = s;
+                    dP[k] = sum_cg(add_xor2(add_xor1(dP[k])));
                 }
                 if (q == 0 && cg == 0 && live) *(f32x4*)(dxp + i * 16 + p * 4) = dP;
             }
@@ -567,18 +605,42 @@ __global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(con
 }
 
 // part [nblk][NB*MAXC*16 + MAXC*16 + 32] -> dW [NB][C][4][4], dbeta_u [C][16], dbeta_a [C]  (+=)
+// A block sums 32 consecutive elements: 8 slices of the partials per element (the 32 element-threads of a slice read 128
+// contiguous bytes), eight independent loads in flight per thread, slices combined through LDS in a fixed order (deterministic).
+constexpr int RED_E = 32, RED_S = 8;
 __global__ __launch_bounds__(256) void em_reduce_kernel(const float* __restrict__ part, int nblk, int C, float* dW, float* dbu, float* dba) {
+    __shared__ double sh[RED_S][RED_E];
     const int stride = NB * MAXC * 16 + MAXC * 16 + 32;
     const int nW = NB * C * 16, nU = C * 16;
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= nW + nU + C) return;
-    int src; float* dst;
-    if (e < nW) { src = e; dst = dW + e; }
-    else if (e < nW + nU) { src = NB * MAXC * 16 + (e - nW); dst = dbu + (e - nW); }
-    else { src = NB * MAXC * 16 + MAXC * 16 + (e - nW - nU); dst = dba + (e - nW - nU); }
+    const int el = threadIdx.x % RED_E, sl = threadIdx.x / RED_E;
+    const int e = blockIdx.x * RED_E + el;
+    const bool act = e < nW + nU + C;
+    int src = 0; float* dst = nullptr;
+    if (act) {
+        if (e < nW) { src = e; dst = dW + e; }
+        else if (e < nW + nU) { src = NB * MAXC * 16 + (e - nW); dst = dbu + (e - nW); }
+        else { src = NB * MAXC * 16 + MAXC * 16 + (e - nW - nU); dst = dba + (e - nW - nU); }
+    }
     double s = 0.0;
-    for (int b = 0; b < nblk; ++b) s += (double)part[(size_t)b * stride + src];
-    *dst += (float)s;
+    if (act) {
+        int b = sl;
+        for (; b + 7 * RED_S < nblk; b += 8 * RED_S) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = part[(size_t)(b + q * RED_S) * stride + src];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += (double)v[q];
+        }
+        for (; b < nblk; b += RED_S) s += (double)part[(size_t)b * stride + src];
+    }
+    sh[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && act) {
+        double t = sh[0][el];
+#pragma unroll
+        for (int q = 1; q < RED_S; ++q) t += sh[q][el];
+        *dst += (float)t;
+    }
 }
 
 // ------------------------------------------------------------------------------ class mask
@@ -739,7 +801,7 @@ extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* be
     const int nblk = em_bwd_blocks(npos);
     hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64 * BWD_WAVES * BWD_GROUPS), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
     PC_CHECK_LAUNCH("em_bwd");
-    hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, 256)), dim3(256), 0, s, ws, nblk * BWD_GROUPS, C, dW, dbeta_u, dbeta_a);
+    hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, RED_E)), dim3(256), 0, s, ws, nblk * BWD_GROUPS, C, dW, dbeta_u, dbeta_a);
     PC_CHECK_LAUNCH("em_reduce");
     return PC_OK;
 }

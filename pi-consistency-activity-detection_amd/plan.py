@@ -55,12 +55,19 @@ class Plan:
             raise ValueError("lanes must be 1..%d" % capi.MAX_LANES)
         self.lanes = lanes
         self.lane = 0
-        # With >= 3 lanes (PICONS_SKIP_LANE=0 turns it off) the last lane carries the decoder's skip convs conv56 / conv112 -- big,
-        # chip-filling GEMMs that depend on nothing but out56 / out112 -- beside the trunk: forward behind Conv3d_2c / Conv3d_1a,
-        # backward from the decoder's gradient until the trunk's backward first touches d(out56).  Their blocks fill the slots the
-        # under-filled 28x28 launches of the Inception modules leave idle.  The Inception branches then use lanes 0..lanes-2.
-        self.skip_lane = lanes - 1 if (os.environ.get("PICONS_SKIP_LANE", "1") != "0" and lanes >= 3) else 0
-        self.branch_lanes = lanes - 1 if self.skip_lane else lanes
+        # Lane roles (measured on MI355X): lanes 0 .. branch_lanes-1 carry the Inception branches; with >= 3 lanes one
+        # lane (PICONS_SKIP_LANE=0 turns it off) carries the decoder's skip convs conv56 / conv112 -- big, chip-filling GEMMs that
+        # depend on nothing but out56 / out112 -- beside the trunk: forward behind Conv3d_2c / Conv3d_1a, backward from the decoder's
+        # gradient until the trunk's backward first touches d(out56); and every weight-gradient launch with its gradient re-layout
+        # goes to a side lane too (PICONS_WGRAD_LANE=0 turns it off; a lane of its own with >= 4 lanes, else the skip lane):
+        # nothing in the backward waits for a weight gradient except the optimiser, so the dgrad / BatchNorm chain and the wgrad
+        # stream overlap, and their blocks fill the slots the under-filled 28x28 launches leave idle.
+        want_skip = os.environ.get("PICONS_SKIP_LANE", "1") != "0" and lanes >= 3
+        want_wg = os.environ.get("PICONS_WGRAD_LANE", "1") != "0" and lanes >= 3
+        own_wg = want_wg and want_skip and lanes >= 4 and os.environ.get("PICONS_WGRAD_SEPARATE", "1") != "0"
+        self.wg_lane = lanes - 1 if want_wg else 0
+        self.skip_lane = (lanes - 2 if own_wg else lanes - 1) if want_skip else 0
+        self.branch_lanes = lanes - len({ln for ln in (self.wg_lane, self.skip_lane) if ln})
         self.skip_bwd = {}
         self.final_lane = {}      # param name -> lane of the op that finalises its gradient
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
@@ -174,12 +181,13 @@ class Plan:
             lane = self.lane if lst in (None, self.cur) else 0
         self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l), lane))
 
-    def fork(self, mask=None):
-        """The side lanes in `mask` (default: the branch lanes) wait for everything enqueued on lane 0 so far (no-op for a
+    def fork(self, mask=None, src=0):
+        """The lanes in `mask` (default: the branch lanes) wait for everything enqueued so far on lane `src` (no-op for a
         single-lane plan)."""
         mask = (1 << self.branch_lanes) - 2 if mask is None else mask
+        mask &= ~(1 << src)
         if self.lanes > 1 and mask:
-            self.lists[self.cur].append((capi.OP_FORK, [mask], [], [], [], 0))
+            self.lists[self.cur].append((capi.OP_FORK, [mask, src], [], [], [], 0))
 
     def join(self, mask=None):
         """Lane 0 waits for everything enqueued so far on the side lanes in `mask` (default: the branch lanes)."""
@@ -260,24 +268,40 @@ class Plan:
     def flush_grad(self, w):
         """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
         wgrad's layer (flush_unprep, after every layer / Inception module of the backward) so a gradient bucket is final
-        (all-reduce can start) as early as possible."""
+        (all-reduce can start) as early as possible.  The re-layout runs on the lane its wgrad ran on."""
         self._pending_unprep = getattr(self, "_pending_unprep", [])
-        self._pending_unprep.extend(w["unprep"])
+        # (a wgrad on a branch lane is joined before the flush: its re-layout runs on whatever lane flushes)
+        lane = self.lane if (self.wg_lane and self.lane == self.wg_lane) else None
+        self._pending_unprep.extend((nm, op, lane) for nm, op in w["unprep"])
 
     def flush_unprep(self):
         """Emit the pending kernel-layout -> reference-layout gradient transposes (several weights of an Inception module
-        as ONE multi-job launch) and mark those parameters final."""
+        as ONE multi-job launch per lane) and mark those parameters final."""
         pend = getattr(self, "_pending_unprep", [])
         if not pend:
             return
-        if len(pend) == 1:
-            self.lists[self.cur].append(pend[0][1] + (self.lane,))
-        else:
-            self.multi_jobs = getattr(self, "multi_jobs", [])
-            self.multi_jobs.append([op for _nm, op in pend])
-            self.lists[self.cur].append((capi.OP_TRANSPOSE_MULTI, [len(pend)], [], [("JOBS", len(self.multi_jobs) - 1)], [], self.lane))
-        self.mark_final(*[nm for nm, _op in pend])
+        pend = [(nm, op, self.lane if ln is None else ln) for nm, op, ln in pend]
+        for lane in sorted({ln for _nm, _op, ln in pend}):
+            mine = [(nm, op) for nm, op, ln in pend if ln == lane]
+            if len(mine) == 1:
+                self.lists[self.cur].append(mine[0][1] + (lane,))
+            else:
+                self.multi_jobs = getattr(self, "multi_jobs", [])
+                self.multi_jobs.append([op for _nm, op in mine])
+                self.lists[self.cur].append((capi.OP_TRANSPOSE_MULTI, [len(mine)], [], [("JOBS", len(self.multi_jobs) - 1)], [], lane))
+            saved, self.lane = self.lane, lane
+            self.mark_final(*[nm for nm, _op in mine])
+            self.lane = saved
         self._pending_unprep = []
+
+    def on_wgrad_lane(self, fn):
+        """Run the emissions of fn (a weight-gradient launch and what hangs off it) on the wgrad lane, behind the current lane."""
+        if not self.wg_lane or self.lane == self.wg_lane:
+            return fn()
+        self.fork(1 << self.wg_lane, src=self.lane)
+        saved, self.lane = self.lane, self.wg_lane
+        fn()
+        self.lane = saved
 
     def mark_final(self, *names):
         for nm in names:
@@ -355,8 +379,7 @@ class Plan:
                           p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
                 wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
                 wd["Cs_real"] = Ci_real
-                self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]])
-                self.flush_grad(w)
+                self.on_wgrad_lane(lambda: (self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]]), self.flush_grad(w)))
                 self.mark_final(*[q + sfx for q in pres for sfx in (".bn.weight", ".bn.bias")])
             if need_dx and part in ("all", "B"):
                 dz = st["dz"]
@@ -473,8 +496,8 @@ class Plan:
             ws = self.alloc(_act_bwd_ws(out.rows, cout))
             self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
-            self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), [dz.ref, x.ref, w["kg"]])
-            self.flush_grad(w)
+            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), [dz.ref, x.ref, w["kg"]]),
+                                        self.flush_grad(w)))
             self.mark_final(name + ".bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
@@ -533,8 +556,8 @@ class Plan:
             else:
                 self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
-            self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), [x.ref, dz.ref, w["kg"]])
-            self.flush_grad(w)
+            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), [x.ref, dz.ref, w["kg"]]),
+                                        self.flush_grad(w)))
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
             dd = D.conv_fwd(x.N, othw, cout, dz.ld, Ci, dx.ld, k, stride, pad, x.thw, flags=capi.F_ACCUM if acc else 0, ldw=cout)
@@ -568,9 +591,9 @@ class Plan:
             dtpl = self.alloc(SL.G * SL.t_g)
             dwv = self.alloc(SL.G * SL.w_g)
             self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dz.ld), capi.AXIS_FIELDS), p=[dz.ref, sm["Gt"], None, dtpl])
-            self.wgrad_op(SL.wgrad(), [xpl, dtpl, dwv])
-            self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[dwv, sm["tw"], w["kg"]])
-            self.flush_grad(w)
+            self.on_wgrad_lane(lambda: (self.wgrad_op(SL.wgrad(), [xpl, dtpl, dwv]),
+                                        self.emit(capi.OP_WSPEC_BWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[dwv, sm["tw"], w["kg"]]),
+                                        self.flush_grad(w)))
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
             dxpl = self.alloc(SL.G * SL.x_g)
@@ -711,10 +734,12 @@ class Plan:
                 dtpl = self.alloc(SL.G * SL.t_g)
                 dwv = self.alloc(SL.G * SL.w_g)
                 self.emit(capi.OP_AXIS, i=D.flatten(SL.dy_to_planes(dcaps.ld), capi.AXIS_FIELDS), p=[dcaps.ref, sm["Gt"], None, dtpl])
-                self.wgrad_op(SL.wgrad(), [dtpl, xpl, dwv])
-                for nm, a0, cnt in pc_names:
-                    self.emit(capi.OP_WSPEC_MASTER_BWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur, self.acc], p=[dwv, sm["tw"], self.G(nm)])
-                self.mark_final(*[nm for nm, _a, _c in pc_names])
+                def pc_wgrad():
+                    self.wgrad_op(SL.wgrad(), [dtpl, xpl, dwv])
+                    for nm, a0, cnt in pc_names:
+                        self.emit(capi.OP_WSPEC_MASTER_BWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur, self.acc], p=[dwv, sm["tw"], self.G(nm)])
+                    self.mark_final(*[nm for nm, _a, _c in pc_names])
+                self.on_wgrad_lane(pc_wgrad)
             else:
                 self.wgrad_op(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))),
                               [dcaps.ref, xd.ref, wpc["kg"]])
@@ -895,6 +920,8 @@ class Plan:
         for fn in reversed(self.tape):
             fn()
             self.flush_unprep()
+        if self.wg_lane or self.skip_lane:
+            self.join((1 << self.wg_lane | 1 << self.skip_lane) & ~1)
 
     def grad_buckets(self, target_floats=12_000_000):
         """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the

@@ -48,8 +48,9 @@ class StepEngine:
         self.hw = hw
         self.jhmdb = jhmdb
         if lanes is None:
-            # measured best on MI355X: lane 1 for the second Inception branch, lane 2 for the decoder's skip convs
-            lanes = int(os.environ.get("PICONS_LANES", "3"))
+            # measured best on MI355X: lane 1 for the second Inception branch, lane 2 for the decoder's skip convs,
+            # lane 3 for the weight gradients
+            lanes = int(os.environ.get("PICONS_LANES", "4"))
         p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         p.build_forward()

@@ -75,10 +75,11 @@ def _check_list(p, lst, lanes):
     for idx, op in enumerate(lst):
         kind, lane = op[0], op[5]
         if kind == capi.OP_FORK:
-            nregions += 1
-            for q in range(1, lanes):
-                if (op[1][0] >> q) & 1:
-                    clock[q] = [max(a, b) for a, b in zip(clock[q], clock[0])]
+            src = op[1][1] if len(op[1]) > 1 else 0
+            nregions += src == 0
+            for q in range(lanes):
+                if (op[1][0] >> q) & 1 and q != src:
+                    clock[q] = [max(a, b) for a, b in zip(clock[q], clock[src])]
             continue
         if kind == capi.OP_JOIN:
             for q in range(1, lanes):
@@ -100,41 +101,67 @@ def _check_list(p, lst, lanes):
     return nregions
 
 
-@pytest.mark.parametrize("lanes", [2, 3, 4])
+def _forks(p, name, mask):
+    return sum(1 for op in p.lists[name] if op[0] == capi.OP_FORK and op[1][0] == mask)
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4, 5])
 def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
     p = _plan(lanes)
-    skip = 1 if p.skip_lane else 0
-    assert bool(p.skip_lane) == (lanes >= 3)
+    assert bool(p.skip_lane) == (lanes >= 3) and bool(p.wg_lane) == (lanes >= 3)
+    assert (p.wg_lane != p.skip_lane) == (lanes >= 4) and p.branch_lanes == {2: 2, 3: 2, 4: 2, 5: 3}[lanes]
     for name in ("fwd", "loss", "bwd", "adam"):
-        n = _check_list(p, p.lists[name], lanes)
-        if name in ("fwd", "bwd"):
-            # one FORK per Inception module (Mixed_3b..4f) + the merged tail's position classes, + two for the skip convs
-            assert n == 8 + 2 * skip, (name, n)
-        else:
-            assert n == 0
-    if skip:
+        _check_list(p, p.lists[name], lanes)
+    branch = (1 << p.branch_lanes) - 2
+    for name in ("fwd", "bwd"):
+        # one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes
+        assert _forks(p, name, branch) == 8, name
+        if p.skip_lane and p.skip_lane != p.wg_lane:
+            assert _forks(p, name, 1 << p.skip_lane) == 2, name          # conv56, conv112
+    if p.skip_lane:
         on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
-        assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4 and sum(1 for op in on_skip if op[0] == capi.OP_WGRAD) == 2
+        assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4
+    if p.wg_lane:
+        wg = [op for op in p.lists["bwd"] if op[0] == capi.OP_WGRAD]
+        assert sum(1 for op in wg if op[5] == p.wg_lane) >= len(wg) - 16      # all but the merged tail's per-class launches
+        assert not [op for op in p.lists["fwd"] if op[5] == p.wg_lane and p.wg_lane != p.skip_lane]
 
 
-def test_skip_lane_can_be_switched_off(monkeypatch):
-    monkeypatch.setenv("PICONS_SKIP_LANE", "0")
+def test_side_lanes_can_be_switched_off(monkeypatch):
+    monkeypatch.setenv("PICONS_SKIP_LANE", "0"); monkeypatch.setenv("PICONS_WGRAD_LANE", "0")
     p = _plan(3)
-    assert not p.skip_lane and p.branch_lanes == 3
-    assert all(op[5] < 3 for lst in p.lists.values() for op in lst)
-    assert _check_list(p, p.lists["bwd"], 3) == 8
+    assert not p.skip_lane and not p.wg_lane and p.branch_lanes == 3
+    _check_list(p, p.lists["bwd"], 3)
+    assert _forks(p, "bwd", 6) == 8
+    monkeypatch.setenv("PICONS_SKIP_LANE", "1"); monkeypatch.setenv("PICONS_WGRAD_LANE", "1"); monkeypatch.setenv("PICONS_WGRAD_SEPARATE", "0")
+    q = _plan(4)
+    assert q.skip_lane == q.wg_lane == 3 and q.branch_lanes == 3
+    for name in ("fwd", "bwd"):
+        _check_list(q, q.lists[name], 4)
 
 
 def test_same_ops_as_single_lane_plan():
+    """Lanes only re-order: the multiset of ops (the gradient re-layout jobs counted one by one, since the lanes group them into
+    different multi-job launches) is that of the single-lane plan."""
     p1, p4 = _plan(1), _plan(4)
+
+    def strip(p, lst):
+        out = collections.Counter()
+        for op in lst:
+            if op[0] in (capi.OP_FORK, capi.OP_JOIN):
+                continue
+            if op[0] == capi.OP_TRANSPOSE_MULTI:
+                for job in p.multi_jobs[op[3][0][1]]:
+                    out[(capi.OP_TRANSPOSE, tuple(job[1]), tuple(job[2]), tuple(job[4]))] += 1
+            else:
+                out[(op[0], tuple(op[1]), tuple(op[2]), tuple(op[4]))] += 1
+        return out
     for name in ("prep", "fwd", "loss", "bwd", "adam"):
-        strip = lambda lst: collections.Counter((op[0], tuple(op[1]), tuple(op[2]), tuple(op[4])) for op in lst
-                                                if op[0] not in (capi.OP_FORK, capi.OP_JOIN))
-        assert strip(p1.lists[name]) == strip(p4.lists[name]), name
+        assert strip(p1, p1.lists[name]) == strip(p4, p4.lists[name]), name
     assert all(op[5] == 0 for lst in p1.lists.values() for op in lst)
 
 
-@pytest.mark.parametrize("lanes", [2, 3, 4])
+@pytest.mark.parametrize("lanes", [2, 3, 4, 5])
 def test_buckets_ready_only_at_joined_points(lanes):
     """A bucket may be all-reduced once every gradient in it is final AND ordered before lane 0's position `ready` in the
     backward list: replay the list up to `ready` with vector clocks and check the finalising op of every parameter of the
@@ -152,9 +179,10 @@ def test_buckets_ready_only_at_joined_points(lanes):
     for idx, op in enumerate(bwd):
         kind, lane = op[0], op[5]
         if kind == capi.OP_FORK:
-            for q in range(1, lanes):
-                if (op[1][0] >> q) & 1:
-                    clock[q] = [max(x, y) for x, y in zip(clock[q], clock[0])]
+            src = op[1][1] if len(op[1]) > 1 else 0
+            for q in range(lanes):
+                if (op[1][0] >> q) & 1 and q != src:
+                    clock[q] = [max(x, y) for x, y in zip(clock[q], clock[src])]
         elif kind == capi.OP_JOIN:
             for q in range(1, lanes):
                 if (op[1][0] >> q) & 1:
