@@ -212,13 +212,17 @@ int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s);
  *  W      [B][C][4][4], beta_u [C][16], beta_a [C]
  *  out    [npos][C*17]   (mu C*16 then a_out C)
  * backward: hand-derived reverse of all iterations (autograd equivalent), per-block partial
- * parameter grads in ws then reduced; dW/dbeta_u/dbeta_a accumulated (+=). */
+ * parameter grads in ws then reduced; dW/dbeta_u/dbeta_a accumulated (+=).
+ *  state  optional, pc_em_state_floats(npos) floats, 16-byte aligned: the forward leaves every iteration's routing state
+ *         there (assignments, means, variances, ...: 21 KB per position) and a backward given the same buffer loads it
+ *         instead of running the routing iterations again; NULL = no state kept / the backward recomputes the forward. */
 int64_t pc_em_ws_floats(int npos, int B, int C);
+int64_t pc_em_state_floats(int npos);
 int pc_em_routing_fwd(const float* x, const float* W, const float* beta_u, const float* beta_a,
-                      int npos, int B, int C, float* out, pc_stream s);
+                      int npos, int B, int C, float* out, float* state, pc_stream s);
 int pc_em_routing_bwd(const float* x, const float* W, const float* beta_u, const float* beta_a,
                       const float* dout, int npos, int B, int C, float* dx, float* dW,
-                      float* dbeta_u, float* dbeta_a, float* ws, pc_stream s);
+                      float* dbeta_u, float* dbeta_a, float* ws, const float* state, pc_stream s);
 
 /* class-capsule masking (capsules_ucf101.py:438-484):
  *  actor_prediction[b][c] = mean_pos act; mask row: labeled -> one-hot(cls), unlabeled ->

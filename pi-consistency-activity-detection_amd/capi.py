@@ -87,8 +87,9 @@ _SIGS = {
     "pc_fill": (i32, [vp, i64, f32, vp]),
     "pc_axpy": (i32, [vp, vp, i64, f32, vp]),
     "pc_em_ws_floats": (i64, [i32, i32, i32]),
-    "pc_em_routing_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp]),
-    "pc_em_routing_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp]),
+    "pc_em_state_floats": (i64, [i32]),
+    "pc_em_routing_fwd": (i32, [vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]),
+    "pc_em_routing_bwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     "pc_class_mask_fwd": (i32, [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp]),
     "pc_class_mask_bwd": (i32, [vp, vp, vp, i32, i32, i32, vp, vp]),
     "pc_tapsum_fwd": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),

@@ -68,10 +68,10 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_AXPY:
             return pc_axpy(P(float*, 0), P(const float*, 1), op.l[0], op.f[0], s);
         case PC_OP_EM_FWD:
-            return pc_em_routing_fwd(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), op.i[0], op.i[1], op.i[2], P(float*, 4), s);
+            return pc_em_routing_fwd(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), op.i[0], op.i[1], op.i[2], P(float*, 4), P(float*, 5), s);
         case PC_OP_EM_BWD:
             return pc_em_routing_bwd(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), P(const float*, 4), op.i[0], op.i[1],
-                                     op.i[2], P(float*, 5), P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), s);
+                                     op.i[2], P(float*, 5), P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), P(const float*, 10), s);
         case PC_OP_CMASK_FWD:
             return pc_class_mask_fwd(P(const float*, 0), op.i[0], op.i[1], op.i[2], P(const float*, 1), P(const int32_t*, 2), op.i[3], P(float*, 3),
                                      P(float*, 4), P(float*, 5), s);

@@ -9,6 +9,7 @@
 // materialised: v[i][c][p,q] = sum_k P_i[p][k] * W[i][c][k][q] is recomputed from the
 // position's poses and W^T held in LDS.  Reductions over h use 16-lane xor shuffles.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,11 +77,11 @@ __device__ __forceinline__ float sum_p(float v) {   // over lane bits 2,3 (the f
 // forward state of one position (floats).  The backward kernel replays the forward and needs every iteration's
 // intermediates (FwdState); the forward kernel only needs the current one (FwdLite: 8.7 KB instead of 21.6 KB per
 // wave, so ten waves instead of four share one copy of W^T in LDS).
-struct FwdState {
-    float P[NB][16];
-    float a[NB];
+// What the backward needs from the forward of one position, apart from the inputs themselves (5 236 floats, 21 KB).  The
+// training forward kernel can leave it in global memory (pc_em_routing_fwd `state`), so the backward loads it instead of running
+// the three routing iterations again (a third of its time).
+struct EmSaved {
     float R[2][NB][MAXC];      // assignments entering iterations 1 and 2 (iteration 0 uses the constant 1/C)
-    float rn[NB][MAXC];        // scratch: normalised assignment of the current iteration
     float invS[3][NB];
     float rs[3][MAXC];
     float mu[3][MAXC][16];
@@ -88,6 +89,14 @@ struct FwdState {
     float aout[3][MAXC];
     float sd[3][MAXC][16];     // sum_i co (v - mu) as the rounded arithmetic leaves it (zero in exact arithmetic up to eps/(rs+eps))
     float D[4];                // stdv + eps per iteration
+    float pad_[8];             // 5 248 floats: a whole number of 16-byte pieces
+};
+static_assert(sizeof(EmSaved) % 16 == 0, "EmSaved is copied in 16-byte pieces");
+
+struct FwdState : EmSaved {
+    float P[NB][16];
+    float a[NB];
+    float rn[NB][MAXC];        // scratch: normalised assignment of the current iteration
     static constexpr bool KEEP_SD = true;
     static __device__ __forceinline__ int ti(int t) { return t; }
     __device__ __forceinline__ float& r_prev(int t, int i, int c) { return R[t - 1][i][c]; }
@@ -171,7 +180,7 @@ __device__ __forceinline__ void xwave_sum(float (&v)[CJ], float* red, int wv, in
 
 // Forward EM for the position held in st->P / st->a.  Leaves every iteration's state in *st.
 template <int NW, class ST>
-__device__ void em_forward(ST* st, const float* WT, const float* beta_u, const float* beta_a, int C, int tid, float* red) {
+__device__ void em_forward(ST* st, const float* WT, const float* beta_u, const float* beta_a, int C, int tid, float* red, EmSaved* gs = nullptr) {
     const int lane = tid & 63, wv = tid >> 6;
     const int h = lane & 15, cg = lane >> 4, p = h >> 2, q = h & 3;
     const int i0 = wv * (NB / NW), i1 = i0 + NB / NW;
@@ -225,12 +234,12 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
                 if (c < C) {
                     const float d = vote(WT, prow, i, c, q, C) - m[j], cw = st->rnorm(i, c) * irs[j];
                     sg[j] += cw * d * d;
-                    if (ST::KEEP_SD) sdv[j] += cw * d;
+                    if (ST::KEEP_SD || gs) sdv[j] += cw * d;
                 }
             }
         }
         xwave_sum<NW>(sg, red, wv, lane);
-        if (ST::KEEP_SD) {
+        if (ST::KEEP_SD || gs) {
             // The backward needs d sigma^2 / d mu = -2 sum_i co (v - mu) with the SAME rounded differences the sigma^2 above was
             // built from: the rounding error of mu then cancels between this term and the direct 2 co (v - mu) term of each
             // vote's gradient (as it does in autograd).  Its exact-arithmetic value -2 mu eps / (rs + eps) does not cancel it,
@@ -245,6 +254,7 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
             if (c < C) {
                 sg[j] += EPS;
                 if (wv == 0) { st->mu[tt][c][h] = m[j]; st->s2[tt][c][h] = sg[j]; if (ST::KEEP_SD) ((FwdState*)st)->sd[tt][c][h] = sdv[j]; }
+                if (gs && wv == 0) { gs->mu[t][c][h] = m[j]; gs->s2[t][c][h] = sg[j]; gs->sd[t][c][h] = sdv[j]; }
                 cost[j] = sum16((beta_u[c * 16 + h] + 0.5f * logf(sg[j])) * st->rs[tt][c]);
                 csum += (double)cost[j];
             }
@@ -268,10 +278,14 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
             ao[j] = 0.f;
             if (c < C) {
                 ao[j] = 1.0f / (1.0f + expf(-LAMBDA * (beta_a[c] - (mean - cost[j]) / D)));
-                if (h == 0 && wv == 0) st->aout[tt][c] = ao[j];
+                if (h == 0 && wv == 0) { st->aout[tt][c] = ao[j]; if (gs) gs->aout[t][c] = ao[j]; }
             }
         }
-        if (tid == 0) st->D[t] = D;
+        if (tid == 0) { st->D[t] = D; if (gs) gs->D[t] = D; }
+        if (gs) {
+            if (tid < NB) gs->invS[t][tid] = st->invS[tt][tid];
+            if (tid < C) gs->rs[t][tid] = st->rs[tt][tid];
+        }
         SYNC<NW>();
         if (t == 2) break;
         // ---- E-step (capsules_ucf101.py:176-181)
@@ -304,7 +318,7 @@ __device__ void em_forward(ST* st, const float* WT, const float* beta_u, const f
             for (int c = part; c < C; c += RP) { const float e = expf(st->r_next(t, i, c) - mx); st->r_next(t, i, c) = e; s += e; }
             s = seg_sum<RP>(s);
             const float inv = 1.0f / s;
-            for (int c = part; c < C; c += RP) st->r_next(t, i, c) *= inv;
+            for (int c = part; c < C; c += RP) { const float r = st->r_next(t, i, c) * inv; st->r_next(t, i, c) = r; if (gs) gs->R[t][i][c] = r; }
         }
         SYNC<NW>();
     }
@@ -333,7 +347,7 @@ constexpr int FWD_WAVES = 10;
 // (A cooperative 4-waves-per-position variant was measured slower: more barriers.)
 __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ beta_u, const float* __restrict__ beta_a,
-                                                                 int npos, int C, float* __restrict__ out) {
+                                                                 int npos, int C, float* __restrict__ out, EmSaved* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* WT = smem;
     FwdLite* sts = (FwdLite*)(smem + NB * MAXC * 16);
@@ -345,7 +359,7 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __r
         WSYNC();
         load_pos(st, x, pos, lane, 64);
         WSYNC();
-        em_forward<1>(st, WT, beta_u, beta_a, C, lane, nullptr);
+        em_forward<1>(st, WT, beta_u, beta_a, C, lane, nullptr, state ? state + pos : nullptr);
         float* o = out + pos * (C * 17);
         for (int e = lane; e < C * 16; e += 64) o[e] = (&st->mu[0][0][0])[e];
         if (lane < C) o[C * 16 + lane] = st->aout[0][lane];
@@ -358,13 +372,14 @@ __global__ __launch_bounds__(64 * FWD_WAVES) void em_fwd_kernel(const float* __r
 // no-return float atomics (each element has one owner thread, so there is no contention) instead of 49 KB of LDS.
 constexpr int BWD_WAVES = 4;   // 8 cooperating waves spill (256 VGPR cap at 2 waves/SIMD)
 constexpr int BW = BWD_WAVES;
-constexpr int BWD_GROUPS = 2;
+constexpr int BWD_GROUPS_MAX = 2;     // workspace is sized for two teams per block
 constexpr int EM_SMALL = MAXC * 16 + 32;          // dbeta_u [C][16] + dbeta_a [C] accumulators
 
+template <int BWD_GROUPS>
 __global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(const float* __restrict__ x, const float* __restrict__ W,
                                                                  const float* __restrict__ beta_u, const float* __restrict__ beta_a,
                                                                  const float* __restrict__ dout, int npos, int C, float* __restrict__ dx,
-                                                                 float* __restrict__ part) {
+                                                                 float* __restrict__ part, const EmSaved* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr int NT = 64 * BW;
     constexpr int GRP_FLOATS = EM_SMALL + (sizeof(FwdState) + sizeof(BwdState)) / 4 + BW * MAXC * 16;
@@ -394,8 +409,13 @@ __global__ __launch_bounds__(64 * BWD_WAVES * BWD_GROUPS) void em_bwd_kernel(con
         const int64_t pos = live ? (int64_t)team + (int64_t)rd * nteams : npos - 1;
         __syncthreads();
         load_pos(st, x, pos, tid, NT);
+        if (state) {       // the forward kernel left this position's routing state in global memory
+            const f32x4* src = (const f32x4*)(state + pos);
+            f32x4* dstp = (f32x4*)(EmSaved*)st;
+            for (int e = tid; e < (int)(sizeof(EmSaved) / 16); e += NT) dstp[e] = src[e];
+        }
         __syncthreads();
-        em_forward<BW>(st, WT, beta_u, beta_a, C, tid, red);
+        if (!state) em_forward<BW>(st, WT, beta_u, beta_a, C, tid, red);
         // ---- seeds
         const float* dop = dout + pos * (C * 17);
         for (int e = tid; e < 3 * MAXC * 16; e += NT) { (&bs->dmu[0][0][0])[e] = 0.f; (&bs->ds2[0][0][0])[e] = 0.f; }
@@ -765,19 +785,25 @@ __global__ __launch_bounds__(256) void tapsum_bwd_kernel(const float* __restrict
     }
 }
 
-inline int em_bwd_blocks(int npos) { const int b = (npos + BWD_GROUPS - 1) / BWD_GROUPS; return b < 256 ? b : 256; }
+inline int em_bwd_blocks(int npos, int groups = BWD_GROUPS_MAX) { const int b = (npos + groups - 1) / groups; return b < 256 ? b : 256; }
+// PICONS_EM_GROUPS: teams per block of the EM backward.  2 = 154 KB of LDS per block: nothing else fits on the CU while it runs;
+// 1 = 102 KB: one 128x64 GEMM block of another lane (49 KB) can share the CU, so the skip-conv / weight-gradient lanes keep moving.
+inline int em_groups() { static const int g = getenv("PICONS_EM_GROUPS") ? atoi(getenv("PICONS_EM_GROUPS")) : 2; return g == 1 ? 1 : 2; }
 constexpr size_t EM_PART = NB * MAXC * 16 + MAXC * 16 + 32;
 
 }  // namespace
 
 extern "C" int64_t pc_em_ws_floats(int npos, int B, int C) {
     (void)B; (void)C;
-    return (int64_t)em_bwd_blocks(npos) * BWD_GROUPS * (int64_t)EM_PART + 64;
+    return (int64_t)256 * BWD_GROUPS_MAX * (int64_t)EM_PART + 64;
 }
 
+extern "C" int64_t pc_em_state_floats(int npos) { return (int64_t)npos * (int64_t)(sizeof(EmSaved) / 4); }
+
 extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* beta_u, const float* beta_a, int npos, int B, int C,
-                                 float* out, pc_stream s) {
+                                 float* out, float* state, pc_stream s) {
     PC_CHECK_ARG(x && W && beta_u && beta_a && out, "pc_em_routing_fwd: null");
+    PC_CHECK_ARG(!state || (uintptr_t)state % 16 == 0, "pc_em_routing_fwd: state alignment");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_fwd: B must be 32 and C <= 24 (B=%d C=%d)", B, C);
     PC_CHECK_ARG((uintptr_t)x % 16 == 0, "pc_em_routing_fwd: x alignment");
     const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdLite) * FWD_WAVES;
@@ -785,21 +811,28 @@ extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* be
     if (!attr) { (void)hipFuncSetAttribute((const void*)em_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     int grid = cdiv(npos, FWD_WAVES);
     if (grid > 256) grid = 256;            // one block (10 waves, 136 KB of LDS) per CU, positions strided over the grid
-    hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out);
+    hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out, (EmSaved*)state);
     PC_CHECK_LAUNCH("em_fwd");
     return PC_OK;
 }
 
 extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* beta_u, const float* beta_a, const float* dout, int npos,
-                                 int B, int C, float* dx, float* dW, float* dbeta_u, float* dbeta_a, float* ws, pc_stream s_) {
+                                 int B, int C, float* dx, float* dW, float* dbeta_u, float* dbeta_a, float* ws, const float* state, pc_stream s_) {
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(x && W && beta_u && beta_a && dout && dx && dW && dbeta_u && dbeta_a && ws, "pc_em_routing_bwd: null");
+    PC_CHECK_ARG(!state || (uintptr_t)state % 16 == 0, "pc_em_routing_bwd: state alignment");
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_bwd: B must be 32 and C <= 24");
+    const int BWD_GROUPS = em_groups();
     const size_t lds = (size_t)NB * MAXC * 16 * 4 + BWD_GROUPS * ((size_t)EM_SMALL * 4 + sizeof(FwdState) + sizeof(BwdState) + BWD_WAVES * MAXC * 16 * 4);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)em_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    const int nblk = em_bwd_blocks(npos);
-    hipLaunchKernelGGL(em_bwd_kernel, dim3(nblk), dim3(64 * BWD_WAVES * BWD_GROUPS), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws);
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)em_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)em_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int nblk = em_bwd_blocks(npos, BWD_GROUPS);
+    if (BWD_GROUPS == 1) hipLaunchKernelGGL(em_bwd_kernel<1>, dim3(nblk), dim3(64 * BWD_WAVES), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws, (const EmSaved*)state);
+    else hipLaunchKernelGGL(em_bwd_kernel<2>, dim3(nblk), dim3(64 * BWD_WAVES * 2), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws, (const EmSaved*)state);
     PC_CHECK_LAUNCH("em_bwd");
     hipLaunchKernelGGL(em_reduce_kernel, dim3(cdiv(NB * C * 16 + C * 17, RED_E)), dim3(256), 0, s, ws, nblk * BWD_GROUPS, C, dW, dbeta_u, dbeta_a);
     PC_CHECK_LAUNCH("em_reduce");

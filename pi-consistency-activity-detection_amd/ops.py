@@ -112,16 +112,21 @@ def transpose_batched(src, batch, R, Cc, sbs, sld, dst, dbs, dld, accum=False):
     capi.call("pc_transpose_batched", ptr(src), batch, R, Cc, int(sbs), sld, ptr(dst), int(dbs), dld, int(accum), stream())
 
 
-def em_fwd(x, W, bu, ba, npos, B, C_):
+def em_fwd(x, W, bu, ba, npos, B, C_, state=None):
+    """state: optional float32 device tensor of pc_em_state_floats(npos) floats the forward fills for em_bwd."""
     out = torch.empty(npos, C_ * 17, device=x.device, dtype=torch.float32)
-    capi.call("pc_em_routing_fwd", ptr(x), ptr(W), ptr(bu), ptr(ba), npos, B, C_, ptr(out), stream())
+    capi.call("pc_em_routing_fwd", ptr(x), ptr(W), ptr(bu), ptr(ba), npos, B, C_, ptr(out), ptr(state), stream())
     return out
 
 
-def em_bwd(x, W, bu, ba, dout, npos, B, C_, dW, dbu, dba):
-    dx = torch.empty_like(x)
+def em_state(npos, device):
+    return torch.empty(capi.lib().pc_em_state_floats(int(npos)), device=device, dtype=torch.float32)
+
+
+def em_bwd(x, W, bu, ba, dout, npos, B, C_, dW, dbu, dba, state=None):
+    dx = torch.empty(npos, B * 17, device=x.device, dtype=torch.float32)
     ws = torch.empty(capi.lib().pc_em_ws_floats(npos, B, C_), device=x.device, dtype=torch.float32)
-    capi.call("pc_em_routing_bwd", ptr(x), ptr(W), ptr(bu), ptr(ba), ptr(dout), npos, B, C_, ptr(dx), ptr(dW), ptr(dbu), ptr(dba), ptr(ws), stream())
+    capi.call("pc_em_routing_bwd", ptr(x), ptr(W), ptr(bu), ptr(ba), ptr(dout), npos, B, C_, ptr(dx), ptr(dW), ptr(dbu), ptr(dba), ptr(ws), ptr(state), stream())
     return dx
 
 

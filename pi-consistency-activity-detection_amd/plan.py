@@ -704,7 +704,9 @@ class Plan:
         npos = N * s20 * s20
         comb = self.tensor(N, (1, s20, s20), C * 17, "comb")
         Wc, bu, ba = self.P("conv_caps.weights"), self.P("conv_caps.beta_u"), self.P("conv_caps.beta_a")
-        self.emit(capi.OP_EM_FWD, i=[npos, spec.IN_CAPS, C], p=[caps_in.ref, Wc, bu, ba, comb.ref])
+        # training: the forward leaves its routing state (21 KB per position) for the backward, which then skips the recompute
+        em_state = self.alloc(capi.lib().pc_em_state_floats(int(npos))) if self.training else None
+        self.emit(capi.OP_EM_FWD, i=[npos, spec.IN_CAPS, C], p=[caps_in.ref, Wc, bu, ba, comb.ref, em_state])
         # class-capsule masking (capsules_ucf101.py:438-484)
         self.pred = self.alloc(N * C)
         cmask = self.alloc(N * C)
@@ -722,7 +724,7 @@ class Plan:
                 if not self.acc:
                     self.emit(capi.OP_FILL, p=[self.G(nm)], l=[int(np.prod(self.pshape[nm]))], f=[0.0])
             self.emit(capi.OP_EM_BWD, i=[npos, spec.IN_CAPS, C],
-                      p=[caps_in.ref, Wc, bu, ba, dcomb.ref, dcaps.ref, self.G("conv_caps.weights"), self.G("conv_caps.beta_u"), self.G("conv_caps.beta_a"), ws])
+                      p=[caps_in.ref, Wc, bu, ba, dcomb.ref, dcaps.ref, self.G("conv_caps.weights"), self.G("conv_caps.beta_u"), self.G("conv_caps.beta_a"), ws, em_state])
             # primary caps backward: sigmoid on the activation channels, bias grads, wgrad, dgrad
             ws2 = self.alloc(_act_bwd_ws(caps_in.rows, npose))
             a_sl, da_sl = caps_in.slice(npose, spec.IN_CAPS), dcaps.slice(npose, spec.IN_CAPS)

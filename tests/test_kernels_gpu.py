@@ -417,9 +417,17 @@ def test_em_routing_fwd_bwd(C_, npos, pscale):
     ref64 = _em_oracle(x, W, bu, ba, dout, npos, B, C_, torch.float64)
     ref32 = _em_oracle(x, W, bu, ba, dout, npos, B, C_, torch.float32)
     xg = x.to(DEV); Wg = W[0].contiguous().to(DEV)
-    og = ops.em_fwd(xg, Wg, bu.to(DEV), ba.to(DEV), npos, B, C_)
+    # the training path: the forward leaves its routing state for the backward; without it the backward recomputes the forward --
+    # same gradients either way, up to the rounding of the one-wave / four-wave reductions
+    state = ops.em_state(npos, DEV)
+    og = ops.em_fwd(xg, Wg, bu.to(DEV), ba.to(DEV), npos, B, C_, state=state)
+    assert torch.equal(og, ops.em_fwd(xg, Wg, bu.to(DEV), ba.to(DEV), npos, B, C_))
     dW = torch.zeros(B, C_, 4, 4, device=DEV); dbu = torch.zeros(C_, 16, device=DEV); dba = torch.zeros(C_, device=DEV)
-    dx = ops.em_bwd(xg, Wg, bu.to(DEV), ba.to(DEV), dout.to(DEV), npos, B, C_, dW, dbu, dba)
+    dx = ops.em_bwd(xg, Wg, bu.to(DEV), ba.to(DEV), dout.to(DEV), npos, B, C_, dW, dbu, dba, state=state)
+    dW2 = torch.zeros_like(dW); dbu2 = torch.zeros_like(dbu); dba2 = torch.zeros_like(dba)
+    dx2 = ops.em_bwd(xg, Wg, bu.to(DEV), ba.to(DEV), dout.to(DEV), npos, B, C_, dW2, dbu2, dba2)
+    for a_, b_ in ((dx, dx2), (dW, dW2), (dbu, dbu2), (dba, dba2)):
+        assert ((a_ - b_).norm() / (b_.norm() + 1e-30)).item() < 1e-4
     got = [og[:, :C_ * 16], og[:, C_ * 16:], dx, dW, dbu, dba]
     names = ["mu", "a_out", "dx", "dW", "dbeta_u", "dbeta_a"]
     report = []
