@@ -60,7 +60,7 @@ class _CapsFn(torch.autograd.Function):
     def forward(ctx, owner, slot, n, *params):
         ctx.owner, ctx.slot, ctx.n = owner, slot, n
         ctx.guard = _SlotGuard(slot)
-        ops.run_ops(slot.ops["prep"])
+        ops.run_ops(slot.ops["prep"]); ops.run_ops(slot.ops["prep_late"])
         ops.run_ops(slot.ops["fwd"])
         p = slot.plan
         per = spec.FRAMES * owner.hw * owner.hw
@@ -237,7 +237,7 @@ class CapsNet(nn.Module):
                 return _CapsFn.apply(self, s, n, *self._params)
             # train-mode forward under no_grad (batch statistics, dropout): no backward will come, the slot stays free
         with torch.no_grad():
-            ops.run_ops(s.ops["prep"])
+            ops.run_ops(s.ops["prep"]); ops.run_ops(s.ops["prep_late"])
             ops.run_ops(s.ops["fwd"])
             perm = spec.FRAMES * self.hw * self.hw
             out = s.view(p.out.ref, n * perm).view(n, 1, spec.FRAMES, self.hw, self.hw).clone()
@@ -276,7 +276,7 @@ class InceptionI3d(nn.Module):
             s.view(p.in_cls, n).zero_()
             s.view(p.in_labeled, n, torch.int32).zero_()
         with torch.no_grad():
-            ops.run_ops(s.ops["prep"])
+            ops.run_ops(s.ops["prep"]); ops.run_ops(s.ops["prep_late"])
             ops.run_ops(s.ops["fwd"])
             outs = []
             for nm in ("trunk_out", "conv1.Conv3d_2c_3x3.y", "conv1.Conv3d_1a_7x7.y"):

@@ -70,6 +70,7 @@ class Plan:
         self.branch_lanes = lanes - len({ln for ln in (self.wg_lane, self.skip_lane) if ln})
         self.skip_bwd = {}
         self.final_lane = {}      # param name -> lane of the op that finalises its gradient
+        self.deferred = None      # build_backward: side-lane closures held back until the EM backward is enqueued
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
         self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
@@ -84,7 +85,12 @@ class Plan:
         self.training = training
         self.jhmdb = jhmdb
         self.arena_bytes = 0
-        self.lists = {"prep": [], "fwd": [], "loss": [], "bwd": [], "unprep": [], "adam": []}
+        self.lists = {"prep": [], "prep_late": [], "fwd": [], "loss": [], "bwd": [], "unprep": [], "adam": []}
+        # Weight-layout prep of everything but the first trunk layers goes to `prep_late`: enqueued on the side lanes behind `prep`
+        # and joined inside the forward list before Mixed_3b, so it runs beside the stem / Conv3d_2b / Conv3d_2c instead of in front
+        # of them (0.65 ms of the step's critical path).  PICONS_LATE_PREP=0 or a plan without side lanes: everything in `prep`.
+        self.late_prep = bool(self.wg_lane) and os.environ.get("PICONS_LATE_PREP", "1") != "0"
+        self.prep_target = "prep_late" if self.late_prep else "prep"
         self.cur = "fwd"
         self.tape = []
         self.grads = {}           # buffer name -> [TR, initialised]
@@ -224,23 +230,27 @@ class Plan:
         Ipad = Ipad or I
         O = sum(O_list)
         key = names[0]
+        saved_target = self.prep_target
+        if self.late_prep and any(key.startswith("conv1." + u) for u in ("Conv3d_1a_7x7", "Conv3d_2b_1x1", "Conv3d_2c_3x3")):
+            self.prep_target = "prep"          # needed before anything else runs
         w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc_kg(O * taps * Ipad), unprep=[])
         pl = self.next_prep_lane()
         if Ipad != I:
-            self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst="prep", lane=pl)
+            self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst=self.prep_target, lane=pl)
         if need_tr:
             w["tr"] = self.alloc(I * taps * O)
         o0 = 0
         for nm, Oi in zip(names, O_list):
             src = self.P(nm)
             self.emit(capi.OP_TRANSPOSE, i=[Oi, I, taps, taps, Ipad, 0], l=[I * taps, taps * Ipad],
-                      p=[src, off(w["fwd"], o0 * taps * Ipad)], lst="prep", lane=pl)
+                      p=[src, off(w["fwd"], o0 * taps * Ipad)], lst=self.prep_target, lane=pl)
             if need_tr:
-                self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst="prep", lane=pl)
+                self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst=self.prep_target, lane=pl)
             # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]  (flushed right after the wgrad, see flush_grad)
             w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, self.acc], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
             o0 += Oi
         self.kw[key] = w
+        self.prep_target = saved_target
         return w
 
     def prep_convT_weight(self, name, I, O, k):
@@ -250,8 +260,8 @@ class Plan:
         w = dict(O=O, I=I, taps=taps, fwd=self.alloc(O * taps * I), tr=self.alloc(I * taps * O), kg=self.alloc_kg(I * taps * O), unprep=[])
         src = self.P(name)
         pl = self.next_prep_lane()
-        self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst="prep", lane=pl)
-        self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst="prep", lane=pl)
+        self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst=self.prep_target, lane=pl)
+        self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst=self.prep_target, lane=pl)
         w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, self.acc], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
         self.kw[name] = w
         return w
@@ -298,6 +308,9 @@ class Plan:
         """Run the emissions of fn (a weight-gradient launch and what hangs off it) on the wgrad lane, behind the current lane."""
         if not self.wg_lane or self.lane == self.wg_lane:
             return fn()
+        if self.deferred is not None:
+            self.deferred.append(lambda: self.on_wgrad_lane(fn))
+            return
         self.fork(1 << self.wg_lane, src=self.lane)
         saved, self.lane = self.lane, self.wg_lane
         fn()
@@ -422,16 +435,21 @@ class Plan:
             out = wide.slice(e, c3 + oc[5])
             outer, self.tape = self.tape, []
             self.unit3d([pre + ".b1a", pre + ".b2a", pre + ".b0"], x, [oc[1], oc[3], oc[0]], one, one, out=wide.slice(0, e + oc[0]))
-            # the big 3x3x3 branch on lane 0, pool branch + the small 3x3x3 branch on lane 1 (measured best of four assignments)
-            self.fork()
+            # the big 3x3x3 branch on lane 0, pool branch + the small 3x3x3 branch on lane 1 (measured best of four assignments);
+            # in the forward the weight-gradient lane is idle and takes the small 3x3x3 branch (PICONS_FWD_BRANCH3=0: off)
+            third = self.wg_lane if (self.wg_lane and os.environ.get("PICONS_FWD_BRANCH3", "1") != "0") else 0
+            fmask = ((1 << self.branch_lanes) - 2) | (1 << third if third else 0)
+            self.fork(fmask)
             self.lane = L(0)
             self.unit3d(pre + ".b1b", wide.slice(0, oc[1]), oc[2], (3, 3, 3), one, out=out.slice(c1, oc[2]))
             self.lane = L(1)
             t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
             self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
+            if third:
+                self.lane = third
             self.unit3d(pre + ".b2b", wide.slice(oc[1], oc[3]), oc[4], (3, 3, 3), one, out=out.slice(c2, oc[4]))
             self.lane = 0
-            self.join()
+            self.join(fmask)
             (fused, b1b, pool, b3b, b2b), self.tape = self.tape, outer
 
             def bwd_fused():
@@ -517,12 +535,24 @@ class Plan:
 
     def _on_skip_lane(self, fn):
         def g():
+            if self.deferred is not None:         # held back until the EM backward has been enqueued (release_deferred)
+                self.deferred.append(g)
+                return
             self.fork(1 << self.skip_lane)        # behind the decoder gradient it consumes
             self.lane = self.skip_lane
             fn()
             self.flush_unprep()
             self.lane = 0
         return g
+
+    def release_deferred(self):
+        """The side-lane work held back during the decoder's backward (skip-conv backward, weight gradients) is enqueued now,
+        behind everything lane 0 has enqueued so far.  Called right after the EM backward: that kernel needs whole CUs (154 KB of
+        LDS per block), so side-lane kernels in flight when it starts stretch it from 0.83 to 1.5 ms and stall themselves; and the
+        launches that leave CU slots idle are the trunk's, which come after it -- that is where the side lanes' work belongs."""
+        held, self.deferred = self.deferred, None
+        for fn in held or ():
+            fn()
 
     def convT_layer(self, name, x, cout, k, stride, pad, opad, act, out, cscale=None):
         """nn.ConvTranspose2d/3d + bias (+ReLU) (+Dropout3d scale) into `out` (channel slice)."""
@@ -572,8 +602,8 @@ class Plan:
         sm = {kk: self.const(v) for kk, v in SL.matrices().items()}
         w["wv"] = self.alloc(SL.G * SL.w_g)                  # [g][Co][ky][Ci]  forward (transposed-form) GEMM weight planes
         w["wvt"] = self.alloc(SL.G * SL.w_g)                 # [g][Ci][ky][Co]  dgrad GEMM weight planes
-        self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu, SL.Ur], p=[w["fwd"], sm["tw"], w["wv"]], lst="prep")
-        self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[w["tr"], sm["tw"], w["wvt"]], lst="prep")
+        self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu, SL.Ur], p=[w["fwd"], sm["tw"], w["wv"]], lst=self.prep_target)
+        self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[w["tr"], sm["tw"], w["wvt"]], lst=self.prep_target)
         xpl = self.alloc(SL.G * SL.x_g)
         tpl = self.alloc(SL.G * SL.t_g)
         self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_planes(), capi.AXIS_FIELDS), p=[x.ref, sm["F"], None, xpl])
@@ -628,6 +658,8 @@ class Plan:
             cat112 = self.tensor(N, (4, 4 * s28e, 4 * s28e), 128, "cat112")
         for ent in spec.TRUNK:
             name = "conv1." + ent[0]
+            if ent[0] == "Mixed_3b" and self.late_prep:
+                self.join(1 << self.wg_lane)          # the weight layouts of everything from here on (list prep_late)
             if ent[1] == "conv":
                 x = self.unit3d(name, x, ent[3], ent[4], ent[5], need_dx=not first)
                 first = False
@@ -681,15 +713,15 @@ class Plan:
             pl = self.next_prep_lane()
             for nm, a0, cnt in pc_names:      # pose rows, then activation rows, of the same plane buffers: one lane
                 self.emit(capi.OP_WSPEC_MASTER_FWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[self.P(nm), sm["tw"], wpc["wv"], wpc["wvt"]],
-                          lst="prep", lane=pl)
+                          lst=self.prep_target, lane=pl)
         else:
             wpc = self.prep_conv_weight([nm for nm, _a, _c in pc_names], [cnt for _n, _a, cnt in pc_names], xd.C, (1, KP, KP), True)
             wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
             self.emit(capi.OP_TRANSPOSE, i=[1, Cpc, KP * KP * xd.C, KP * KP * xd.C, Cpc, 0], l=[0, 0],
-                      p=[wpc["fwd"], wpc["tio"]], lst="prep")
+                      p=[wpc["fwd"], wpc["tio"]], lst=self.prep_target)
         pc_bias = self.alloc(npose + spec.IN_CAPS)
-        self.emit(capi.OP_TRANSPOSE, i=[1, 1, npose, npose, 1, 0], l=[0, 0], p=[self.P("primary_caps.pose.bias"), pc_bias], lst="prep")
-        self.emit(capi.OP_TRANSPOSE, i=[1, 1, spec.IN_CAPS, spec.IN_CAPS, 1, 0], l=[0, 0], p=[self.P("primary_caps.a.bias"), off(pc_bias, npose)], lst="prep")
+        self.emit(capi.OP_TRANSPOSE, i=[1, 1, npose, npose, 1, 0], l=[0, 0], p=[self.P("primary_caps.pose.bias"), pc_bias], lst=self.prep_target)
+        self.emit(capi.OP_TRANSPOSE, i=[1, 1, spec.IN_CAPS, spec.IN_CAPS, 1, 0], l=[0, 0], p=[self.P("primary_caps.a.bias"), off(pc_bias, npose)], lst=self.prep_target)
         pc_dbias = self.alloc(npose + spec.IN_CAPS)
         if spectral_pc:
             xpl = self.alloc(SL.G * SL.x_g)
@@ -725,6 +757,7 @@ class Plan:
                     self.emit(capi.OP_FILL, p=[self.G(nm)], l=[int(np.prod(self.pshape[nm]))], f=[0.0])
             self.emit(capi.OP_EM_BWD, i=[npos, spec.IN_CAPS, C],
                       p=[caps_in.ref, Wc, bu, ba, dcomb.ref, dcaps.ref, self.G("conv_caps.weights"), self.G("conv_caps.beta_u"), self.G("conv_caps.beta_a"), ws, em_state])
+            self.release_deferred()
             # primary caps backward: sigmoid on the activation channels, bias grads, wgrad, dgrad
             ws2 = self.alloc(_act_bwd_ws(caps_in.rows, npose))
             a_sl, da_sl = caps_in.slice(npose, spec.IN_CAPS), dcaps.slice(npose, spec.IN_CAPS)
@@ -867,22 +900,36 @@ class Plan:
             sums = self.alloc(N * 32)
             self.emit(capi.OP_TAIL6_BIAS_SUMS, i=[N, It, Ih, Iw], p=[self.dout, sums])
             dW5 = self.alloc(N * 8 * 128 * SP)
-            self.emit(capi.OP_FILL, p=[dW5], l=[N * 8 * 128 * SP], f=[0.0])
+            Gc = self.alloc(N * 128 * 27 * 32)
             dx, acc = self.grad_for_write(cat112)
+
+            def weight_grads(lane_of):
+                """The tail's weight gradients: per-class wgrads, their map onto the 27x27 combined weights, upsample4 / smooth."""
+                self.emit(capi.OP_FILL, p=[dW5], l=[N * 8 * 128 * SP], f=[0.0])
+                for z, wd in tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld):
+                    self.lane = lane_of(z)
+                    self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, z * 128 * SP)])
+
+            def weight_grads_tail():
+                self.emit(capi.OP_TAIL6_WGRAD_MAP, i=[N, 128], p=[dW5, Gc])
+                self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
+                          p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
+                self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
+            if self.wg_lane:
+                # nothing but the optimiser waits for them: the whole group goes to the weight-gradient lane, and lane 0's join
+                # below only waits for the seven thin border classes' dgrads
+                wl = self.wg_lane
+                self.on_wgrad_lane(lambda: (weight_grads(lambda z: wl), weight_grads_tail()))
             self.fork()
-            for z, wd in tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld):
-                self.lane = 0 if z == 0 else 1 % self.branch_lanes
-                self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, z * 128 * SP)])
+            if not self.wg_lane:
+                weight_grads(lambda z: 0 if z == 0 else 1 % self.branch_lanes)
             for q, (z, dd) in enumerate(tail6.dgrad_descs(N, cat112.thw, 128, dx.ld, acc)):
                 self.lane = 0 if z == 0 else 1 % self.branch_lanes
                 self.conv_op(dd, dcols, off(w5t, z * 128 * SP), dx.ref, alg=F_t6 if q == 0 else 0)
             self.lane = 0
             self.join()
-            Gc = self.alloc(N * 128 * 27 * 32)
-            self.emit(capi.OP_TAIL6_WGRAD_MAP, i=[N, 128], p=[dW5, Gc])
-            self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
-                      p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
-            self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
+            if not self.wg_lane:
+                weight_grads_tail()
         self.tape.append(bwd_smooth)
         return out
 
@@ -919,9 +966,13 @@ class Plan:
     def build_backward(self):
         self.cur = "bwd"
         self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
+        if (self.wg_lane or self.skip_lane) and os.environ.get("PICONS_DEFER_SIDE", "0") != "0":
+            self.deferred = []
         for fn in reversed(self.tape):
             fn()
             self.flush_unprep()
+        self.release_deferred()
+        self.flush_unprep()
         if self.wg_lane or self.skip_lane:
             self.join((1 << self.wg_lane | 1 << self.skip_lane) & ~1)
 
@@ -993,6 +1044,16 @@ class Plan:
             lvl1 = [op[:5] + (0,) for op in lst if not first(op)]
             mask = [(1 << self.lanes) - 2]
             lst[:] = [(capi.OP_FORK, mask, [], [], [], 0)] + lvl0 + [(capi.OP_JOIN, mask, [], [], [], 0)] + lvl1
+        late = self.lists["prep_late"]
+        if late and late[0][0] != capi.OP_FORK:
+            # the skip convs' own weights are laid out on the skip lane, in front of the convs that read them; everything else on the
+            # weight-gradient lane (idle during the forward), joined by the forward list before Mixed_3b
+            mine = set()
+            for nm in ("conv56.weight", "conv112.weight"):
+                if nm in self.kw:
+                    mine |= {self.kw[nm].get("fwd"), self.kw[nm].get("tr")}
+            lane_of = lambda op: self.skip_lane if (self.skip_lane and any(r in mine for r in op[3] if r is not None)) else self.wg_lane
+            late[:] = [(capi.OP_FORK, [(1 << self.wg_lane | 1 << self.skip_lane) & ~1, 0], [], [], [], 0)] + [op[:5] + (lane_of(op),) for op in late]
 
     def resolve(self, bases):
         """-> dict list-name -> numpy array of capi.OP_DTYPE with absolute device pointers."""
@@ -1000,7 +1061,7 @@ class Plan:
         out = {}
         keep = out["_tjobs"] = []          # host job tables of the TRANSPOSE_MULTI ops (the list's owner keeps `out` alive)
         for name, lst in self.lists.items():
-            if name == "prep":
+            if name in ("prep", "prep_late"):
                 lst = self._merge_prep_transposes(lst, bases, keep)
             arr = np.zeros(len(lst), dtype=capi.OP_DTYPE)
             for j, (kind, i, f, p, l, lane) in enumerate(lst):

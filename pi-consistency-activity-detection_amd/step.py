@@ -160,6 +160,7 @@ class StepEngine:
                 # each other's event-timed duration, and the roofline leg wants every kernel's own duration
                 ops.run_ops_timed(arr, timed_kind, side=None, defer=True)    # read after the step's own sync
         run(o["prep"])
+        run(o["prep_late"])        # side lanes only; joined inside the forward list (plan.late_prep)
         run(o["fwd"])
         run(o["loss"])
         if reducer is None or reducer.world == 1:

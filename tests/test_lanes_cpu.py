@@ -110,21 +110,28 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
     p = _plan(lanes)
     assert bool(p.skip_lane) == (lanes >= 3) and bool(p.wg_lane) == (lanes >= 3)
     assert (p.wg_lane != p.skip_lane) == (lanes >= 4) and p.branch_lanes == {2: 2, 3: 2, 4: 2, 5: 3}[lanes]
-    for name in ("fwd", "loss", "bwd", "adam"):
+    assert p.late_prep == (lanes >= 3)
+    # prep_late is enqueued on the side lanes in front of the forward list, which joins it before Mixed_3b: one sequence
+    _check_list(p, p.lists["prep_late"] + p.lists["fwd"], lanes)
+    for name in ("loss", "bwd", "adam"):
         _check_list(p, p.lists[name], lanes)
+    if p.late_prep:
+        assert len(p.lists["prep"]) < 12 < len(p.lists["prep_late"]) and all(op[5] != 0 for op in p.lists["prep_late"][1:])
     branch = (1 << p.branch_lanes) - 2
+    third = branch | (1 << p.wg_lane if p.wg_lane else 0)
+    # one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes; the forward's module
+    # forks include the weight-gradient lane (idle there: the third branch)
+    assert _forks(p, "bwd", branch) == 8 and sum(_forks(p, "fwd", m) for m in {third, branch}) == 8
     for name in ("fwd", "bwd"):
-        # one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes
-        assert _forks(p, name, branch) == 8, name
         if p.skip_lane and p.skip_lane != p.wg_lane:
             assert _forks(p, name, 1 << p.skip_lane) == 2, name          # conv56, conv112
-    if p.skip_lane:
+    if p.skip_lane and p.skip_lane != p.wg_lane:
         on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
         assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4
     if p.wg_lane:
         wg = [op for op in p.lists["bwd"] if op[0] == capi.OP_WGRAD]
         assert sum(1 for op in wg if op[5] == p.wg_lane) >= len(wg) - 16      # all but the merged tail's per-class launches
-        assert not [op for op in p.lists["fwd"] if op[5] == p.wg_lane and p.wg_lane != p.skip_lane]
+        assert sum(1 for op in p.lists["fwd"] if op[5] == p.wg_lane and op[0] == capi.OP_CONV) >= 7
 
 
 def test_side_lanes_can_be_switched_off(monkeypatch):
@@ -136,8 +143,8 @@ def test_side_lanes_can_be_switched_off(monkeypatch):
     monkeypatch.setenv("PICONS_SKIP_LANE", "1"); monkeypatch.setenv("PICONS_WGRAD_LANE", "1"); monkeypatch.setenv("PICONS_WGRAD_SEPARATE", "0")
     q = _plan(4)
     assert q.skip_lane == q.wg_lane == 3 and q.branch_lanes == 3
-    for name in ("fwd", "bwd"):
-        _check_list(q, q.lists[name], 4)
+    _check_list(q, q.lists["prep_late"] + q.lists["fwd"], 4)
+    _check_list(q, q.lists["bwd"], 4)
 
 
 def test_same_ops_as_single_lane_plan():
@@ -156,7 +163,8 @@ def test_same_ops_as_single_lane_plan():
             else:
                 out[(op[0], tuple(op[1]), tuple(op[2]), tuple(op[4]))] += 1
         return out
-    for name in ("prep", "fwd", "loss", "bwd", "adam"):
+    assert strip(p1, p1.lists["prep"] + p1.lists["prep_late"]) == strip(p4, p4.lists["prep"] + p4.lists["prep_late"])
+    for name in ("fwd", "loss", "bwd", "adam"):
         assert strip(p1, p1.lists[name]) == strip(p4, p4.lists[name]), name
     assert all(op[5] == 0 for lst in p1.lists.values() for op in lst)
 
