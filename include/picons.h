@@ -42,6 +42,10 @@ typedef void* pc_stream;            /* hipStream_t */
                                        patch of all samples, so taps that are padding for the whole tile are skipped
                                        (9x9 ConvTranspose / PrimaryCaps dgrad: 784 gathered vs 400 real positions); with groups the
                                        order holds inside each group */
+#define PC_F_TOUT    32             /* channel-major output: out[(n * ldo + co) * (To*Ho*Wo) + position] instead of
+                                       out[(n*To*Ho*Wo + position) * ldo + co].  Plain launches only (no bias / activation / cscale /
+                                       accumulate / BN partials): the merged tail's column GEMMs, whose gather then streams every
+                                       column entry once instead of pulling 4 bytes out of 27 different 512-byte rows */
 
 int         pc_version(void);
 const char* pc_last_error(void);

@@ -56,7 +56,7 @@ TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64)
                        ("C", np.int32), ("sld", np.int32), ("dld", np.int32), ("accum", np.int32)], align=False)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST = 1, 2, 4, 8, 16
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT = 1, 2, 4, 8, 16, 32
 
 _SIGS = {
     "pc_version": (i32, []),

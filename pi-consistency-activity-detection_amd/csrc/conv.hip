@@ -66,6 +66,35 @@ __device__ __forceinline__ bool store_tile_rows(const f32x16 (&acc)[TM][TN], flo
     return true;
 }
 
+// Channel-major output (PC_F_TOUT): the tile goes through LDS like store_tile_rows, but is read back column by column so that
+// a wave writes 64 consecutive positions of ONE output channel (256 contiguous bytes where the tile's rows are consecutive
+// positions).  The 16-byte column groups of a row are XOR-ed with the row so both the accumulator-layout writes (32 consecutive
+// columns of one row per half-wave) and the column reads (32 consecutive rows of one column) hit distinct banks.
+template <int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ __forceinline__ void store_tile_cols(const f32x16 (&acc)[TM][TN], float* T, const int* rout, const int* rinfo, const ConvK& p,
+                                                int n0, int wm, int wn, int lane, int tid) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = wn * (BN / WN) + j * 32 + (lane & 31);
+                T[row * BN + (col ^ (row & 31))] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    const size_t P3 = (size_t)p.To * p.Ho * p.Wo;
+    for (int e = tid; e < BM * BN; e += 256) {
+        const int col = e / BM, row = e % BM;
+        const int op = rout[row];
+        if (op < 0 || n0 + col >= p.Co) continue;
+        const size_t n = (size_t)rinfo[row * 4];
+        p.out[(n * p.ldo + n0 + col) * P3 + ((size_t)op - n * P3)] = T[row * BN + (col ^ (row & 31))];
+    }
+}
+
 template <int BM, int BN, int WM, int WN, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -231,6 +260,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
             if (lane < 32 && col < p.Co) { part[col] = s; part[p.Co + col] = s2; }
         }
     }
+    if (ABL == 0 && (p.flags & PC_F_TOUT)) { store_tile_cols<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, n0, wm, wn, lane, tid); return; }
     if (ABL == 0 && store_tile_rows<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, bbase, n0, wm, wn, lane, tid)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -479,6 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         }
     }
     static_assert(BM * BN <= 2 * (BM + BN) * BK, "output tile fits the operand buffers");
+    if (p.flags & PC_F_TOUT) { store_tile_cols<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, n0, wm, wn, lane, tid); return; }
     if (store_tile_rows<BM, BN, WM, WN, TM, TN>(acc, smem, rout, rinfo, p, bbase, n0, wm, wn, lane, tid)) return;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -630,6 +661,8 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     PC_CHECK_ARG(!(d->flags & PC_F_CSCALE) || cscale, "pc_conv_fwd: cscale flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_BNPART) || bnpart, "pc_conv_fwd: bnpart flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_NFAST) || !(d->flags & (PC_F_BNPART | PC_F_CSCALE)), "pc_conv_fwd: NFAST cannot be combined with BN partials / cscale");
+    PC_CHECK_ARG(!(d->flags & PC_F_TOUT) || (!(d->flags & (PC_F_BNPART | PC_F_CSCALE | PC_F_BIAS | PC_F_ACCUM | PC_F_NFAST)) && d->act == PC_ACT_NONE),
+                 "pc_conv_fwd: channel-major output (PC_F_TOUT) is for plain launches only");
     PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)w % 16 == 0), "pc_conv_fwd: in/w must be 16-byte aligned");
     ConvK k;
     k.in = in; k.w = w; k.bias = bias; k.cscale = cscale; k.out = out; k.bnpart = bnpart;

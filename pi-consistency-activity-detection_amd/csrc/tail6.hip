@@ -10,6 +10,7 @@
 // Backward is the transposed pair: scatter dout into dcols, two GEMMs per class (dx, dW5), and the map of dW5 back onto
 // the 27x27 combined weights the existing pc_tail_grads consumes.  This file holds the small kernels around those GEMMs.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -66,7 +67,10 @@ __device__ __forceinline__ int dim_terms(int o, int I, int (&ii)[3], int (&kk)[3
     return n;
 }
 
-// out[n][o] = bsm + sum_{ks: o + 1 - ks in grid} bc[n][ks] + sum_terms cols[n][i][slot]
+// out[n][o] = bsm + sum_{ks: o + 1 - ks in grid} bc[n][ks] + sum_terms colsT[n][slot][i]
+// colsT is channel-major (the column GEMMs run with PC_F_TOUT): [n][128 slots][It][Ih][Iw].  Every (i, slot) entry lands on exactly
+// one output voxel, and for a fixed slot consecutive outputs of one w parity read consecutive iw: the gather streams the 411 MB
+// once (row-major columns cost 5x that: 4 bytes out of each of 27 different 512-byte rows per output).
 __global__ __launch_bounds__(256) void tail6_gather_kernel(const float* __restrict__ cols, const float* __restrict__ bc, const float* __restrict__ bsm,
                                                            int N, int It, int Ih, int Iw, float* __restrict__ out) {
     const int Ot = 2 * It, Oh = 2 * Ih, Ow = 2 * Iw;
@@ -90,12 +94,84 @@ __global__ __launch_bounds__(256) void tail6_gather_kernel(const float* __restri
             }
         }
     }
+    const size_t P3 = (size_t)It * Ih * Iw;
+    const float* base = cols + (size_t)n * SP * P3;
     for (int a = 0; a < nt; ++a)
         for (int b = 0; b < nh; ++b) {
-            const float* row = cols + ((((size_t)n * It + it[a]) * Ih + ih[b]) * Iw) * SP + (kt[a] * 5 + kh[b]) * 5;
-            for (int c = 0; c < nw; ++c) acc += row[(size_t)iw[c] * SP + kw[c]];
+            const size_t pos = ((size_t)it[a] * Ih + ih[b]) * Iw;
+            const int slot0 = (kt[a] * 5 + kh[b]) * 5;
+            for (int c = 0; c < nw; ++c) acc += base[(size_t)(slot0 + kw[c]) * P3 + pos + iw[c]];
         }
     out[idx] = acc;
+}
+
+// The same gather with uniform control flow: a launch handles ONE parity class of (ot, oh), a thread the output pair
+// (ow = 2 qw, 2 qw + 1) of one (n, ot, oh) row, so the term lists are compile-time (3 x 3 / 3 x 2 / 2 x 3 / 2 x 2 (t, h) pairs, five w
+// loads each), every load of a wave reads consecutive iw of one slot plane, out-of-range inputs are clamped loads times zero, and
+// the two outputs leave as one 8-byte store.  o even: (i, k5) = (o/2 + 1, 0), (o/2, 2), (o/2 - 1, 4); o odd: ((o+1)/2, 1), ((o-1)/2, 3).
+template <int PT, int PH>
+__global__ __launch_bounds__(128) void tail6_gather_rows_kernel(const float* __restrict__ cols, const float* __restrict__ bc, const float* __restrict__ bsm,
+                                                                int N, int It, int Ih, int Iw, float* __restrict__ out) {
+    __shared__ float sbc[28];
+    const int Ot = 2 * It, Oh = 2 * Ih, Ow = 2 * Iw;
+    int row = blockIdx.x;                                   // (n, qt, qh)
+    const int qh = row % Ih; row /= Ih;
+    const int qt = row % It; const int n = row / It;
+    const int ot = 2 * qt + PT, oh = 2 * qh + PH;
+    if (threadIdx.x < 27) sbc[threadIdx.x] = bc[n * J32 + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int e = 0; e < 27; ++e) t += sbc[e]; sbc[27] = t; }
+    __syncthreads();
+    constexpr int NT = PT ? 2 : 3, NH = PH ? 2 : 3;
+    const size_t P3 = (size_t)It * Ih * Iw;
+    const float* base = cols + (size_t)n * SP * P3;
+    const bool tb = ot == 0 || ot == Ot - 1, hb = oh == 0 || oh == Oh - 1;
+    for (int qw = threadIdx.x; qw < Iw; qw += 128) {
+        float acc0 = 0.f, acc1 = 0.f;                       // ow = 2 qw, 2 qw + 1
+        const int iwp = qw + 1 < Iw ? qw + 1 : qw, iwm = qw >= 1 ? qw - 1 : 0;
+        const float fwp = qw + 1 < Iw ? 1.f : 0.f, fwm = qw >= 1 ? 1.f : 0.f;
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int it_ = PT ? qt + 1 - a : qt + 1 - a, kt = PT ? 1 + 2 * a : 2 * a;
+            const bool vt = it_ >= 0 && it_ < It;
+            const int itc = vt ? it_ : 0;
+#pragma unroll
+            for (int b = 0; b < NH; ++b) {
+                const int ih_ = qh + 1 - b, kh = PH ? 1 + 2 * b : 2 * b;
+                const bool vh = ih_ >= 0 && ih_ < Ih;
+                const int ihc = vh ? ih_ : 0;
+                const float f = (vt && vh) ? 1.f : 0.f;
+                const float* pl = base + (size_t)((kt * 5 + kh) * 5) * P3 + ((size_t)itc * Ih + ihc) * Iw;
+                const float e0 = pl[iwp], e2 = pl[2 * P3 + qw], e4 = pl[4 * P3 + iwm];          // even ow: k5w = 0, 2, 4
+                const float o1 = pl[P3 + iwp], o3 = pl[3 * P3 + qw];                                // odd ow: k5w = 1, 3
+                acc0 += f * ((fwp * e0 + e2) + fwm * e4);
+                acc1 += f * (fwp * o1 + o3);
+            }
+        }
+        // bias terms: every (kt, kh, kw) of `smooth` whose intermediate voxel o + 1 - k exists; all 27 away from the borders
+        float b0, b1;
+        const bool w0b = qw == 0, w1b = qw == Iw - 1;
+        if (!tb && !hb && !w0b && !w1b) { b0 = b1 = sbc[27]; }
+        else {
+            b0 = b1 = 0.f;
+            for (int a = 0; a < 3; ++a) {
+                const int mt = ot + 1 - a;
+                if (mt < 0 || mt >= Ot) continue;
+                for (int b = 0; b < 3; ++b) {
+                    const int mh = oh + 1 - b;
+                    if (mh < 0 || mh >= Oh) continue;
+                    for (int c = 0; c < 3; ++c) {
+                        const int m0 = 2 * qw + 1 - c, m1 = 2 * qw + 2 - c;
+                        const float v = sbc[(a * 3 + b) * 3 + c];
+                        if (m0 >= 0 && m0 < Ow) b0 += v;
+                        if (m1 >= 0 && m1 < Ow) b1 += v;
+                    }
+                }
+            }
+        }
+        const float bs = bsm[0];
+        *(float2*)(out + (((size_t)n * Ot + ot) * Oh + oh) * Ow + 2 * qw) = make_float2(bs + b0 + acc0, bs + b1 + acc1);
+    }
 }
 
 // dcols[n][i][slot] = dout[n][2i - 2 + k5] where that output exists, else 0
@@ -191,7 +267,16 @@ extern "C" int pc_tail6_gather(const float* cols, const float* bc, const float* 
     PC_CHECK_ARG(cols && bc && bsm && out && N >= 1 && It >= 1 && Ih >= 1 && Iw >= 1, "pc_tail6_gather: bad args");
     const int64_t total = (int64_t)N * 8 * It * Ih * Iw;
     PC_CHECK_ARG((total + 255) / 256 < (1ll << 31), "pc_tail6_gather: too large");
-    hipLaunchKernelGGL(tail6_gather_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+    static const int rows_env = getenv("PICONS_TAIL6_GATHER_ROWS") ? atoi(getenv("PICONS_TAIL6_GATHER_ROWS")) : 1;
+    if (rows_env && ((uintptr_t)out & 7) == 0) {
+        const dim3 grid((unsigned)((int64_t)N * It * Ih));
+        hipLaunchKernelGGL((tail6_gather_rows_kernel<0, 0>), grid, dim3(128), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+        hipLaunchKernelGGL((tail6_gather_rows_kernel<0, 1>), grid, dim3(128), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+        hipLaunchKernelGGL((tail6_gather_rows_kernel<1, 0>), grid, dim3(128), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+        hipLaunchKernelGGL((tail6_gather_rows_kernel<1, 1>), grid, dim3(128), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+    } else {
+        hipLaunchKernelGGL(tail6_gather_kernel, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, (hipStream_t)s, cols, bc, bsm, N, It, Ih, Iw, out);
+    }
     PC_CHECK_LAUNCH("tail6_gather");
     return PC_OK;
 }

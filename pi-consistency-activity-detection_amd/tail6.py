@@ -27,8 +27,10 @@ def _sub(d, start, ext):
 
 
 def conv_descs(N, thw, Ci, ldx):
-    """cols[n][i][:] = x[n][i][:] . W5f[n][z]: [(z, desc)], weights at W5f + z*SP*Ci, per-sample stride 8*SP*Ci."""
-    base = D.conv_fwd(N, thw, Ci, ldx, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, groups=N)
+    """colsT[n][:][i] = x[n][i][:] . W5f[n][z], written channel-major ([n][slot][position], PC_F_TOUT) for the streaming gather:
+    [(z, desc)], weights at W5f + z*SP*Ci, per-sample stride 8*SP*Ci."""
+    from . import capi
+    base = D.conv_fwd(N, thw, Ci, ldx, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0), thw, flags=capi.F_TOUT, groups=N)
     base["wgstride"] = 8 * SP * Ci
     base["Co_real"] = NSLOT
     return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
