@@ -103,6 +103,15 @@ typedef struct pc_wgrad_desc {
                                      * [N][Td][Hd][Wd][ldd] tensor (with nbatch > 1: per problem, N = 1 each) */
 } pc_wgrad_desc;
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
+/* Several weight gradients in one call (the wgrads of one Inception module; the eight position classes of the merged tail):
+ * the problems the generic split-K kernel would take share ONE grid, each with a range of blocks in proportion to its work; the
+ * others (stem, row-segment, long-K shapes) get their usual launch.  Same results as njobs pc_conv_wgrad calls up to the order
+ * of the fp32 atomic sums.  `jobs` is host memory. */
+typedef struct pc_wgrad_job {
+    pc_wgrad_desc d;
+    const float* D; const float* S; float* g;
+} pc_wgrad_job;
+int pc_conv_wgrad_multi(const pc_wgrad_job* jobs, int njobs, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * BatchNorm3d(train) + ReLU (pytorch_i3d.py:116-119; eps 1e-3, momentum 0.01 at :80).
@@ -379,8 +388,9 @@ enum {
     PC_OP_TAIL6_WGRAD_MAP,          /* i = N, Ci; p = dW5, Gc */
     PC_OP_TAIL6_BIAS_SUMS,          /* i = N, It, Ih, Iw; p = dout, sums */
     PC_OP_TRANSPOSE_MULTI,          /* p[0] = HOST pointer to pc_transpose_job[i[0]] (kept alive by the owner of the list) */
-    PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued on lane 0 so far */
+    PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued so far on lane i[1] (0 by default) */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
+    PC_OP_WGRAD_MULTI,              /* p[0] = HOST pointer to pc_wgrad_job[i[0]] (kept alive by the owner of the list): pc_conv_wgrad_multi */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

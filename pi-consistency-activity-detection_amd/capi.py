@@ -48,8 +48,11 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
  OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN) = range(1, 42)
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI) = range(1, 43)
 MAX_LANES = 8
+
+# numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 40 int32, then D, S, g)
+WJOB_DTYPE = np.dtype([("d", np.int32, 40), ("D", np.uint64), ("S", np.uint64), ("g", np.uint64)], align=False)
 
 # numpy mirror of struct pc_transpose_job
 TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64), ("dbs", np.int64), ("batch", np.int32), ("R", np.int32),
@@ -64,6 +67,7 @@ _SIGS = {
     "pc_conv_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "pc_conv_bnpart_rows": (i32, [C.POINTER(ConvDesc)]),
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
+    "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
     "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),
@@ -135,6 +139,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         assert C.sizeof(ConvDesc) == 48 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
+        assert C.sizeof(WgradDesc) == 160 and WJOB_DTYPE.itemsize == 184
         _lib = L
     return _lib
 

@@ -131,6 +131,8 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_tail6_bias_sums(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         case PC_OP_TRANSPOSE_MULTI:
             return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
+        case PC_OP_WGRAD_MULTI:
+            return pc_conv_wgrad_multi(P(const pc_wgrad_job*, 0), op.i[0], s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

@@ -5,6 +5,8 @@
 // Replaces the ATen/cuDNN convolution call sites listed in SURVEY.md §2a (K1, K6, K9-K12).
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 namespace {
 
@@ -722,8 +724,8 @@ struct WgK {
     int mt, ntl;                     // tiles along Cd and along the columns; the grid is 1-D: mt * ntl * problems * slices blocks
 };
 
-template <int BM, int BN, int ABL = 0, int KB = 32>
-__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
+template <int BM, int BN, int ABL, int KB>
+__device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     constexpr int BK = KB;                           // positions per chunk (shadows the file-level BK)
     constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
     static_assert(TM >= 1 && TN >= 1, "tile");
@@ -734,9 +736,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    // XCD-aware order: the blocks of one K slice (every tile reads the same rows of D, and overlapping rows of S) get
-    // consecutive logical ids, i.e. run on one XCD and share its L2
-    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    // lid: logical block id of this problem (XCD-aware order: the blocks of one K slice -- every tile reads the same rows of D, and
+    // overlapping rows of S -- get consecutive ids, i.e. run on one XCD and share its L2)
     const int tiles = p.mt * p.ntl, tile = lid % tiles, bz = lid / tiles;
     const int m0 = p.mbase + (tile % p.mt) * BM, n0 = (tile / p.mt) * BN;
     // bz = problem * nsplit + K slice
@@ -861,6 +862,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
                 }
             }
         }
+}
+
+template <int BM, int BN, int ABL = 0, int KB = 32>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
+    wgrad_body<BM, BN, ABL, KB>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+
+// Several weight-gradient problems in ONE grid (pc_conv_wgrad_multi): the wgrads of one Inception module, or the eight position
+// classes of the merged tail.  Each problem keeps its own descriptor (by value in the kernel arguments) and a contiguous range of
+// blocks sized in proportion to its work, so split-K fills the chip once per group instead of once per layer: fewer, longer K
+// slices (a slice's 64 KB of atomics buy 4x the FLOPs) and no 30-microsecond launches for 1 GFLOP of work.
+constexpr int WG_MAXJOBS = 8;
+struct WgMulti { int njobs; int first[WG_MAXJOBS + 1]; WgK job[WG_MAXJOBS]; };
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256, 2) void wgrad_multi_kernel(const WgMulti m) {
+    int j = 0;
+    const int bid = blockIdx.x;
+    while (j + 1 < m.njobs && bid >= m.first[j + 1]) ++j;
+    wgrad_body<BM, BN, 0, 32>(m.job[j], xcd_remap(bid - m.first[j], m.first[j + 1] - m.first[j]));
 }
 
 
@@ -1264,5 +1285,109 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     else if (pad128 > 1.15 * pad64) launch(0, d->Cd, true);
     else launch(0, d->Cd, false);
     PC_CHECK_LAUNCH("wgrad_kernel");
+    return PC_OK;
+}
+
+
+// ---- several weight-gradient problems in one launch ------------------------------------------------------------------------
+namespace {
+
+// the problems pc_conv_wgrad would give to the generic split-K kernel (not the stem / row-segment kernels, not a forced split)
+bool wg_is_generic(const pc_wgrad_desc* d) {
+    if (getenv("PICONS_WGRAD_ABLATE")) return false;
+    const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
+    const bool stem = d->Cs == 4 && d->KW == 7;
+    const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
+    const bool row3 = d->KW == 3 && padw == 1 && d->Wq == d->Ws && (csb64 || csb32) && d->Ws % 28 == 0 && nprob == 1 && d->splitk >= 0;
+    const bool row9 = d->KW == 9 && padw == 0 && d->Wq == d->Ws - 8 && d->Wq == 20 && csb64 && d->Tq == 1 && d->Hq == 1;
+    const bool rowseg = d->Td == 0 && d->ntap[2] == d->KW && d->wk0[2] == 0 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 &&
+                        (row3 || row9);
+    const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+    const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+    const bool wide = Ntot >= 512 && P >= 65536;          // long-K launches keep their 256-column tiles
+    return !stem && !rowseg && !wide && d->splitk == 0;
+}
+
+int wg_fill(const pc_wgrad_desc* d, const float* D, const float* S, float* g, WgK& k) {
+    PC_CHECK_ARG(d && D && S && g, "pc_conv_wgrad_multi: null pointer");
+    PC_CHECK_ARG(d->Cd >= 1 && d->Cs >= 4 && d->Cs % 4 == 0 && d->ldd % 4 == 0 && d->lds % 4 == 0, "pc_conv_wgrad_multi: channel counts / strides must be multiples of 4");
+    PC_CHECK_ARG(((uintptr_t)D % 16 == 0) && ((uintptr_t)S % 16 == 0), "pc_conv_wgrad_multi: D/S must be 16-byte aligned");
+    PC_CHECK_ARG(d->wk0[0] + d->ntap[0] <= d->KT && d->wk0[1] + d->ntap[1] <= d->KH && d->wk0[2] + d->ntap[2] <= d->KW, "pc_conv_wgrad_multi: trimmed taps exceed the weight extents");
+    k.D = D; k.S = S; k.g = g;
+    k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
+    k.Ts = d->Ts; k.Hs = d->Hs; k.Ws = d->Ws; k.Cs = d->Cs; k.lds = d->lds;
+    for (int i = 0; i < 3; ++i) { k.istr[i] = d->istr[i]; k.ntap[i] = d->ntap[i]; k.ioff0[i] = d->ioff0[i]; k.istep[i] = d->istep[i]; k.wk0[i] = d->wk0[i]; k.doff[i] = d->doff[i]; }
+    k.KH = d->KH; k.KW = d->KW; k.NtotFull = d->KT * d->KH * d->KW * d->Cs;
+    k.dlat = d->Td > 0; k.Td = d->Td; k.Hd = d->Hd; k.Wd = d->Wd;
+    const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+    PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad_multi: position count out of range");
+    PC_CHECK_ARG(!k.dlat || (int64_t)d->N * d->Td * d->Hd * d->Wd < (1ll << 31), "pc_conv_wgrad_multi: D tensor too large");
+    k.P = (int)P;
+    k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+    k.nchunks = cdiv(P, 32);
+    k.mbase = 0; k.mend = d->Cd; k.store = 0;
+    const int nb = d->nbatch > 1 ? d->nbatch : 1;
+    k.dbs = nb > 1 ? d->dbstride : 0; k.sbs = nb > 1 ? d->sbstride : 0; k.gbs = nb > 1 ? d->gbstride : 0;
+    return PC_OK;
+}
+
+}  // namespace
+
+extern "C" int pc_conv_wgrad_multi(const pc_wgrad_job* jobs, int njobs, pc_stream s_) {
+    hipStream_t s = (hipStream_t)s_;
+    PC_CHECK_ARG(jobs && njobs >= 1 && njobs <= 64, "pc_conv_wgrad_multi: jobs=%p njobs=%d (1..64)", (const void*)jobs, njobs);
+    static const int multi_env = getenv("PICONS_WGRAD_MULTI") ? atoi(getenv("PICONS_WGRAD_MULTI")) : 1;
+    std::vector<int> gen;
+    for (int j = 0; j < njobs; ++j) {
+        if (multi_env && wg_is_generic(&jobs[j].d)) { gen.push_back(j); continue; }
+        const int rc = pc_conv_wgrad(&jobs[j].d, jobs[j].D, jobs[j].S, jobs[j].g, s_);      // stem / row-segment / long-K problems: own launch
+        if (rc != PC_OK) return rc;
+    }
+    for (size_t g0 = 0; g0 < gen.size(); g0 += WG_MAXJOBS) {
+        const int n = (int)std::min<size_t>(WG_MAXJOBS, gen.size() - g0);
+        if (n == 1) {
+            const pc_wgrad_job& q = jobs[gen[g0]];
+            const int rc = pc_conv_wgrad(&q.d, q.D, q.S, q.g, s_);
+            if (rc != PC_OK) return rc;
+            continue;
+        }
+        WgMulti m;
+        m.njobs = n;
+        // 64- or 128-row tiles for the whole group: whichever pads less (64-row tiles run at ~0.88 of the 128-row rate)
+        double work[2] = {0, 0};
+        for (int j = 0; j < n; ++j) {
+            const pc_wgrad_desc& d = jobs[gen[g0 + j]].d;
+            const double cols = (double)cdiv(d.ntap[0] * d.ntap[1] * d.ntap[2] * d.Cs, 128) * 128, P = (double)d.N * d.Tq * d.Hq * d.Wq * (d.nbatch > 1 ? d.nbatch : 1);
+            work[0] += (double)cdiv(d.Cd, 64) * 64 * cols * P;
+            work[1] += (double)cdiv(d.Cd, 128) * 128 * cols * P;
+        }
+        const bool small_m = work[0] < 0.88 * work[1];
+        const int bm = small_m ? 64 : 128, slots = small_m ? 768 : 512;
+        const double total = work[small_m ? 0 : 1];
+        int first = 0;
+        for (int j = 0; j < n; ++j) {
+            const pc_wgrad_job& q = jobs[gen[g0 + j]];
+            WgK& k = m.job[j];
+            const int rc = wg_fill(&q.d, q.D, q.S, q.g, k);
+            if (rc != PC_OK) return rc;
+            const int nb = q.d.nbatch > 1 ? q.d.nbatch : 1;
+            k.mt = cdiv(q.d.Cd, bm); k.ntl = cdiv(k.Ntot, 128);
+            const int64_t tiles = (int64_t)k.mt * k.ntl * nb;
+            // blocks in proportion to the problem's (padded) work: every block of the grid gets about the same number of chunks
+            const double w = (double)k.mt * bm * k.ntl * 128 * (double)k.P * nb;
+            int splitk = (int)(slots * (w / total) / (double)tiles + 0.5);
+            const int maxsplit = k.nchunks / 8 > 0 ? k.nchunks / 8 : 1;
+            if (splitk > maxsplit) splitk = maxsplit;
+            if (splitk < 1) splitk = 1;
+            k.chunks_per_split = cdiv(k.nchunks, splitk);
+            k.nsplit = cdiv(k.nchunks, k.chunks_per_split);
+            m.first[j] = first;
+            first += (int)(tiles * k.nsplit);
+        }
+        for (int j = n; j <= WG_MAXJOBS; ++j) m.first[j] = first;
+        if (small_m) hipLaunchKernelGGL((wgrad_multi_kernel<64, 128>), dim3((unsigned)first), dim3(256), 0, s, m);
+        else hipLaunchKernelGGL((wgrad_multi_kernel<128, 128>), dim3((unsigned)first), dim3(256), 0, s, m);
+        PC_CHECK_LAUNCH("wgrad_multi_kernel");
+    }
     return PC_OK;
 }

@@ -49,6 +49,23 @@ def conv_wgrad(d, Dt, St, g):
     return g
 
 
+def wgrad_job_table(jobs):
+    """[(desc dict, D ptr, S ptr, g ptr)] with integer device addresses -> host array of pc_wgrad_job."""
+    tab = np.zeros(len(jobs), dtype=capi.WJOB_DTYPE)
+    for q, (d, Dp, Sp, gp) in enumerate(jobs):
+        tab[q]["d"][:] = D.flatten(d, D.WGRAD_FIELDS)
+        tab[q]["D"], tab[q]["S"], tab[q]["g"] = Dp, Sp, gp
+    return tab
+
+
+def conv_wgrad_multi(jobs):
+    """jobs: [(desc dict, D tensor, S tensor, g tensor)]: pc_conv_wgrad_multi (one grid for the generic split-K problems)."""
+    tab = wgrad_job_table([(d, Dt.data_ptr(), St.data_ptr(), g.data_ptr()) for d, Dt, St, g in jobs])
+    for _d, Dt, St, g in jobs:
+        ptr(Dt); ptr(St); ptr(g)
+    capi.call("pc_conv_wgrad_multi", C.c_void_p(tab.ctypes.data), len(jobs), stream())
+
+
 def bn_finalize(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean=None, rvar=None):
     stat = torch.empty(groups, 4, C_, device=part.device, dtype=torch.float32)
     capi.call("pc_bn_finalize", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),

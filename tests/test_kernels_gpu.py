@@ -765,3 +765,41 @@ def test_full_correlation_as_gemm_plus_col2im():
     close(dx.permute(0, 3, 1, 2).cpu(), x.grad, what="col2im dgrad")
     capi.call("pc_col2im", ops.ptr(cols), N, Ho, Ho, K, K, Ci, ops.ptr(dx), Ci, 1, ops.stream())
     close(dx.permute(0, 3, 1, 2).cpu(), 2 * x.grad, what="col2im accumulate")
+
+
+def test_wgrad_multi_matches_individual_launches():
+    """pc_conv_wgrad_multi: the wgrads of an Inception-module-like group (1x1x1 and 1x3x3 problems of different channel counts, one
+    of them a row-segment shape that keeps its own launch, one batched sub-lattice problem like the merged tail's classes) in one
+    call against pc_conv_wgrad per problem: same gradients up to the order of the fp32 atomic sums."""
+    g = torch.Generator().manual_seed(21)
+    N, thw = 4, (1, 28, 28)
+    jobs, refs = [], []
+    for Cd, Cs, k in [(96, 48, (1, 1, 1)), (72, 16, (1, 3, 3)), (208, 96, (1, 3, 3)), (64, 112, (1, 1, 1)), (40, 24, (1, 3, 3))]:
+        pad = tuple(x // 2 for x in k)
+        Dt = torch.randn(N, *thw, Cd, generator=g).to(DEV); St = torch.randn(N, *thw, Cs, generator=g).to(DEV)
+        d = desc.trim_wgrad(desc.wgrad(N, thw, Cd, Cd, thw, Cs, Cs, k, (1, 1, 1), pad))
+        g1 = torch.zeros(Cd, k[0] * k[1] * k[2], Cs, device=DEV); g2 = torch.zeros_like(g1)
+        ops.conv_wgrad(d, Dt, St, g1)
+        jobs.append((d, Dt, St, g2)); refs.append(g1)
+    # a batched sub-lattice problem (nbatch = N, D = positions (1.., 1..) of a larger tensor), as the merged tail's classes are
+    Cd, Cs, I = 32, 128, (2, 6, 6)
+    X = torch.randn(N, *I, Cd, generator=g).to(DEV); Y = torch.randn(N, *I, Cs, generator=g).to(DEV)
+    per = I[0] * I[1] * I[2]
+    d = desc.wgrad(1, (1, 5, 5), Cd, Cd, I, Cs, Cs, (1, 1, 1), (1, 1, 1), (0, 0, 0))
+    d.update(ioff0=[1, 1, 1], Td=I[0], Hd=I[1], Wd=I[2], doff=[1, 1, 1], nbatch=N, dbstride=per * Cd, sbstride=per * Cs, gbstride=Cd * Cs)
+    g1 = torch.zeros(N, Cd, 1, Cs, device=DEV); g2 = torch.zeros_like(g1)
+    ops.conv_wgrad(d, X, Y, g1)
+    jobs.append((d, X, Y, g2)); refs.append(g1)
+    ops.conv_wgrad_multi(jobs)
+    for (d, _a, _b, got), want in zip(jobs, refs):
+        assert want.abs().max().item() > 0
+        rel = ((got - want).norm() / want.norm()).item()
+        assert rel < 2e-6, (d["Cd"], d["Cs"], rel)
+    # and against torch for one of them
+    d, Dt, St, got = jobs[2]
+    x = St.permute(0, 4, 1, 2, 3).contiguous().requires_grad_(False)
+    w = torch.zeros(208, 96, 1, 3, 3, device=DEV, requires_grad=True)
+    y = torch.nn.functional.conv3d(x, w, padding=(0, 1, 1))
+    y.backward(Dt.permute(0, 4, 1, 2, 3).contiguous())
+    want = w.grad.permute(0, 2, 3, 4, 1).reshape(208, 9, 96)
+    assert ((got - want).norm() / want.norm()).item() < 1e-5

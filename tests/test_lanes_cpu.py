@@ -55,6 +55,10 @@ def _accesses(p, op):
         for job in p.multi_jobs[ptrs[0][1]]:
             out += [(job[3][0], False), (job[3][1], True)]
         return out
+    if kind == capi.OP_WGRAD_MULTI:
+        for _d, refs in p.wjobs[ptrs[0][1]]:
+            out += [(refs[0], False), (refs[1], False), (refs[2], True)]
+        return out
     assert kind in WRITES, "op kind %d has no write map" % kind
     for q, r in enumerate(ptrs):
         if r is None:
@@ -129,9 +133,18 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
         on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
         assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4
     if p.wg_lane:
-        wg = [op for op in p.lists["bwd"] if op[0] == capi.OP_WGRAD]
-        assert sum(1 for op in wg if op[5] == p.wg_lane) >= len(wg) - 16      # all but the merged tail's per-class launches
+        wg = [op for op in p.lists["bwd"] if op[0] in (capi.OP_WGRAD, capi.OP_WGRAD_MULTI)]
+        assert all(op[5] == p.wg_lane for op in wg)
+        assert not any(op[0] == capi.OP_WGRAD_MULTI for op in wg)          # grouped launches are opt-in (PICONS_WGRAD_MULTI*)
         assert sum(1 for op in p.lists["fwd"] if op[5] == p.wg_lane and op[0] == capi.OP_CONV) >= 7
+
+
+def test_inception_wgrads_as_grouped_launches(monkeypatch):
+    monkeypatch.setenv("PICONS_WGRAD_MULTI", "1"); monkeypatch.setenv("PICONS_WGRAD_MULTI_TAIL", "1")
+    p = _plan(4)
+    _check_list(p, p.lists["bwd"], 4)
+    assert sorted(len(j) for j in p.wjobs) == [4] * 7 + [8]
+    assert sum(1 for op in p.lists["bwd"] if op[0] == capi.OP_WGRAD_MULTI) == 8
 
 
 def test_side_lanes_can_be_switched_off(monkeypatch):
@@ -160,6 +173,10 @@ def test_same_ops_as_single_lane_plan():
             if op[0] == capi.OP_TRANSPOSE_MULTI:
                 for job in p.multi_jobs[op[3][0][1]]:
                     out[(capi.OP_TRANSPOSE, tuple(job[1]), tuple(job[2]), tuple(job[4]))] += 1
+            elif op[0] == capi.OP_WGRAD_MULTI:
+                from picons_amd import desc as D
+                for wd, _refs in p.wjobs[op[3][0][1]]:
+                    out[(capi.OP_WGRAD, tuple(D.flatten(wd, D.WGRAD_FIELDS)), (), ())] += 1
             else:
                 out[(op[0], tuple(op[1]), tuple(op[2]), tuple(op[4]))] += 1
         return out
