@@ -310,10 +310,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int AR = BM / 32, BR = BN / 32;
     static_assert(WM * WN == 4 && TM >= 1 && TN >= 1, "4 waves");
+    // VAR bits 3-4: LDS-DMA ring of 2 + n stages instead of the double buffer.  With one chunk in flight a block waits out the
+    // full latency of every tile fetch that misses its XCD's L2 (the activations were just written by a kernel on other XCDs)
+    // unless a second resident block covers it -- which the under-filled 28x28 launches (392 blocks on 512 slots) do not have.
+    constexpr int ST = 2 + ((VAR >> 3) & 3);
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                          // [2][BM][32]
-    float* Bs = smem + 2 * BM * BK;            // [2][BN][32]
-    int* rinfo = (int*)(Bs + 2 * BN * BK);     // [BM][4] n,t0,h0,w0
+    float* As = smem;                          // [ST][BM][32]
+    float* Bs = smem + ST * BM * BK;           // [ST][BN][32]
+    int* rinfo = (int*)(Bs + ST * BN * BK);    // [BM][4] n,t0,h0,w0
     int* rout = rinfo + BM * 4;                // [BM] output position index or -1
     unsigned* tile_or = (unsigned*)(rout + BM);   // OR of every row's tap-validity mask
 
@@ -457,8 +461,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nchunks = TAP4 ? ((a_hi - a_lo + 1) * nb_ * nc_ + 7) / 8 : (a_hi - a_lo + 1) * nb_ * nc_ * (p.Ci / BK);
-    if (nchunks > 0) fetch(0);
-    __syncthreads();
     const int arow = wm * (BM / WM) + (lane & 31), brow = wn * (BN / WN) + (lane & 31);
     const int kh = lane >> 5;
     int aoff[TM], boff[TN], asw[TM], bsw[TN];
@@ -466,9 +468,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     for (int i = 0; i < TM; ++i) { const int r = arow + i * 32; aoff[i] = r * BK; asw[i] = (r >> 1) & 7; }
 #pragma unroll
     for (int j = 0; j < TN; ++j) { const int r = brow + j * 32; boff[j] = r * BK; bsw[j] = (r >> 1) & 7; }
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-        if (!(VAR & 2) && c + 1 < nchunks) fetch(buf ^ 1);
+    auto mma_chunk = [&](int buf, int c) {
         const float* a = As + buf * BM * BK;
         const float* b = Bs + buf * BN * BK;
 #pragma unroll
@@ -488,9 +488,34 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
             if (VAR & 1) __builtin_amdgcn_s_setprio(0);
-            if ((VAR & 2) && ks == 0 && c + 1 < nchunks) fetch(buf ^ 1);   // issue the next tile's DMA behind the first MFMA group
+            if (ST == 2 && (VAR & 2) && ks == 0 && c + 1 < nchunks) fetch(buf ^ 1);   // issue the next tile's DMA behind the first MFMA group
         }
-        __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
+    };
+    if constexpr (ST == 2) {
+        if (nchunks > 0) fetch(0);
+        __syncthreads();
+        for (int c = 0; c < nchunks; ++c) {
+            const int buf = c & 1;
+            if (!(VAR & 2) && c + 1 < nchunks) fetch(buf ^ 1);
+            mma_chunk(buf, c);
+            __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
+        }
+    } else {
+        // ring: chunks c .. c+ST-2 in flight while chunk c is multiplied.  Each thread issues AR + BR DMA pieces per chunk, in order,
+        // so "chunk c has landed" is vmcnt <= (chunks issued after c) * (AR + BR) for every wave, then the barrier (which also says
+        // every wave is done reading the buffer the next fetch overwrites: the one multiplied in the previous iteration).
+        constexpr int PIECES = AR + BR;
+        for (int c = 0; c < ST - 1 && c < nchunks; ++c) fetch(c);
+        int buf = 0, fbuf = (ST - 1) % ST;
+        for (int c = 0; c < nchunks; ++c) {
+            if (nchunks - 1 - c >= ST - 2) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"((ST - 2) * PIECES) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            if (c + ST - 1 < nchunks) fetch(fbuf);
+            mma_chunk(buf, c);
+            buf = buf + 1 == ST ? 0 : buf + 1;
+            fbuf = fbuf + 1 == ST ? 0 : fbuf + 1;
+        }
+        __syncthreads();          // the operand ring is reused as the output staging tile
     }
 
     // ---- epilogue (same as conv_gemm_kernel)
@@ -543,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 template <int BM, int BN, int WM, int WN, int VAR>
 int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
-    const size_t lds = (size_t)(2 * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
+    constexpr int ST = 2 + ((VAR >> 3) & 3);
+    const size_t lds = (size_t)(ST * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         attr_set = true;
@@ -564,6 +590,17 @@ int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
 template <int BM, int BN, int WM, int WN>
 int launch_conv_glds(const ConvK& k, hipStream_t s) {
     static const int var = getenv("PICONS_CONV_VARIANT") ? atoi(getenv("PICONS_CONV_VARIANT")) : CONV_DEFAULT_VARIANT;
+    // LDS-DMA ring depth.  Default: 3 stages for launches of at most one block per CU (the 196-block 28x28 layers: 10-25 % faster --
+    // nothing else on the CU covers the latency of a tile fetch that misses L2), the double buffer otherwise (a ring costs full
+    // launches 5-8 %).  PICONS_CONV_STAGES=2|3|4 forces a depth where two blocks of it still fit a CU.
+    static const int stages = getenv("PICONS_CONV_STAGES") ? atoi(getenv("PICONS_CONV_STAGES")) : 0;
+    if constexpr (BM * BN <= 128 * 64) {
+        const size_t per_stage = (size_t)(BM + BN) * BK * sizeof(float);
+        const long long grid = (long long)k.groups * cdiv(k.Mg, BM) * cdiv(k.Co, BN);
+        const int want = stages ? stages : (grid <= 256 ? 3 : 2);
+        if (want == 4 && 4 * per_stage <= 72 * 1024) return launch_conv_glds_v<BM, BN, WM, WN, 16>(k, s);
+        if (want >= 3 && 3 * per_stage <= 76 * 1024) return launch_conv_glds_v<BM, BN, WM, WN, 8>(k, s);
+    }
     switch (var & 3) {
         case 1: return launch_conv_glds_v<BM, BN, WM, WN, 1>(k, s);
         case 2: return launch_conv_glds_v<BM, BN, WM, WN, 2>(k, s);

@@ -53,6 +53,9 @@ class StepEngine:
             lanes = int(os.environ.get("PICONS_LANES", "4"))
         p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
+        # PICONS_PRIO=1: lane 0 (the dependency chain) on a high-priority stream of its own, so its workgroups win the CU slots and
+        # the side lanes fill what is left
+        self.main = torch.cuda.Stream(device=self.dev, priority=-1) if (lanes > 1 and os.environ.get("PICONS_PRIO", "0") != "0") else None
         p.build_forward()
         p.build_loss(args)
         p.build_backward()
@@ -212,6 +215,15 @@ class StepEngine:
         self.kind_count += cnt
 
     def run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True):
+        if self.main is not None and reducer is None:
+            self.main.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.main):
+                out = self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect)
+            torch.cuda.current_stream().wait_stream(self.main)
+            return out
+        return self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect)
+
+    def _run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True):
         """One full step on the minibatch already staged in HBM: fwd x2 + losses + bwd (+ all-reduce) +
         Adam + the packed loss read-back.  collect=False leaves the timing events of a timed step pending (the caller
         reads them with collect_timing() later, e.g. after its timed region: reading 212 events costs ~0.4 ms of host time)."""
