@@ -75,7 +75,7 @@ def main():
     ap.add_argument("--gv", action="store_true", help="BASELINE config 3 (--gv instead of --bv)")
     ap.add_argument("--epoch", type=int, default=1, help="epoch the step runs at (>= 11 = --thresh_epoch: argmax pseudo-labels "
                     "for the unlabeled rows, capsules_ucf101.py:463)")
-    ap.add_argument("--time-every", type=int, default=20, help="attach hipEvent pairs to the conv kernels of every n-th timed step")
+    ap.add_argument("--time-every", type=int, default=40, help="attach hipEvent pairs to the conv kernels of every n-th timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()

@@ -339,7 +339,7 @@ __device__ __forceinline__ void load_pos(ST* st, const float* x, int64_t pos, in
     if (tid < NB) st->a[tid] = xp[NB * 16 + tid];
 }
 
-constexpr int FWD_WAVES = 10;
+constexpr int FWD_WAVES = 13;   // 25 positions per CU at bs = 8: 13 waves finish them in two rounds (10 or 12 need three); 13 x 8.7 KB + 48 KB of W^T = 158 KB
 
 // Forward: one wave per position, FWD_WAVES independent waves per block sharing W^T in LDS.  The kernel is a chain
 // of dependent reductions, so it lives on waves per SIMD: 4 waves/block (full FwdState) ran 1.38 ms, 8 with the
