@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bs", type=int, default=8)
     ap.add_argument("--gv", action="store_true", help="BASELINE config 3 (--gv instead of --bv)")
+    ap.add_argument("--jhmdb", action="store_true", help="BASELINE config 5's shape: 21 classes, main_jhmdb.py's step")
     ap.add_argument("--epoch", type=int, default=1, help="epoch the step runs at (>= 11 = --thresh_epoch: argmax pseudo-labels "
                     "for the unlabeled rows, capsules_ucf101.py:463)")
     ap.add_argument("--time-every", type=int, default=40, help="attach hipEvent pairs to the conv kernels of every n-th timed step")
@@ -90,8 +91,9 @@ def main():
     torch.cuda.set_device(local)
 
     args = pstep.default_args(bv=not a.gv, gv=a.gv, n_frames=5, wt_cons=0.1, lr=1e-4, epochs=100, thresh_epoch=11)
-    eng = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=24, device=dev)
-    lab, unl, perm, drops = synthetic.make_step_inputs(a.bs, rank=rank, step=0)
+    ncls = 21 if a.jhmdb else 24
+    eng = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=ncls, jhmdb=a.jhmdb, device=dev)
+    lab, unl, perm, drops = synthetic.make_step_inputs(a.bs, rank=rank, step=0, num_classes=ncls)
     eng.stage(lab, unl, perm, drops)                     # inputs resident in HBM before the timed region
     reducer = eng.make_reducer() if world > 1 else None
     ramp = pstep.exp_rampup(100)(a.epoch)
@@ -166,7 +168,7 @@ def main():
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: UCF101-24-shaped synthetic, I3D+caps, 8 frames (16-frame span, stride 2) x224x224, "
+        "config": {"workload": ("configs[4] on one rank: JHMDB-21-shaped" if a.jhmdb else "configs[1]: UCF101-24-shaped") + " synthetic, I3D+caps, 8 frames (16-frame span, stride 2) x224x224, "
                                "bs=%d/GPU (bs/2 labeled + bs/2 unlabeled), %s consistency, dice+BCE loc loss, spread cls loss, Adam"
                                % (a.bs, "--gv" if a.gv else "--bv --n_frames 5 L2"),
                    "global_batch": world * a.bs, "clip": [3, 8, 224, 224], "parallelism": "dp%d" % world,

@@ -75,6 +75,11 @@ class StepEngine:
         self.ops = p.resolve(self.bases)
         self.step_count = 0
         self.kind_ms, self.kind_count = 0.0, 0
+        # the loss scalars are final before the backward starts: their D2H goes out on a stream of its own behind the loss list and
+        # the step waits for THAT copy only, so the host is enqueueing the next step while the backward and Adam still run
+        self.scal_host = torch.empty(20, dtype=torch.float32).pin_memory()
+        self.scal_stream = torch.cuda.Stream(device=self.dev)
+        self.scal_event = None
         self.load_state(state if state is not None else synthetic.init_state(seed, num_classes))
 
     # ------------------------------------------------------------------ views
@@ -166,6 +171,7 @@ class StepEngine:
         run(o["prep_late"])        # side lanes only; joined inside the forward list (plan.late_prep)
         run(o["fwd"])
         run(o["loss"])
+        self._send_scalars()
         if reducer is None or reducer.world == 1:
             run(o["bwd"])
         else:
@@ -188,9 +194,24 @@ class StepEngine:
         for k in self.nbt:
             self.nbt[k] += 2           # two forward passes per step
 
+    def _send_scalars(self):
+        cur = torch.cuda.current_stream()
+        done = torch.cuda.Event()
+        done.record(cur)
+        self.scal_stream.wait_event(done)
+        with torch.cuda.stream(self.scal_stream):
+            self.scal_host.copy_(self.aview(self.plan.scalars, 20), non_blocking=True)   # spread_out sits at scalars + 16 (plan.build_loss)
+            self.scal_event = torch.cuda.Event()
+            self.scal_event.record(self.scal_stream)
+
     def read_scalars(self):
-        """One packed D2H for the step's loss scalars (replaces the reference's five .item() syncs)."""
-        s = self.aview(self.plan.scalars, 20).cpu()           # spread_out sits at scalars + 16 (plan.build_loss)
+        """One packed D2H for the step's loss scalars (replaces the reference's five .item() syncs); the copy was enqueued behind
+        the loss list by forward_backward, this waits for it (not for the backward / Adam)."""
+        if self.scal_event is None:                           # the loss list was replayed by hand (tools/bench_loss.py): blocking copy
+            s = self.aview(self.plan.scalars, 20).cpu()
+        else:
+            self.scal_event.synchronize()
+            s = self.scal_host.clone()
         loc, cons, cls = float(s[0]), float(s[1]), float(s[16])
         a = self.args
         return dict(total=a.wt_loc * loc + a.wt_cls * cls + a.wt_cons * cons, loc=loc, cls=cls, cons=cons,
@@ -233,7 +254,7 @@ class StepEngine:
             reducer.wait()
             gscale = reducer.gscale
         self.adam(self.args.lr if lr is None else lr, gscale)
-        out = self.read_scalars()            # the step's one host sync
+        out = self.read_scalars()            # the step's one host wait: for the loss scalars' copy, not for the GPU to drain
         if timed_kind is not None and collect:
             self.collect_timing()
         return out

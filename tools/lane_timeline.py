@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Where is the chip under-filled during a multi-lane step?  Reads a rocprofv3 --kernel-trace csv of `bench.py` (four lanes),
+takes the last full step (between the last two adam_kernel dispatches) and prints
+
+  * per stream: kernels, busy time, share of the step;
+  * the step's wall time split by how many CU slots the kernels running at that instant could fill at most
+    (sum over concurrent kernels of min(1, blocks / (256 CUs x resident blocks per CU)), resident blocks from the
+    dispatch's LDS bytes / VGPRs / workgroup size);
+  * the kernels that run while that sum is below --thresh, by accumulated under-filled time.
+
+    python tools/lane_timeline.py gpurun_out/r02g/prof/r02_kernel_trace.csv [--thresh 0.6] [--out profiles/r02_lane_timeline.txt]
+"""
+import argparse
+import collections
+import csv
+import sys
+
+CUS, LDS_CU, VGPR_SIMD, WAVES_SIMD = 256, 160 * 1024, 512, 8
+
+
+def clean(name):
+    n = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return n.split("(")[0].strip()[:60]
+
+
+# rocprofv3's dispatch record does not carry dynamic LDS and reports allocation granules, so the GEMM and EM kernels' resident
+# blocks per CU come from their launch code (conv.hip: __launch_bounds__(256, 2), 3 for the small-tile wgrad variants; caps.hip)
+OVERRIDE = (("wgrad4_kernel", 3), ("wgrad_kernel<64,", 3), ("wgrad_kernel<128, 256", 3), ("conv_gemm", 2), ("wgrad", 2), ("em_fwd", 1), ("em_bwd", 1))
+
+
+def resident(r):
+    n = clean(r["Kernel_Name"])
+    for pre, v in OVERRIDE:
+        if n.startswith(pre):
+            return v
+    wg = int(r["Workgroup_Size_X"]) * int(r["Workgroup_Size_Y"]) * int(r["Workgroup_Size_Z"])
+    waves = max(1, (wg + 63) // 64)
+    vg = max(1, int(r["VGPR_Count"]) + int(r["Accum_VGPR_Count"]))
+    wps = max(1, min(WAVES_SIMD, VGPR_SIMD // vg))
+    by_vgpr = max(1, wps * 4 // waves)
+    lds = int(r["LDS_Block_Size"])
+    by_lds = LDS_CU // lds if lds else 64
+    return max(1, min(by_vgpr, by_lds, 32 // waves if waves <= 32 else 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("trace"); ap.add_argument("--thresh", type=float, default=0.6); ap.add_argument("--out")
+    a = ap.parse_args()
+    rows = [r for r in csv.DictReader(open(a.trace)) if r["Kind"] == "KERNEL_DISPATCH"]
+    for r in rows:
+        r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    adams = sorted(r["e"] for r in rows if "adam_kernel" in r["Kernel_Name"])
+    assert len(adams) >= 2, "need two steps in the trace"
+    t0, t1 = adams[-2], adams[-1]
+    step = [r for r in rows if r["s"] >= t0 and r["e"] <= t1]
+    out = []
+    out.append("step window %.3f ms, %d kernel dispatches" % ((t1 - t0) / 1e6, len(step)))
+    per = collections.defaultdict(lambda: [0, 0])
+    for r in step:
+        k = (r["Queue_Id"], r["Stream_Id"])
+        per[k][0] += 1; per[k][1] += r["e"] - r["s"]
+    out.append("\nper stream (queue, stream): kernels, summed duration ms, share of the step")
+    for k, (n, d) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        out.append("  %-12s %5d %8.3f %6.2f" % (k, n, d / 1e6, d / (t1 - t0)))
+    ev = []
+    for i, r in enumerate(step):
+        blocks = 1
+        for ax in "XYZ":
+            blocks *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
+        r["fill"] = min(1.0, blocks / float(CUS * resident(r)))
+        ev.append((r["s"], 1, i)); ev.append((r["e"], 0, i))
+    ev.sort()
+    live = set()
+    hist = collections.Counter()
+    under = collections.Counter()
+    alone = collections.Counter()
+    prev = t0
+    for t, kind, i in ev:
+        dt = t - prev
+        if dt > 0:
+            f = sum(step[j]["fill"] for j in live)
+            hist[min(10, int(f * 10))] += dt
+            if f < a.thresh:
+                for j in live:
+                    under[clean(step[j]["Kernel_Name"])] += dt
+                if len(live) == 1:
+                    alone[clean(step[next(iter(live))]["Kernel_Name"])] += dt
+                if not live:
+                    under["(nothing running)"] += dt
+        prev = t
+        (live.add if kind else live.discard)(i)
+    out.append("\nwall time by summed fill of the running kernels (1.0 = every resident-block slot of the chip could be taken)")
+    for b in range(11):
+        out.append("  fill %s %8.3f ms" % ("<%.1f" % ((b + 1) / 10) if b < 10 else ">=1.0", hist[b] / 1e6))
+    out.append("\nkernels running while fill < %.1f (ms of such time; a kernel counts for every instant it is live)" % a.thresh)
+    for k, d in under.most_common(25):
+        out.append("  %8.3f  (alone %6.3f)  %s" % (d / 1e6, alone[k] / 1e6, k))
+    text = "\n".join(out) + "\n"
+    sys.stdout.write(text)
+    if a.out:
+        open(a.out, "w").write(text)
+
+
+if __name__ == "__main__":
+    main()
