@@ -81,6 +81,12 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     a = ap.parse_args()
 
+    # stdout carries ONE JSON line: RCCL writes a version banner to C stdio's stdout (flushed at exit, i.e. after anything printed
+    # here), so fd 1 is pointed at stderr for the whole run and the line goes out through a saved copy of the real stdout
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import picons_amd  # noqa: F401
     from picons_amd import capi, dist as pdist, step as pstep, synthetic
     rank, world, local = pdist.init_from_env()
@@ -95,11 +101,17 @@ def main():
     eng = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=ncls, jhmdb=a.jhmdb, device=dev)
     lab, unl, perm, drops = synthetic.make_step_inputs(a.bs, rank=rank, step=0, num_classes=ncls)
     eng.stage(lab, unl, perm, drops)                     # inputs resident in HBM before the timed region
-    reducer = eng.make_reducer() if world > 1 else None
+    # PICONS_FORCE_REDUCER=1 on one GPU: a one-rank RCCL group and the whole DP schedule (segmented backward, bucket all-reduces on
+    # the comm stream behind events, 1/world in Adam) -- the N > 1 code path executed through RCCL where only one GPU exists
+    forced = world == 1 and os.environ.get("PICONS_FORCE_REDUCER", "0") == "1"
+    if forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    reducer = eng.make_reducer(force=forced) if (world > 1 or forced) else None
     ramp = pstep.exp_rampup(100)(a.epoch)
     kind = None if a.no_kernel_timing else capi.OP_CONV
     ranks_observed = 1
-    if world > 1:                                        # an all-reduce of ones: the rank count the collective really spans
+    if world > 1 or forced:                              # an all-reduce of ones: the rank count the collective really spans
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
         ranks_observed = int(ones.item())
@@ -177,14 +189,16 @@ def main():
         "roofline": roof,
         "roofline_step": roof_step,
         "ranks_observed": ranks_observed,
+        "reducer": None if reducer is None else {"buckets": len(reducer.buckets), "backend": torch.distributed.get_backend(),
+                                                 "forced_single_rank": forced},
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    if world > 1 or forced:
         torch.distributed.destroy_process_group()
 
 

@@ -39,17 +39,20 @@ class GradReducer:
     enqueued; on GPU the collective is issued on a dedicated stream behind an event, so it overlaps
     with the remaining backward kernels.  wait() joins before Adam."""
 
-    def __init__(self, flat_grad, buckets, group=None):
+    def __init__(self, flat_grad, buckets, group=None, force=False):
+        """force: run the bucket schedule and the collectives even in a group of ONE rank (an all-reduce over one rank is the
+        identity) -- how the RCCL path is executed on a one-GPU box (tests/test_dp_gpu.py, bench.py PICONS_FORCE_REDUCER=1)."""
         self.g = flat_grad
         self.buckets = list(buckets)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force) and dist.is_initialized())
         self.cuda = flat_grad.is_cuda
         self.comm_stream = torch.cuda.Stream(device=flat_grad.device) if self.cuda else None
         # RCCL reduces device memory in place.  With any other backend (gloo: the single-GPU two-process test of the real
         # engine, tests/test_dp_gpu.py -- RCCL refuses two ranks on one device) device gradients are staged through pinned
         # host memory: D2H on the side stream behind the bucket's event, the host all-reduce and the H2D copy in wait().
-        self.host_staged = bool(self.cuda and self.world > 1 and dist.get_backend(group) != "nccl")
+        self.host_staged = bool(self.cuda and self.active and dist.get_backend(group) != "nccl")
         self.host = torch.empty(flat_grad.numel(), dtype=flat_grad.dtype).pin_memory() if self.host_staged else None
         self.handles = []
         self.launched = []
@@ -58,7 +61,7 @@ class GradReducer:
         """Start bucket i's all-reduce behind everything enqueued so far on torch's current stream and on `streams`
         (the engine's side lanes: Plan.grad_buckets only marks a bucket ready at joined points, waiting on the
         side lanes as well makes that independent of the plan)."""
-        if self.world == 1:
+        if not self.active:
             return
         _ready, a, b = self.buckets[i]
         view = self.g[a:b]
@@ -92,7 +95,7 @@ class GradReducer:
             h.wait()
         self.handles = []
         self.launched = []
-        if self.cuda and self.world > 1:
+        if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 
     @property

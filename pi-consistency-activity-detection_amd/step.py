@@ -172,7 +172,7 @@ class StepEngine:
         run(o["fwd"])
         run(o["loss"])
         self._send_scalars()
-        if reducer is None or reducer.world == 1:
+        if reducer is None or not reducer.active:
             run(o["bwd"])
         else:
             done = 0
@@ -225,9 +225,9 @@ class StepEngine:
         pred = self.aview(p.pred, 2 * self.bs * self.C).view(2 * self.bs, self.C)
         return out[:self.bs], out[self.bs:], pred[:self.bs]
 
-    def make_reducer(self, group=None, target_floats=3_000_000):
+    def make_reducer(self, group=None, target_floats=3_000_000, force=False):
         from . import dist as pdist
-        return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats), group)
+        return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats), group, force=force)
 
     def collect_timing(self):
         """Read the event pairs the timed replays left pending (pc_run_ops_timed_collect) into kind_ms / kind_count."""

@@ -52,3 +52,53 @@ def test_two_rank_dp_step_on_one_gpu(tmp_path):
         failed = {k: c for k, c in v["checks"].items() if not c["ok"]}
         assert not failed and procs[rank].returncode == 0, (rank, failed, logs[rank][-2000:])
     assert "mean_gradient_vs_mean_of_oracle_steps" in verdicts[0]["checks"]
+
+
+RCCL_ONE_RANK = r"""
+import json, os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+import picons_amd
+from picons_amd import step as pstep, synthetic
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+args = pstep.default_args(lr=1e-4, bv=True, n_frames=5, wt_cons=0.1)
+eng = pstep.StepEngine(args, bs=2, hw=112, device="cuda:0")
+eng.stage(*synthetic.make_step_inputs(2, rank=0, step=0, hw=112))
+ramp = pstep.exp_rampup(100)(1)
+eng.forward_backward(1, ramp)
+torch.cuda.synchronize()
+G0 = eng.G.clone()
+red = eng.make_reducer(target_floats=3_000_000, force=True)
+assert red.active and not red.host_staged and red.world == 1 and dist.get_backend() == "nccl"
+eng.load_state(synthetic.init_state(47, 24))
+eng.forward_backward(1, ramp, reducer=red)
+n_launched = len(red.launched)
+red.wait()
+torch.cuda.synchronize()
+rel = ((eng.G - G0).norm() / G0.norm()).item()
+ones = torch.ones(4, device="cuda:0")
+dist.all_reduce(ones)
+out = eng.run_staged(1, ramp, reducer=red)          # the whole DP step: segmented backward, RCCL buckets, Adam with gscale
+torch.cuda.synchronize()
+json.dump({"rel": rel, "buckets": len(red.buckets), "launched": n_launched, "ones": ones.tolist(), "gscale": red.gscale,
+           "total": out["total"]}, open(sys.argv[1], "w"))
+dist.destroy_process_group()
+"""
+
+
+def test_rccl_one_rank_group_runs_the_dp_schedule(tmp_path):
+    """The N > 1 code path through RCCL itself on the one GPU a box has: a one-rank "nccl" process group, GradReducer forced
+    active, the backward replayed in bucket segments with every bucket's all-reduce issued on the comm stream behind the lanes'
+    events.  An all-reduce over one rank is the identity, so the gradient must equal the unsegmented one (fp32 split-K atomics
+    reorder sums only)."""
+    out = str(tmp_path / "rccl.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.run([sys.executable, "-c", RCCL_ONE_RANK % {"root": ROOT}, out], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert p.returncode == 0 and os.path.exists(out), p.stdout[-3000:]
+    v = json.load(open(out))
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_one_rank.json"), "w") as f:
+        json.dump(v, f)
+    assert v["buckets"] >= 3 and v["launched"] == v["buckets"], v
+    assert v["rel"] < 2e-4 and v["ones"] == [1.0] * 4 and v["gscale"] == 1.0, v
+    assert v["total"] == v["total"], v

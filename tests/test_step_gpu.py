@@ -258,6 +258,7 @@ def test_segmented_backward_matches_unsegmented():
 
     class FakeReducer:
         world = 2
+        active = True
         gscale = 0.5
 
         def __init__(self, buckets):
