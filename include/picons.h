@@ -46,6 +46,8 @@ typedef void* pc_stream;            /* hipStream_t */
                                        out[(n*To*Ho*Wo + position) * ldo + co].  Plain launches only (no bias / activation / cscale /
                                        accumulate / BN partials): the merged tail's column GEMMs, whose gather then streams every
                                        column entry once instead of pulling 4 bytes out of 27 different 512-byte rows */
+#define PC_F_CI3     64             /* Ci == 4 whose 4th channel is padding (the RGB clip, 3 channels in 16-byte pieces): that
+                                     * channel is taken as zero whatever it holds; the LDS-DMA stem kernel skips its MFMAs */
 
 int         pc_version(void);
 const char* pc_last_error(void);
@@ -101,7 +103,10 @@ typedef struct pc_wgrad_desc {
     int32_t dbstride, sbstride, gbstride;
     int32_t Td, Hd, Wd, doff[3];    /* Td > 0: D is not dense but the sub-lattice (Tq,Hq,Wq) starting at doff of a
                                      * [N][Td][Hd][Wd][ldd] tensor (with nbatch > 1: per problem, N = 1 each) */
+    int32_t flags;                  /* PC_WG_CS3: Cs == 4 whose 4th channel is padding -- g[..][3] may be left untouched */
+    int32_t reserved;
 } pc_wgrad_desc;
+#define PC_WG_CS3    1
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
 /* Several weight gradients in one call (the wgrads of one Inception module; the eight position classes of the merged tail):
  * the problems the generic split-K kernel would take share ONE grid, each with a range of blocks in proportion to its work; the

@@ -20,7 +20,7 @@ class ConvDesc(C.Structure):
 
 class WgradDesc(C.Structure):
     _fields_ = [(n, i32) for n in ("N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds")] + \
-               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride", "Td", "Hd", "Wd")] + [("doff", i32 * 3)]
+               [(n, i32 * 3) for n in ("istr", "ntap", "ioff0", "istep", "wk0")] + [(n, i32) for n in ("KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride", "Td", "Hd", "Wd")] + [("doff", i32 * 3), ("flags", i32), ("reserved", i32)]
 
 
 AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "accum", "in_sr", "in_hi", "in_lo", "out_sr", "out_hi", "out_lo"]
@@ -51,15 +51,16 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI) = range(1, 43)
 MAX_LANES = 8
 
-# numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 40 int32, then D, S, g)
-WJOB_DTYPE = np.dtype([("d", np.int32, 40), ("D", np.uint64), ("S", np.uint64), ("g", np.uint64)], align=False)
+# numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 42 int32, then D, S, g)
+WJOB_DTYPE = np.dtype([("d", np.int32, 42), ("D", np.uint64), ("S", np.uint64), ("g", np.uint64)], align=False)
 
 # numpy mirror of struct pc_transpose_job
 TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64), ("dbs", np.int64), ("batch", np.int32), ("R", np.int32),
                        ("C", np.int32), ("sld", np.int32), ("dld", np.int32), ("accum", np.int32)], align=False)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT = 1, 2, 4, 8, 16, 32
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3 = 1, 2, 4, 8, 16, 32, 64
+WG_CS3 = 1
 
 _SIGS = {
     "pc_version": (i32, []),
@@ -139,7 +140,7 @@ def lib():
             fn.restype = res
             fn.argtypes = args
         assert C.sizeof(ConvDesc) == 48 * 4 and OP_DTYPE.itemsize == 4 + 192 + 32 + 4 + 96 + 32
-        assert C.sizeof(WgradDesc) == 160 and WJOB_DTYPE.itemsize == 184
+        assert C.sizeof(WgradDesc) == 168 and WJOB_DTYPE.itemsize == 192
         _lib = L
     return _lib
 

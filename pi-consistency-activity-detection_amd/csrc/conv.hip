@@ -480,8 +480,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) bf[j] = *(const f32x4*)(b + boff[j] + ((q ^ bsw[j]) << 2));
             if (VAR & 1) __builtin_amdgcn_s_setprio(1);
+            // TAP4 with PC_F_CI3 (VAR bit 5): a 16-byte slot is one tap's (c0, c1, c2, padding) -- the padding channel's MFMA is not issued
+            constexpr int NE = (TAP4 && (VAR & 32)) ? 3 : 4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < NE; ++e)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -656,7 +658,7 @@ int launch_conv(const ConvK& k, hipStream_t s) {
     if constexpr (BM == 128 && BN == 64)
         if (k.Ci == 4 && !no_glds && !no_tap4 && k.ntap[0] <= 10 && k.ntap[1] <= 10 && k.ntap[2] <= 10 && ((uintptr_t)k.in % 16 == 0) && k.ldi % 4 == 0 &&
             k.ldw % 4 == 0)
-            return launch_conv_glds_v<BM, BN, WM, WN, 4>(k, s);
+            return (k.flags & PC_F_CI3) ? launch_conv_glds_v<BM, BN, WM, WN, 4 | 32>(k, s) : launch_conv_glds_v<BM, BN, WM, WN, 4>(k, s);
     if (fast && !no_glds && k.ntap[0] <= 10 && k.ntap[1] <= 10 && k.ntap[2] <= 10 && ((uintptr_t)k.in % 16 == 0) && k.ldi % 4 == 0)
         return launch_conv_glds<BM, BN, WM, WN>(k, s);
     return fast ? launch_conv2<BM, BN, WM, WN, true>(k, s) : launch_conv2<BM, BN, WM, WN, false>(k, s);
@@ -1068,7 +1070,12 @@ struct Wg4K {
     int pre[11];                               // slice prefix per kt (ntap_t + 1 entries)
 };
 
-template <int BKP, int KW, int SW, int NKH>
+// PACK3 (PC_WG_CS3: the 4th source channel is padding): the NKH * KW * 3 real columns are packed into ceil(147 / 32) = 5
+// accumulators instead of one 32-column accumulator per kh with 21 real columns in it -- 5 MFMAs per k-step instead of 7.  Column
+// G = jj * 32 + lane -> (kh, kw, cs) = (G / 21, G % 21 / 3, G % 3) reads LDS dword kh*ROW + 4*SW*k + 4*kw + cs: per-lane constant
+// offsets; the padding dwords leave a quarter of the banks unused, so these ds_read_b32 are 2-way conflicted (2 of 22 LDS cycles
+// per k-step more per wave, far from the LDS limit).
+template <int BKP, int KW, int SW, int NKH, bool PACK3>
 __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     constexpr int BM = 64;
     constexpr int ROWP = SW * BKP + KW - 1;                  // pieces per kh row
@@ -1119,12 +1126,26 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
         }
     };
 
-    f32x16 acc[NKH];
+    constexpr int NCOL = NKH * KW * 3, NACC = PACK3 ? (NCOL + 31) / 32 : NKH;
+    f32x16 acc[NACC];
 #pragma unroll
-    for (int j = 0; j < NKH; ++j)
+    for (int j = 0; j < NACC; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
     const int nl = lane & 31, kh2 = lane >> 5, ml = wm * 32 + nl;
+    int boff[NACC], gcol[NACC];                // LDS dword of this lane's column in accumulator j / its offset inside g's [tap][4] rows (-1: none)
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        if constexpr (PACK3) {
+            const int G = j * 32 + nl, kh = G / (KW * 3), rem = G - kh * (KW * 3), kw = rem / 3, cs = rem - kw * 3;
+            const bool v = G < NCOL;
+            boff[j] = v ? kh * ROWP * 4 + kw * 4 + cs : 0;
+            gcol[j] = v ? (kh * KW + kw) * 4 + cs : -1;
+        } else {
+            boff[j] = j * ROWP * 4 + nl;
+            gcol[j] = nl < KW * 4 ? j * KW * 4 + nl : -1;          // kw = KW..7 are padding columns
+        }
+    }
     gload(c_begin, 0);
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
@@ -1135,24 +1156,22 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
         for (int q = 0; q < BKP / 4; ++q) {
             const int pp = (2 * q + wk) * 2 + kh2;
             const float af = Ds[buf][pp][ml];
-            float bf[NKH];
+            float bf[NACC];
 #pragma unroll
-            for (int j = 0; j < NKH; ++j) bf[j] = sb[j * ROWP * 4 + 4 * SW * pp + nl];
+            for (int j = 0; j < NACC; ++j) bf[j] = sb[boff[j] + 4 * SW * pp];
 #pragma unroll
-            for (int j = 0; j < NKH; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
         }
         __syncthreads();
     }
-    if (nl >= KW * 4) return;                  // padding columns
+    const size_t tap0 = (size_t)((kt_ + p.wk0_t) * p.KH + p.wk0_h) * KW * 4;       // g offset of (kt, kh = 0, kw = 0, cs = 0)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m >= p.Cd) continue;
 #pragma unroll
-        for (int j = 0; j < NKH; ++j) {
-            const int tap = ((kt_ + p.wk0_t) * p.KH + j + p.wk0_h) * KW;
-            atomicAdd(p.g + ((size_t)m * p.taps_full + tap) * 4 + nl, acc[j][r]);
-        }
+        for (int j = 0; j < NACC; ++j)
+            if (gcol[j] >= 0) atomicAdd(p.g + (size_t)m * p.taps_full * 4 + tap0 + gcol[j], acc[j][r]);
     }
 }
 
@@ -1219,7 +1238,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             q.pre[a + 1] = q.pre[a] + sl;
         }
         const dim3 grid((unsigned)(q.pre[q.ntap_t] * q.mt));
-        hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7>), grid, dim3(256), 0, s, q);
+        static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
+        if ((d->flags & PC_WG_CS3) && pack3) hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7, false>), grid, dim3(256), 0, s, q);
         PC_CHECK_LAUNCH("wgrad4_kernel");
         return PC_OK;
     }

@@ -388,8 +388,9 @@ class Plan:
         stat = self.alloc(self.groups * 4 * cout)
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
+        ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
         if self.training:
-            d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART, groups=self.groups)
+            d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART | (capi.F_CI3 if ci3 else 0), groups=self.groups)
             d["Ci_real"] = Ci_real
             nrows = _bnpart_rows(d)
             part = self.alloc(nrows * 2 * cout)
@@ -399,7 +400,7 @@ class Plan:
                       p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
             g_apply = self.groups
         else:
-            d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw)
+            d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_CI3 if ci3 else 0)
             d["Ci_real"] = Ci_real
             self.conv_op(d, x.ref, w["fwd"], z.ref)
             self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
@@ -420,6 +421,7 @@ class Plan:
                           p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
                 wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
                 wd["Cs_real"] = Ci_real
+                wd["flags"] = capi.WG_CS3 if ci3 else 0
                 self.on_wgrad_lane(lambda: (self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]]), self.flush_grad(w)))
                 self.mark_final(*[q + sfx for q in pres for sfx in (".bn.weight", ".bn.bias")])
             if need_dx and part in ("all", "B"):

@@ -33,7 +33,7 @@ def test_header_symbols_exported(built):
 def test_struct_layouts_match_header(built):
     import ctypes as C
     assert C.sizeof(capi.ConvDesc) == 48 * 4
-    assert C.sizeof(capi.WgradDesc) == 40 * 4
+    assert C.sizeof(capi.WgradDesc) == 42 * 4
     assert C.sizeof(capi.PoolDesc) == 19 * 4
     assert C.sizeof(capi.LossDesc) == 16 * 4
     assert capi.OP_DTYPE.itemsize == 360 and capi.OP_DTYPE.fields["p"][1] == 232

@@ -89,6 +89,42 @@ def test_conv_same_fwd_dgrad_wgrad(Ci, Co, k, s, thw, N):
     close(gw.cpu(), w.grad.reshape(Co, Ci, taps).permute(0, 2, 1), what="wgrad")
 
 
+@pytest.mark.parametrize("Co,thw,N", [(64, (8, 12, 56), 2), (24, (5, 9, 112), 1), (64, (4, 28, 56), 3)])
+def test_stem_padding_channel_flags(Co, thw, N):
+    """PC_F_CI3 / PC_WG_CS3: the 4th channel of the RGB clip's 16-byte pieces is padding.  The forward must give the 3-channel
+    convolution whatever that channel and its weights hold (its MFMAs are not issued), the weight gradient must be right in the
+    three real channels and leave the padding column of g alone (the packed 5-accumulator wgrad4 kernel)."""
+    from picons_amd import capi
+    g = torch.Generator().manual_seed(9)
+    k, s_ = (7, 7, 7), (2, 2, 2)
+    x3 = torch.randn(N, 3, *thw, generator=g)
+    w3 = (torch.randn(Co, 3, *k, generator=g) / np.sqrt(3 * 343)).requires_grad_(True)
+    pads = [spec.same_pad(thw[i], k[i], s_[i]) for i in range(3)]
+    xp = F.pad(x3, (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    y = F.conv3d(xp, w3, None, s_)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    othw = tuple(y.shape[2:]); pf = [p[0] for p in pads]
+    junk = torch.randn(N, 1, *thw, generator=g) * 3.0
+    x4 = cl(torch.cat([x3, junk], 1))                                  # garbage in the padding channel
+    w4 = torch.cat([w3.detach(), torch.randn(Co, 1, *k, generator=g)], 1)   # and in its weights
+    out = torch.empty(N, *othw, Co, device=DEV)
+    d = desc.conv_fwd(N, thw, 4, 4, Co, Co, k, s_, pf, othw, flags=capi.F_CI3)
+    ops.conv_fwd(d, x4, w_oki(w4), out)
+    close(uncl(out), y, what="fwd with PC_F_CI3")
+    x4z = cl(torch.cat([x3, torch.zeros(N, 1, *thw)], 1))
+    gw = torch.full((Co, 343, 4), 5.0, device=DEV)
+    gw[:, :, :3] = 0
+    wd = desc.wgrad(N, othw, Co, Co, thw, 4, 4, k, s_, pf)
+    wd["flags"] = capi.WG_CS3
+    ops.conv_wgrad(wd, cl(dy), x4z, gw)
+    close(gw[:, :, :3].cpu(), w3.grad.reshape(Co, 3, 343).permute(0, 2, 1), what="wgrad, real channels")
+    assert torch.equal(gw[:, :, 3].cpu(), torch.full((Co, 343), 5.0)), "padding column of g was written"
+    gw2 = torch.zeros(Co, 343, 4, device=DEV)                            # the same launch without the flag agrees
+    ops.conv_wgrad(desc.wgrad(N, othw, Co, Co, thw, 4, 4, k, s_, pf), cl(dy), x4z, gw2)
+    close(gw2[:, :, :3].cpu(), gw[:, :, :3].cpu(), what="packed vs 7-accumulator wgrad4")
+
+
 def test_wgrad_primarycaps_shape_remainder_rows():
     """PrimaryCaps weight gradient at its real channel counts (544 = 4*128 + 32 rows, 81*832 columns): the grid is
     deep enough that the last 32 rows go to a second launch with 64-row tiles; both row ranges are checked
