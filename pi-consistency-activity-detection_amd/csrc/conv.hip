@@ -967,20 +967,21 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     const int c_begin = slice * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
     if (c_begin >= c_end) return;
 
-    // chunk c -> (n, t, h, seg); returns false when the tap pair reads outside the volume (the chunk contributes nothing)
-    auto decode = [&](int c, int& row_d, int& row_s, int& w0) -> bool {
-        const int seg = c % p.nseg; int r = c / p.nseg;
-        const int h = r % p.H; r /= p.H;
-        const int t = r % p.T; const int n = r / p.T;
-        w0 = seg * BKP;
-        row_d = ((n * p.T + t) * p.H + h) * p.W;
-        const int ts = t * p.istr_t + p.ioff_t + kt_, hs = h * p.istr_h + p.ioff_h + kh_;
-        row_s = ((n * p.Ts + ts) * p.Hs + hs) * p.Wsw;
+    // chunk -> (n, t, h, seg), kept as a counter that advances with every fetch (chunks are fetched in order: no divisions in the
+    // K loop); a fetch returns false when the tap pair reads outside the volume (the chunk contributes nothing)
+    int q_seg = c_begin % p.nseg, q_h, q_t, q_n;
+    { int r = c_begin / p.nseg; q_h = r % p.H; r /= p.H; q_t = r % p.T; q_n = r / p.T; }
+    auto decode = [&](int& row_d, int& row_s, int& w0) -> bool {
+        w0 = q_seg * BKP;
+        row_d = ((q_n * p.T + q_t) * p.H + q_h) * p.W;
+        const int ts = q_t * p.istr_t + p.ioff_t + kt_, hs = q_h * p.istr_h + p.ioff_h + kh_;
+        row_s = ((q_n * p.Ts + ts) * p.Hs + hs) * p.Wsw;
+        if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == p.T) { q_t = 0; ++q_n; } } }
         return (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
     };
-    auto gload = [&](int c, int buf) -> bool {
+    auto gload = [&](int buf) -> bool {
         int row_d, row_s, w0;
-        if (!decode(c, row_d, row_s, w0)) return false;
+        if (!decode(row_d, row_s, w0)) return false;
         float* ld = &Ds[buf][0][0];
         float* ls = &Ss[buf][0][0];
         for (int i = wave; i < DI; i += 4) {                               // D tile: BKP rows x BM channels
@@ -1012,11 +1013,11 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) { const int col = wn * (BN / WNW) + 32 * j; kwj[j] = col / CSB; csj[j] = col % CSB + (lane & 31); }
     const int ml = wm * (BM / WMW) + (lane & 31), kh = lane >> 5;
-    bool live = gload(c_begin, 0);
+    bool live = gload(0);
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        const bool next_live = c + 1 < c_end ? gload(c + 1, buf ^ 1) : false;
+        const bool next_live = c + 1 < c_end ? gload(buf ^ 1) : false;
         if (live) {
 #pragma unroll
             for (int ks = 0; ks < BKP / 2; ++ks) {
@@ -1102,10 +1103,12 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     if (c_begin >= c_end) return;
     const int m0 = mtile * BM;
 
-    auto gload = [&](int c, int buf) {
-        const int seg = c % p.nseg; int r = c / p.nseg;
-        const int h = r % p.H; r /= p.H;
-        const int t = tlo + r % ntv; const int n = r / ntv;
+    // chunk -> (n, t, h, seg) as a counter advanced by every fetch (chunks are fetched in order)
+    int q_seg = c_begin % p.nseg, q_h, q_t, q_n;
+    { int r = c_begin / p.nseg; q_h = r % p.H; r /= p.H; q_t = r % ntv; q_n = r / ntv; }
+    auto gload = [&](int buf) {
+        const int seg = q_seg, h = q_h, t = tlo + q_t, n = q_n;
+        if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == ntv) { q_t = 0; ++q_n; } } }
         const int w0 = seg * BKP;
         const int row_d = ((n * p.T + t) * p.H + h) * p.W;
         const int ts = t * p.istr_t + p.ioff_t + kt_, hs0 = h * p.istr_h + p.ioff_h;
@@ -1146,11 +1149,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
             gcol[j] = nl < KW * 4 ? j * KW * 4 + nl : -1;          // kw = KW..7 are padding columns
         }
     }
-    gload(c_begin, 0);
+    gload(0);
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) gload(c + 1, buf ^ 1);
+        if (c + 1 < c_end) gload(buf ^ 1);
         const float* sb = &Ss[buf][0];
 #pragma unroll
         for (int q = 0; q < BKP / 4; ++q) {

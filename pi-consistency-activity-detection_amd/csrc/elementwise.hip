@@ -649,7 +649,8 @@ extern "C" int pc_axpy(float* y, const float* x, int64_t n, float a, pc_stream s
 
 extern "C" int pc_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, int step,
                             float gscale, pc_stream s) {
-    PC_CHECK_ARG(p && g && m && v && step >= 1, "pc_adam_step: bad args");
+    PC_CHECK_ARG(p && g && m && v && step >= 1 && n >= 0, "pc_adam_step: bad args");
+    if (n == 0) return PC_OK;                  // an un-armed early-Adam op of the backward list
     const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
                        (float)(1.0 / sqrt(bc2)), gscale);
