@@ -11,6 +11,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
 def _run(*flags, env=None):
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], capture_output=True, text=True, timeout=900, cwd=ROOT,
                        env=dict(os.environ, **(env or {})))
@@ -46,6 +55,6 @@ def test_bench_dp_schedule_through_rccl_on_one_rank():
     """PICONS_FORCE_REDUCER=1: the N > 1 code path (one-rank RCCL group, segmented backward, bucket all-reduces, rank count from an
     all-reduce of ones) and still exactly one stdout line -- RCCL's version banner must not land on stdout."""
     j = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing",
-             env={"PICONS_FORCE_REDUCER": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29517"})
+             env={"PICONS_FORCE_REDUCER": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert j["ranks_observed"] == 1 and j["reducer"]["backend"] == "nccl" and j["reducer"]["buckets"] >= 3 and j["reducer"]["forced_single_rank"]
     assert j["ms_per_step"] < 60.0 and j["loss"]["total"] == j["loss"]["total"]
