@@ -405,6 +405,10 @@ int pc_run_ops(const pc_op* ops, int n, pc_stream s);
  * branches of an Inception module (pytorch_i3d.py:149-154) and their backward run concurrently between
  * a FORK and the matching JOIN.  Lanes >= nlanes fold onto lane 0.  Every list must end joined. */
 int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes);
+/* `target` waits for everything enqueued so far on each of the nlanes streams (one persistent event per lane, no host sync):
+ * how a gradient bucket's all-reduce stream is put behind every lane of a step replayed in segments (dist.GradReducer.launch;
+ * the reference has no counterpart -- it is single-GPU, main_ucf101.py:171-184). */
+int pc_streams_fanin(pc_stream target, const pc_stream* lanes, int nlanes);
 /* same, with a hipEvent pair around every op of `kind` on the stream that op runs on (for PC_OP_CONV, whose ops are
  * one kernel each, the pair rides in the kernel's own dispatch and brackets exactly the kernel; other kinds are
  * bracketed by recorded events); returns elapsed ms summed over those ops in *ms and their count in *count (bench.py

@@ -233,6 +233,25 @@ extern "C" int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes,
     return run_list(ops, n, lanes, nlanes, 0, nullptr, nullptr);
 }
 
+extern "C" int pc_streams_fanin(pc_stream target, const pc_stream* lanes, int nlanes) {
+    if (nlanes < 0 || nlanes > PC_MAX_LANES || (nlanes && !lanes)) { pc_set_error("pc_streams_fanin: nlanes=%d (0..%d)", nlanes, PC_MAX_LANES); return PC_E_ARG; }
+    static thread_local hipEvent_t ev[PC_MAX_LANES];
+    static thread_local bool init = false;
+    if (!init) {
+        for (int i = 0; i < PC_MAX_LANES; ++i)
+            if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { pc_set_error("hipEventCreate failed"); return PC_E_LAUNCH; }
+        init = true;
+    }
+    for (int q = 0; q < nlanes; ++q) {
+        if (lanes[q] == target) continue;
+        if (hipEventRecord(ev[q], (hipStream_t)lanes[q]) != hipSuccess || hipStreamWaitEvent((hipStream_t)target, ev[q], 0) != hipSuccess) {
+            pc_set_error("pc_streams_fanin: event record / wait failed on lane %d", q);
+            return PC_E_LAUNCH;
+        }
+    }
+    return PC_OK;
+}
+
 // Times every op of `kind` with a hipEvent pair on the SAME stream that op's kernels run on
 // (torch.cuda.Event would only see torch's current stream).  Synchronises at the end.
 extern "C" int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes) {

@@ -67,11 +67,11 @@ class GradReducer:
         view = self.g[a:b]
         self.launched.append(i)
         if self.cuda:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream())
-            self.comm_stream.wait_event(ev)
-            for s in streams:
-                self.comm_stream.wait_stream(s)
+            # the comm stream goes behind torch's current stream and every lane through the library's persistent events
+            # (pc_streams_fanin): torch's wait_stream() creates and drops an event per call, and dropping an event that a busy lane
+            # has not reached yet stalled the host -- 0.7 ms per step with five buckets
+            from . import ops
+            ops.streams_fanin(self.comm_stream, streams)
             with torch.cuda.stream(self.comm_stream):
                 if self.host_staged:
                     self.host[a:b].copy_(view, non_blocking=True)

@@ -297,6 +297,12 @@ def _lane_array(side):
     return (C.c_void_p * len(hs))(*hs), len(hs)
 
 
+def streams_fanin(target, side=None):
+    """`target` (a torch stream) waits for everything enqueued so far on torch's current stream and on the side streams."""
+    arr, nl = _lane_array(side)
+    capi.call("pc_streams_fanin", C.c_void_p(target.cuda_stream), arr, nl)
+
+
 def run_ops(ops_np, n=None, side=None):
     """ops_np: numpy array of capi.OP_DTYPE (host memory); replayed by the library.  side: extra
     torch.cuda.Stream objects for the plan's lanes 1.. (None -> everything on the current stream)."""

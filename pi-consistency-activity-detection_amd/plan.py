@@ -1020,10 +1020,16 @@ class Plan:
         if self.wg_lane or self.skip_lane:
             self.join((1 << self.wg_lane | 1 << self.skip_lane) & ~1)
 
-    def grad_buckets(self, target_floats=12_000_000):
+    def grad_buckets(self, target_floats=12_000_000, joined=False):
         """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the
-        order their gradients become final during backward, each with the bwd-op index after which it may
-        be reduced.  -> [(ready_after_bwd_ops, start_float, end_float)] sorted by readiness."""
+        order their gradients become final during backward, each with the number of bwd ops that must have been ENQUEUED
+        before it may be reduced.  -> [(ready_after_bwd_ops, start_float, end_float)] sorted by readiness.
+
+        Default: a bucket is ready once the last op that writes one of its gradients has been enqueued, on whatever lane -- the
+        caller must put the collective behind EVERY lane's stream (GradReducer.launch(i, streams) does).  With the weight
+        gradients on a lane of their own that is joined only at the end of the list, this is what lets a bucket leave while
+        the backward is still running.  joined=True: ready only where lane 0 has JOINed the lane that finalised it (a caller
+        that orders the collective behind lane 0 alone); with a weight-gradient lane that is the end of the list."""
         missing = [k for k in self.pshape if k not in self.final_at]
         if missing:
             raise RuntimeError("no backward op finalises %s" % missing[:4])
@@ -1054,6 +1060,8 @@ class Plan:
 
         def ready_of(nm):
             k, lane = self.final_at[nm], self.final_lane.get(nm, 0)
+            if not joined:
+                return max(1, min(k, len(bwd)))
             if lane == 0:
                 return snap[k]
             j = cover[min(k, len(bwd))].get(lane) if k < len(bwd) else None

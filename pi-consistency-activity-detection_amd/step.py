@@ -53,6 +53,15 @@ class StepEngine:
             lanes = int(os.environ.get("PICONS_LANES", "4"))
         p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
+        # ROCm binds a stream to one of its (by default four) hardware queues when the stream is first used, and two lanes on one
+        # hardware queue serialise: use the lanes, in order, before anything else in this process creates work on another stream
+        # (the collectives of a process group, the loss read-back stream) -- GPU_MAX_HW_QUEUES != 4 is 3-25 % slower
+        if os.environ.get("PICONS_BIND_LANES", "1") != "0":
+            tick = torch.zeros(64, device=self.dev)
+            for st in [torch.cuda.current_stream(self.dev)] + self.side:
+                with torch.cuda.stream(st):
+                    tick.add_(1.0)
+            torch.cuda.synchronize(self.dev)
         # PICONS_PRIO=1: lane 0 (the dependency chain) on a high-priority stream of its own, so its workgroups win the CU slots and
         # the side lanes fill what is left
         self.main = torch.cuda.Stream(device=self.dev, priority=-1) if (lanes > 1 and os.environ.get("PICONS_PRIO", "0") != "0") else None
@@ -227,7 +236,8 @@ class StepEngine:
 
     def make_reducer(self, group=None, target_floats=3_000_000, force=False):
         from . import dist as pdist
-        return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats), group, force=force)
+        joined = os.environ.get("PICONS_BUCKETS_JOINED", "0") != "0"      # A/B switch: buckets only where lane 0 has joined their lane
+        return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats, joined=joined), group, force=force)
 
     def collect_timing(self):
         """Read the event pairs the timed replays left pending (pc_run_ops_timed_collect) into kind_ms / kind_count."""

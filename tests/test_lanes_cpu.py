@@ -193,7 +193,7 @@ def test_buckets_ready_only_at_joined_points(lanes):
     bucket happens-before lane 0's clock there."""
     p = _plan(lanes)
     bwd = p.lists["bwd"]
-    b = p.grad_buckets(500_000)
+    b = p.grad_buckets(500_000, joined=True)
     assert len(b) > 8
     spans = sorted((a, e) for _r, a, e in b)
     assert spans[0][0] == 0 and spans[-1][1] == p.nparams
@@ -288,3 +288,33 @@ def test_flat_layout_groups_the_stacked_units(monkeypatch):
     # one conv / BN per group instead of three: 2 x 7 fewer convs forward
     count = lambda pl, kind: sum(1 for op in pl.lists["fwd"] if op[0] == kind)
     assert count(q, capi.OP_CONV) - count(p, capi.OP_CONV) == 14 and count(q, capi.OP_BN_APPLY) - count(p, capi.OP_BN_APPLY) == 14
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_buckets_ready_once_their_last_writer_is_enqueued(lanes):
+    """The default schedule (the collective is ordered behind every lane's stream by GradReducer.launch): a bucket is ready as
+    soon as the last op that writes one of its gradients is in the enqueued prefix -- on whatever lane -- and not earlier.  With a
+    weight-gradient lane that is joined only at the end, this is the difference between buckets leaving during the backward and
+    all of them leaving at its end."""
+    p = _plan(lanes)
+    bwd = p.lists["bwd"]
+    b = p.grad_buckets(500_000)
+    spans = sorted((a, e) for _r, a, e in b)
+    assert spans[0][0] == 0 and spans[-1][1] == p.nparams and all(spans[i][1] == spans[i + 1][0] for i in range(len(spans) - 1))
+    gkeys = {p.G(nm): nm for nm in p.pshape}
+    last_writer = {}
+    for idx, op in enumerate(bwd):
+        if op[0] in (capi.OP_FORK, capi.OP_JOIN):
+            continue
+        for key, wr in _accesses(p, op):
+            if wr and key in gkeys:
+                last_writer[gkeys[key]] = idx
+    for ready, a, e in b:
+        inside = [nm for nm, off in p.poff.items() if a <= off < e]
+        need = max(last_writer[nm] for nm in inside if nm in last_writer) + 1
+        assert need <= ready <= len(bwd), (a, e, ready, need)
+        assert ready == max(p.final_at[nm] for nm in inside)
+    readies = sorted(r for r, _a, _e in b)
+    assert readies[0] < 0.35 * len(bwd) and readies[len(readies) // 2] < 0.9 * len(bwd)       # buckets leave throughout the backward
+    if lanes >= 4:       # what the joined schedule would do with a weight-gradient lane: everything at the end of the list
+        assert all(r == len(bwd) for r, _a, _e in p.grad_buckets(500_000, joined=True))
