@@ -58,7 +58,11 @@ class StepEngine:
         # (the collectives of a process group, the loss read-back stream) -- GPU_MAX_HW_QUEUES != 4 is 3-25 % slower
         if os.environ.get("PICONS_BIND_LANES", "1") != "0":
             tick = torch.zeros(64, device=self.dev)
-            for st in [torch.cuda.current_stream(self.dev)] + self.side:
+            order = [torch.cuda.current_stream(self.dev)] + self.side
+            perm = os.environ.get("PICONS_BIND_ORDER")             # diagnostic: e.g. "0,3,2,1"
+            if perm:
+                order = [order[int(q)] for q in perm.split(",") if int(q) < len(order)]
+            for st in order:
                 with torch.cuda.stream(st):
                     tick.add_(1.0)
             torch.cuda.synchronize(self.dev)
