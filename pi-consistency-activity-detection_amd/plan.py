@@ -51,6 +51,10 @@ class Plan:
         lanes: HIP streams the runner may use; >1 tags the four branches of every Inception module (and their
         backward) onto separate lanes between FORK/JOIN ops, so the under-filled 14x14 launches overlap."""
         self.acc = 1 if accum_grads else 0
+        if hw % 8 or hw // 8 < spec.PRIMARY_K:
+            # the reference fails the same way, inside nn.Conv2d (capsules_ucf101.py:43-49: a 9x9 valid conv on the hw/8 feature map)
+            raise ValueError("frame size %d: must be a multiple of 8 and at least %d (the 9x9 PrimaryCaps conv needs a feature map of "
+                             "9x9 or more)" % (hw, 8 * spec.PRIMARY_K))
         if not 1 <= lanes <= capi.MAX_LANES:
             raise ValueError("lanes must be 1..%d" % capi.MAX_LANES)
         self.lanes = lanes

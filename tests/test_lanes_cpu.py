@@ -318,3 +318,12 @@ def test_buckets_ready_once_their_last_writer_is_enqueued(lanes):
     assert readies[0] < 0.35 * len(bwd) and readies[len(readies) // 2] < 0.9 * len(bwd)       # buckets leave throughout the backward
     if lanes >= 4:       # what the joined schedule would do with a weight-gradient lane: everything at the end of the list
         assert all(r == len(bwd) for r, _a, _e in p.grad_buckets(500_000, joined=True))
+
+
+def test_frame_size_is_checked_where_the_reference_would_fail():
+    """hw / 8 is the feature map the 9x9 valid PrimaryCaps conv runs on (capsules_ucf101.py:43-49): below 72 (or not a multiple of 8)
+    the reference dies inside nn.Conv2d; the plan says so instead of failing in a kernel launch."""
+    for hw in (64, 100, 60):
+        with pytest.raises(ValueError, match="frame size"):
+            Plan(24, hw, n=1, groups=2)
+    Plan(24, 72, n=1, groups=2)

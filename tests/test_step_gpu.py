@@ -36,7 +36,7 @@ def run_pair(akw, hw, bs, epoch, ncls=24, jhmdb=False, stepid=0, lr=1e-4, condit
     return eng, ref, P, P64
 
 
-def check_gradients_fp64_anchored(eng, P, P64, tag):
+def check_gradients_fp64_anchored(eng, P, P64, tag, floor=5e-3):
     """Every parameter gradient: relative L2 per tensor against the fp64 oracle, judged next to the fp32 oracle's own
     distance from it (the fp32 reference differs from ITSELF by ~1 % on gradients, SURVEY finding 4)."""
     bad, rows = [], []
@@ -48,7 +48,7 @@ def check_gradients_fp64_anchored(eng, P, P64, tag):
         rel_c = (r32 - r64).norm().item() / den
         rows.append((name, rel_g, rel_c, den))
         num_g += (g - r64).norm().item() ** 2; num_c += (r32 - r64).norm().item() ** 2; den_all += den ** 2
-        if rel_g > max(4 * rel_c, 5e-3) and (g - r64).abs().max().item() > 1e-7:
+        if rel_g > max(4 * rel_c, floor) and (g - r64).abs().max().item() > 1e-7:
             bad.append((name, rel_g, rel_c, den))
     tot_g, tot_c = (num_g / den_all) ** 0.5, (num_c / den_all) ** 0.5
     os.makedirs("gpurun_out", exist_ok=True)
@@ -95,6 +95,26 @@ def test_step_vs_oracle_small(tag, akw, epoch, ncls, jhmdb):
     ostep.adam_step(P, m, v, 1, 1e-4)
     for k in before:
         assert (eng.param(k).cpu() - P[k].detach()).abs().max().item() <= 5e-5, k   # half an Adam step (lr 1e-4): |g| ~ eps entries amplify the ~2 % gradient noise
+
+
+@pytest.mark.parametrize("bs,hw", [(6, 112), (4, 80)])
+def test_step_vs_oracle_other_batch_and_frame_sizes(bs, hw):
+    """Nothing in the path may assume a power-of-two batch or the two frame sizes the other tests use: bs = 6 (three labeled + three
+    unlabeled clips, 12 clip-passes: ragged row tiles in every GEMM, 12 x 6 x 6 EM positions) at 112^2 and bs = 4 at 80^2
+    (10 x 10 features, 2 x 2 capsule grid: the smallest frame size but one the 9 x 9 PrimaryCaps conv admits).  Scalars / outputs at the bars of test_step_vs_oracle_small; the per-tensor gradient floor is 2 % here: on
+    this minibatch ONE pre-activation of Mixed_4f.b2b (channel 0) sits within fp32 rounding of zero, its ReLU mask comes out the other
+    way than in the fp64 run, and that single element moves the branch's small gradients by 0.6 - 1 % (every other channel agrees to
+    1e-6: tools/probe_bs_grads.py 6 112 7 conv1.Mixed_4f.b2b.bn.bias) -- a discontinuity of the function, not of the kernels."""
+    akw = dict(bv=True, gv=True, n_frames=5, wt_cons=0.1)
+    eng, ref, P, P64 = run_pair(akw, hw, bs, 1, 24, False, stepid=7)
+    got = eng.read_scalars()
+    out, flip, pred = eng.outputs()
+    for k in ("total", "loc", "cls", "cons"):
+        assert abs(got[k] - float(ref[k])) <= 1e-4, (k, got[k], float(ref[k]))
+    assert (pred.cpu() - ref["predicted_action"]).abs().max().item() <= 1e-3
+    assert (out.cpu() - ref["output"]).abs().max().item() <= 1e-3
+    assert (flip.cpu() - ref["flip_op"]).abs().max().item() <= 1e-3
+    check_gradients_fp64_anchored(eng, P, P64, "bs%d_hw%d" % (bs, hw), floor=2e-2)
 
 
 GSAMPLE_STRIDE = {"upsample3.weight": 7, "upsample4.weight": 13, "primary_caps.pose.weight": 997, "primary_caps.a.weight": 97}
