@@ -46,13 +46,16 @@ def resident(r):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace"); ap.add_argument("--thresh", type=float, default=0.6); ap.add_argument("--out")
+    ap.add_argument("--window", type=int, default=-1, help="which step of the trace (index into the windows between adam_kernel dispatches; "
+                    "-1 = the last; the last step of a short profiled run can carry host stalls of the profiler's own)")
     a = ap.parse_args()
     rows = [r for r in csv.DictReader(open(a.trace)) if r["Kind"] == "KERNEL_DISPATCH"]
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     adams = sorted(r["e"] for r in rows if "adam_kernel" in r["Kernel_Name"])
     assert len(adams) >= 2, "need two steps in the trace"
-    t0, t1 = adams[-2], adams[-1]
+    wins = list(zip(adams, adams[1:]))
+    t0, t1 = wins[a.window]
     step = [r for r in rows if r["s"] >= t0 and r["e"] <= t1]
     out = []
     out.append("step window %.3f ms, %d kernel dispatches" % ((t1 - t0) / 1e6, len(step)))
