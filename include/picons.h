@@ -84,6 +84,15 @@ typedef struct pc_conv_desc {
 int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const float* bias,
                 const float* cscale, float* out, float* bnpart, pc_stream s);
 int pc_conv_bnpart_rows(const pc_conv_desc* d);
+/* Host-only work accounting of one pc_conv_fwd launch (no GPU call; measurement support for bench.py / tools/launch_table.py,
+ * no reference counterpart).  Walks the launch's tiles in the kernel's own row order and counts the K loop each block really
+ * runs (taps that are padding for every row of a tile are skipped by the kernel).  out[7]:
+ *   [0] multiply-accumulates ISSUED to the matrix cores (whole tiles: what an MFMA instruction counter sees),
+ *   [1] EXECUTED on real outputs (real rows x real columns x the tile's K; padding taps inside the tile's tap box included),
+ *   [2] VALID (taps that read inside the volume, real channels only),  [3] blocks,  [4] BM,  [5] BN,
+ *   [6] 1 = LDS-DMA kernel with the per-tile tap box, 0 = register-staged kernel (flattened K).
+ * ci_real / co_real: channels that are not padding (0 = Ci / Co). */
+int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, double* out);
 
 /* Weight gradient:  g[m][ (a,b,c) , cs ] += sum_{n,q} D[n,q,m] * S[n, q*istr+ioff0+(a,b,c)*istep, cs]
  * D dense over the lattice (Tq,Hq,Wq), S gathered.  g layout [Cd][KT*KH*KW][Cs], tap (a,b,c) -> wk0+(a,b,c),
@@ -108,6 +117,11 @@ typedef struct pc_wgrad_desc {
 } pc_wgrad_desc;
 #define PC_WG_CS3    1
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
+/* Host-only work accounting of one pc_conv_wgrad launch (no GPU call; see pc_conv_work).  out[5]: multiply-accumulates ISSUED to
+ * the matrix cores, EXECUTED on real rows x columns, VALID (non-padding source positions), and the kernel family the problem is
+ * routed to (0 stem, 1 row-segment with 3 taps, 2 row-segment with 9 taps, 3 generic split-K), kernel launches the call makes.
+ * cd_real / cs_real: 0 = Cd / Cs. */
+int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, double* out);
 /* Several weight gradients in one call (the wgrads of one Inception module; the eight position classes of the merged tail):
  * the problems the generic split-K kernel would take share ONE grid, each with a range of blocks in proportion to its work; the
  * others (stem, row-segment, long-K shapes) get their usual launch.  Same results as njobs pc_conv_wgrad calls up to the order

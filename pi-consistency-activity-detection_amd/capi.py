@@ -67,8 +67,10 @@ _SIGS = {
     "pc_last_error": (C.c_char_p, []),
     "pc_conv_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "pc_conv_bnpart_rows": (i32, [C.POINTER(ConvDesc)]),
+    "pc_conv_work": (i32, [C.POINTER(ConvDesc), i32, i32, C.POINTER(C.c_double)]),
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
     "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),
+    "pc_wgrad_work": (i32, [C.POINTER(WgradDesc), i32, i32, C.POINTER(C.c_double)]),
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
     "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),

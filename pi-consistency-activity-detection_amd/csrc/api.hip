@@ -181,16 +181,19 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
             const bool fork = op.kind == PC_OP_FORK;
             // FORK: the lanes in mask i[0] wait for everything enqueued so far on lane i[1] (0 unless the plan says otherwise)
             const int src = (fork && op.i[1] > 0 && op.i[1] < nlanes) ? op.i[1] : 0;
-            if (fork) (void)hipEventRecord(g_ev[src], (hipStream_t)lanes[src]);
-            for (int q = 0; q < nlanes; ++q) {
+            // a failed record / wait would silently drop a dependency between lanes (a race, not an error): fail the list instead
+            hipError_t he = hipSuccess;
+            if (fork) he = hipEventRecord(g_ev[src], (hipStream_t)lanes[src]);
+            for (int q = 0; q < nlanes && he == hipSuccess; ++q) {
                 if (!((op.i[0] >> q) & 1) || (fork && q == src) || (!fork && q == 0)) continue;
                 if (fork) {
-                    (void)hipStreamWaitEvent((hipStream_t)lanes[q], g_ev[src], 0);
+                    he = hipStreamWaitEvent((hipStream_t)lanes[q], g_ev[src], 0);
                 } else {
-                    (void)hipEventRecord(g_ev[q], (hipStream_t)lanes[q]);
-                    (void)hipStreamWaitEvent((hipStream_t)lanes[0], g_ev[q], 0);
+                    he = hipEventRecord(g_ev[q], (hipStream_t)lanes[q]);
+                    if (he == hipSuccess) he = hipStreamWaitEvent((hipStream_t)lanes[0], g_ev[q], 0);
                 }
             }
+            if (he != hipSuccess) { pc_set_error("%s: event record / wait failed: %s", fork ? "FORK" : "JOIN", hipGetErrorString(he)); rc = PC_E_LAUNCH; ++k; break; }
             continue;
         }
         const int ln = (op.lane > 0 && op.lane < nlanes) ? op.lane : 0;

@@ -684,7 +684,97 @@ inline TileCfg choose_tile(int Mg, int groups, int Co, int Ci) {
     return bc;
 }
 
+// The tile pc_conv_fwd launches for a descriptor (shared with the host-side work accounting, pc_conv_work).
+inline TileCfg launch_tile(const pc_conv_desc* d, int groups) {
+    const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    TileCfg c = choose_tile((int)Mg, groups, d->Co, d->Ci);
+    static const char* force = getenv("PICONS_CONV_TILE");      // diagnostic: "bm,bn" for grouped launches without BN partials
+    if (force && groups > 2 && !(d->flags & PC_F_BNPART)) {
+        int bm = 0, bn = 0;
+        if (sscanf(force, "%d,%d", &bm, &bn) == 2) { c.bm = bm; c.bn = bn; c.wm = (bm == 64 && bn == 128) ? 1 : (bn == 32 ? 4 : 2); }
+    }
+    if (d->flags & PC_F_NFAST) {
+        // n-fastest rows: a tile should hold whole groups of N samples of consecutive w so its tap box is tight;
+        // when Wq*N is not a multiple of 128 use 64-row tiles (28 w x 16 samples = 7 tiles of 64, none straddles a row)
+        const long long per_row = (long long)d->Wq * (d->N / groups);
+        if (per_row % 128 != 0 && per_row % 64 == 0) { c.bm = 64; c.bn = d->Co >= 128 ? 128 : 64; c.wm = d->Co >= 128 ? 1 : 2; }
+    }
+    return c;
+}
+
 }  // namespace
+
+// Host-only accounting of the multiply-accumulates one pc_conv_fwd launch performs (no GPU call).  It walks the launch's tiles
+// with the kernel's own row order (conv_gemm_glds_kernel: rinfo / amask / tap box) and counts, per tile, the K the block's loop
+// really walks.  out[0] = MACs ISSUED to the matrix cores (whole BM x BN tiles, what an MFMA instruction counter sees),
+// out[1] = MACs EXECUTED on real outputs (real rows x real columns x the tile's K: padding taps INSIDE the tap box included),
+// out[2] = VALID MACs (taps that read inside the volume only, real channels), out[3] = blocks, out[4] = BM, out[5] = BN,
+// out[6] = 1 if the LDS-DMA kernel (tap box) runs, 0 for the register-staged kernel (flattened K, no tap skipping).
+// ci_real / co_real: channels that are not padding (0 = Ci / Co).
+extern "C" int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, double* out) {
+    PC_CHECK_ARG(d && out, "pc_conv_work: null pointer");
+    const int groups = d->groups > 0 ? d->groups : 1;
+    PC_CHECK_ARG(d->N % groups == 0, "pc_conv_work: N %% groups");
+    const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    const TileCfg c = launch_tile(d, groups);
+    if (ci_real <= 0) ci_real = d->Ci;
+    if (co_real <= 0) co_real = d->Co;
+    const bool small_taps = d->ntap[0] <= 10 && d->ntap[1] <= 10 && d->ntap[2] <= 10;
+    static const int no_glds = getenv("PICONS_CONV_NO_GLDS") ? atoi(getenv("PICONS_CONV_NO_GLDS")) : 0;
+    static const int no_tap4 = getenv("PICONS_CONV_NO_TAP4") ? atoi(getenv("PICONS_CONV_NO_TAP4")) : 0;
+    const bool tap4 = c.bm == 128 && c.bn == 64 && d->Ci == 4 && !no_glds && !no_tap4 && small_taps;
+    const bool glds = tap4 || (d->Ci % BK == 0 && !no_glds && small_taps);
+    const int64_t mtiles = cdiv(Mg, c.bm), ntiles = cdiv(d->Co, c.bn);
+    const int ng = d->N / groups;
+    const int I[3] = {d->Ti, d->Hi, d->Wi};
+    double issued = 0, executed = 0, valid = 0;
+    const int Kflat = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Ci;
+    for (int g = 0; g < groups; ++g)
+        for (int64_t lt = 0; lt < mtiles; ++lt) {
+            unsigned box[3] = {0, 0, 0};
+            int64_t rows = 0;
+            double vtaps = 0;
+            for (int r = 0; r < c.bm; ++r) {
+                const int64_t lm = lt * c.bm + r;
+                if (lm >= Mg) break;
+                ++rows;
+                int64_t m = (int64_t)g * Mg + lm;
+                if (d->flags & PC_F_NFAST) m = lm / ng;
+                const int q[3] = {(int)((m / ((int64_t)d->Wq * d->Hq)) % d->Tq), (int)((m / d->Wq) % d->Hq), (int)(m % d->Wq)};
+                int nv[3];
+                for (int k = 0; k < 3; ++k) {
+                    nv[k] = 0;
+                    const int base = q[k] * d->istr[k] + d->ioff0[k];
+                    for (int a = 0; a < d->ntap[k]; ++a)
+                        if ((unsigned)(base + a * d->istep[k]) < (unsigned)I[k]) { box[k] |= 1u << a; ++nv[k]; }
+                }
+                vtaps += (double)nv[0] * nv[1] * nv[2];
+            }
+            double Ktile, Kreal;                     // K the block walks (kernel channels) / the same in real channels
+            if (glds) {
+                int ext[3];
+                bool any = box[0] && box[1] && box[2];
+                for (int k = 0; k < 3; ++k) ext[k] = any ? (32 - __builtin_clz(box[k])) - __builtin_ctz(box[k]) : 0;
+                const double taps = (double)ext[0] * ext[1] * ext[2];
+                if (tap4) {                          // 8 taps per chunk; with PC_F_CI3 three MFMAs per 16-byte piece instead of four
+                    const double ch = (d->flags & PC_F_CI3) ? 3.0 : 4.0;
+                    Ktile = ceil(taps / 8.0) * 8.0 * ch;
+                    Kreal = taps * ci_real;
+                } else {
+                    Ktile = taps * d->Ci;
+                    Kreal = taps * ci_real;
+                }
+            } else {
+                Ktile = (double)cdiv(Kflat, BK) * BK;
+                Kreal = (double)d->ntap[0] * d->ntap[1] * d->ntap[2] * ci_real;
+            }
+            issued += (double)c.bm * c.bn * ntiles * Ktile;
+            executed += (double)rows * co_real * Kreal;
+            valid += vtaps * ci_real * co_real;
+        }
+    out[0] = issued; out[1] = executed; out[2] = valid; out[3] = (double)groups * mtiles * ntiles; out[4] = c.bm; out[5] = c.bn; out[6] = glds ? 1.0 : 0.0;
+    return PC_OK;
+}
 
 extern "C" int pc_conv_bnpart_rows(const pc_conv_desc* d) {
     const int groups = d->groups > 0 ? d->groups : 1;
@@ -721,18 +811,7 @@ static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, con
     k.M = (int)M; k.groups = groups; k.Mg = (int)(M / groups);
     static const int scalar_epi = getenv("PICONS_CONV_SCALAR_EPI") ? atoi(getenv("PICONS_CONV_SCALAR_EPI")) : 0;
     k.act = d->act; k.flags = (d->flags & ~F_SCALAR_EPI) | (scalar_epi ? F_SCALAR_EPI : 0); k.act_c0 = d->act_c0; k.wgstride = d->wgstride; k.bgstride = d->bgstride;
-    TileCfg c = choose_tile(k.Mg, groups, d->Co, d->Ci);
-    static const char* force = getenv("PICONS_CONV_TILE");      // diagnostic: "bm,bn" for grouped launches without BN partials
-    if (force && groups > 2 && !(d->flags & PC_F_BNPART)) {
-        int bm = 0, bn = 0;
-        if (sscanf(force, "%d,%d", &bm, &bn) == 2) { c.bm = bm; c.bn = bn; c.wm = (bm == 64 && bn == 128) ? 1 : (bn == 32 ? 4 : 2); }
-    }
-    if (d->flags & PC_F_NFAST) {
-        // n-fastest rows: a tile should hold whole groups of N samples of consecutive w so its tap box is tight;
-        // when Wq*N is not a multiple of 128 use 64-row tiles (28 w x 16 samples = 7 tiles of 64, none straddles a row)
-        const long long per_row = (long long)d->Wq * (d->N / groups);
-        if (per_row % 128 != 0 && per_row % 64 == 0) { c.bm = 64; c.bn = d->Co >= 128 ? 128 : 64; c.wm = d->Co >= 128 ? 1 : 2; }
-    }
+    const TileCfg c = launch_tile(d, groups);
     if (c.bm == 64 && c.bn == 128) return launch_conv<64, 128, 1, 4>(k, s);
     if (c.bm == 128 && c.bn == 128) return launch_conv<128, 128, 2, 2>(k, s);
     if (c.bm == 128 && c.bn == 64) return launch_conv<128, 64, 2, 2>(k, s);
@@ -1178,7 +1257,123 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     }
 }
 
+// Which kernel family pc_conv_wgrad gives a problem to -- ONE classification for pc_conv_wgrad, pc_conv_wgrad_multi and the host-side
+// work accounting (pc_wgrad_work), so the A/B switches mean the same everywhere and the fp32 atomic sum order the goldens were
+// made with cannot drift between copies of the predicates.
+enum WgRoute { WG_STEM, WG_ROW3, WG_ROW9, WG_GENERIC };
+inline bool wg_ablate() { static const bool a = getenv("PICONS_WGRAD_ABLATE") != nullptr; return a; }
+inline WgRoute wg_route(const pc_wgrad_desc* d) {
+    static const int s4_env = getenv("PICONS_WGRAD_STEM") ? atoi(getenv("PICONS_WGRAD_STEM")) : 1;
+    static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
+    if (s4_env && d->Cs == 4 && d->lds % 4 == 0 && d->KW == 7 && d->ntap[2] == 7 && d->wk0[2] == 0 && d->istr[2] == 2 && d->ntap[1] == 7 &&
+        d->ntap[0] <= 10 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 && d->Td == 0 && d->nbatch <= 1 && d->splitk >= 0 &&
+        d->Wq % 28 == 0 && !wg_ablate())
+        return WG_STEM;
+    const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
+    const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
+    const bool row3 = d->KW == 3 && padw == 1 && d->Wq == d->Ws && (csb64 || csb32) && d->Ws % 28 == 0 && nprob == 1 && d->splitk >= 0;
+    const bool row9 = d->KW == 9 && padw == 0 && d->Wq == d->Ws - 8 && d->Wq == 20 && csb64 && d->Tq == 1 && d->Hq == 1;   // spectral forms
+    if (row_env && !wg_ablate() && d->Td == 0 && d->ntap[2] == d->KW && d->wk0[2] == 0 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 &&
+        d->istep[2] == 1 && (row3 || row9))
+        return row9 ? WG_ROW9 : WG_ROW3;
+    return WG_GENERIC;
+}
+// 256-column tiles with 16-position chunks for the long-K launches of the generic kernel (PICONS_WGRAD_WIDE bit 0: 128-row, bit 1: 64-row tiles)
+inline bool wg_wide(const pc_wgrad_desc* d, bool small_m) {
+    static const int wide_env = getenv("PICONS_WGRAD_WIDE") ? atoi(getenv("PICONS_WGRAD_WIDE")) : 3;
+    const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+    const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+    return !wg_ablate() && Ntot >= 512 && (((wide_env & 1) && !small_m) || ((wide_env & 2) && small_m)) && P >= 65536;
+}
+// row-segment kernel geometry (shared by the launch and the accounting)
+struct Row3Geo { bool csb64, small_m; int bkp, bm, csb; };
+inline Row3Geo wg_row_geo(const pc_wgrad_desc* d, bool row9) {
+    Row3Geo r;
+    r.csb64 = d->Cs % 64 == 0;
+    // 64-row tiles also when they pad at least 20 % less than 128-row tiles (192 = 3 x 64 vs 2 x 128)
+    r.small_m = d->Cd <= 64 || row9 || (r.csb64 && cdiv(d->Cd, 64) * 64 * 5 <= cdiv(d->Cd, 128) * 128 * 4);
+    r.bkp = row9 ? 20 : ((r.csb64 && r.small_m && d->Ws % 56 == 0) ? 56 : 28);
+    r.bm = r.small_m ? 64 : 128;
+    r.csb = r.csb64 ? 64 : 32;
+    return r;
+}
+// the generic kernel's launches for a problem: up to two row ranges [lo, hi) with 64- or 128-row tiles
+struct WgSplit { int n; int lo[2], hi[2]; bool small_m[2]; };
+inline WgSplit wg_generic_split(const pc_wgrad_desc* d) {
+    // 128-row tiles for the bulk.  When the grid is many rounds deep without split-K (PrimaryCaps: 544 = 4*128 + 32
+    // rows x 527 column tiles), a remainder of at most 64 channels gets its own launch with 64-row tiles instead
+    // of a padded 128-row tile (4.98 vs 5.23 ms); small problems lose more to the second launch than they save
+    const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+    const int full = d->Cd / 128 * 128, rem = d->Cd - full;
+    const bool deep = (int64_t)(full / 128) * cdiv(Ntot, 128) * (d->nbatch > 1 ? d->nbatch : 1) >= 1024;
+    // 64-row tiles run at ~0.88 of the 128-row tiles' rate: take them when they pad that much less (192 = 3 x 64 vs 2 x 128)
+    const double pad128 = (double)cdiv(d->Cd, 128) * 128, pad64 = (double)cdiv(d->Cd, 64) * 64;
+    WgSplit w; w.n = 1; w.lo[0] = 0; w.hi[0] = d->Cd; w.small_m[0] = false;
+    if (d->Cd <= 64) w.small_m[0] = true;
+    else if (rem != 0 && rem <= 64 && deep) { w.n = 2; w.hi[0] = full; w.lo[1] = full; w.hi[1] = d->Cd; w.small_m[1] = true; }
+    else if (pad128 > 1.15 * pad64) w.small_m[0] = true;
+    return w;
+}
+
 }  // namespace
+
+// Host-only work accounting of one pc_conv_wgrad call (no GPU call), see pc_conv_work.  out[5]: multiply-accumulates ISSUED to
+// the matrix cores (whole tiles, padded chunks; chunks the row-segment / stem kernels never multiply because their (kt, kh) tap
+// reads outside the volume are not counted), EXECUTED on real rows x real columns of the same chunks, VALID (non-padding source
+// positions only), the route (0 stem, 1 row-segment 3 taps, 2 row-segment 9 taps, 3 generic split-K) and the number of kernel launches.
+extern "C" int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, double* out) {
+    PC_CHECK_ARG(d && out, "pc_wgrad_work: null pointer");
+    if (cd_real <= 0) cd_real = d->Cd;
+    if (cs_real <= 0) cs_real = d->Cs;
+    const int nb = d->nbatch > 1 ? d->nbatch : 1;
+    const int Q[3] = {d->Tq, d->Hq, d->Wq}, I[3] = {d->Ts, d->Hs, d->Ws};
+    // per dimension and tap: lattice points whose source position exists
+    double V[3][16] = {}, Vsum[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+        PC_CHECK_ARG(d->ntap[k] >= 1 && d->ntap[k] <= 16, "pc_wgrad_work: ntap out of range");
+        for (int a = 0; a < d->ntap[k]; ++a) {
+            int cnt = 0;
+            for (int q = 0; q < Q[k]; ++q) cnt += (unsigned)(q * d->istr[k] + d->ioff0[k] + a * d->istep[k]) < (unsigned)I[k];
+            V[k][a] = cnt; Vsum[k] += cnt;
+        }
+    }
+    const double valid = (double)d->N * nb * Vsum[0] * Vsum[1] * Vsum[2] * cd_real * cs_real;
+    const WgRoute route = wg_route(d);
+    double issued = 0, executed = 0, launches = 1;
+    if (route == WG_STEM) {
+        const int nseg = d->Wq / 28, mt = cdiv(d->Cd, 64);
+        static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
+        const bool p3 = (d->flags & PC_WG_CS3) && pack3;
+        const double nacc = p3 ? (7 * 7 * 3 + 31) / 32 : 7;
+        for (int a = 0; a < d->ntap[0]; ++a) {
+            const double chunks = (double)d->N * V[0][a] * d->Hq * nseg;          // every kh of the kt tap, all w
+            issued += chunks * 28.0 * (mt * 64.0) * nacc * 32.0;
+            executed += chunks * 28.0 * cd_real * (7.0 * 7.0 * cs_real);
+        }
+    } else if (route == WG_ROW3 || route == WG_ROW9) {
+        const Row3Geo r = wg_row_geo(d, route == WG_ROW9);
+        const int nseg = d->Wq / r.bkp, mt = cdiv(d->Cd, r.bm), ncs = d->Cs / r.csb;
+        for (int a = 0; a < d->ntap[0]; ++a)
+            for (int b = 0; b < d->ntap[1]; ++b) {
+                const double chunks = (double)d->N * nb * V[0][a] * V[1][b] * nseg;
+                issued += chunks * r.bkp * (mt * (double)r.bm) * ((double)d->KW * r.csb * ncs);
+                executed += chunks * r.bkp * cd_real * ((double)d->KW * cs_real);
+            }
+    } else {
+        const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
+        const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
+        const WgSplit w = wg_generic_split(d);
+        launches = w.n;
+        for (int i = 0; i < w.n; ++i) {
+            const bool wide = wg_wide(d, w.small_m[i]);
+            const int bm = w.small_m[i] ? 64 : 128, bn = wide ? 256 : 128, kb = wide ? 16 : BK;
+            issued += (double)cdiv(P, kb) * kb * ((double)cdiv(w.hi[i] - w.lo[i], bm) * bm) * ((double)cdiv(Ntot, bn) * bn) * nb;
+        }
+        executed = (double)P * nb * cd_real * ((double)d->ntap[0] * d->ntap[1] * d->ntap[2] * cs_real);
+    }
+    out[0] = issued; out[1] = executed; out[2] = valid; out[3] = (double)route; out[4] = launches;
+    return PC_OK;
+}
 
 extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s_) {
     hipStream_t s = (hipStream_t)s_;
@@ -1210,10 +1405,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     // split-K fills `rounds` rounds of resident-block slots: one round measured best on the step (fewer atomics per weight;
     // the second lane's launches fill what a single round leaves idle)
     static const double rounds = getenv("PICONS_WGRAD_ROUNDS") ? atof(getenv("PICONS_WGRAD_ROUNDS")) : 1.0;
-    static const int s4_env = getenv("PICONS_WGRAD_STEM") ? atoi(getenv("PICONS_WGRAD_STEM")) : 1;
-    if (s4_env && d->Cs == 4 && d->lds % 4 == 0 && d->KW == 7 && d->ntap[2] == 7 && d->wk0[2] == 0 && d->istr[2] == 2 && d->ntap[1] == 7 &&
-        d->ntap[0] <= 10 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 && d->Td == 0 && d->nbatch <= 1 && d->splitk >= 0 &&
-        d->Wq % 28 == 0 && !getenv("PICONS_WGRAD_ABLATE")) {
+    const WgRoute route = wg_route(d);
+    if (route == WG_STEM) {
         Wg4K q;
         q.D = D; q.S = S; q.g = g;
         q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Wq; q.Cd = d->Cd; q.ldd = d->ldd; q.lds = d->lds;
@@ -1247,13 +1440,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         PC_CHECK_LAUNCH("wgrad4_kernel");
         return PC_OK;
     }
-    static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
-    const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
-    const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
-    const bool row3 = d->KW == 3 && padw == 1 && d->Wq == d->Ws && (csb64 || csb32) && d->Ws % 28 == 0 && nprob == 1 && d->splitk >= 0;
-    const bool row9 = d->KW == 9 && padw == 0 && d->Wq == d->Ws - 8 && d->Wq == 20 && csb64 && d->Tq == 1 && d->Hq == 1;   // spectral forms
-    if (row_env && !abl && d->Td == 0 && d->ntap[2] == d->KW && d->wk0[2] == 0 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 &&
-        d->istep[2] == 1 && (row3 || row9)) {
+    if (route == WG_ROW3 || route == WG_ROW9) {
+        const bool row9 = route == WG_ROW9;
+        const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
         Wg3K q;
         q.D = D; q.S = S; q.g = g;
         q.N = d->N; q.T = d->Tq; q.H = d->Hq; q.W = d->Wq; q.Cd = d->Cd; q.ldd = d->ldd; q.Cs = d->Cs; q.lds = d->lds;
@@ -1261,9 +1450,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.ntap_t = d->ntap[0]; q.ntap_h = d->ntap[1]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
         q.taps_full = d->KT * d->KH * d->KW;
         q.Wsw = d->Ws; q.padw = padw; q.nprob = nprob; q.dbs = d->dbstride; q.sbs = d->sbstride; q.gbs = d->gbstride;
-        // 64-row tiles also when they pad at least 20 % less than 128-row tiles (192 = 3 x 64 vs 2 x 128)
-        const bool small_m = d->Cd <= 64 || row9 || (csb64 && cdiv(d->Cd, 64) * 64 * 5 <= cdiv(d->Cd, 128) * 128 * 4);
-        const int bkp = row9 ? 20 : ((csb64 && small_m && d->Ws % 56 == 0) ? 56 : 28);
+        const Row3Geo geo = wg_row_geo(d, row9);
+        const bool csb64 = geo.csb64, small_m = geo.small_m;
+        const int bkp = geo.bkp;
         q.nseg = d->Wq / bkp;
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
         q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / (csb64 ? 64 : 32);
@@ -1284,12 +1473,11 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         PC_CHECK_LAUNCH("wgrad3_kernel");
         return PC_OK;
     }
-    static const int wide_env = getenv("PICONS_WGRAD_WIDE") ? atoi(getenv("PICONS_WGRAD_WIDE")) : 3;   // bit 0: 128-row, bit 1: 64-row launches
     auto launch = [&](int m_lo, int m_hi, bool small_m) {
         // 256-column tiles with 16-position chunks for the long-K launches: 17-25 % less tile traffic per FLOP.  The kernel
         // is bound by the LDS-DMA fill rate, not by the MFMA loop (fetch ablation: 148 TF/s without the fetch, 113-118 with either
         // operand tile alone, 103 with both): 3x3x3 128->128 @112^2 103 -> 115 TF/s, the 64-channel layers 87 -> 92
-        const bool wide = !abl && k.Ntot >= 512 && ((wide_env & 1) && !small_m || (wide_env & 2) && small_m) && P >= 65536;
+        const bool wide = wg_wide(d, small_m);
         const int bm = small_m ? 64 : 128, bn = wide ? 256 : 128;
         k.nchunks = cdiv(P, wide ? 16 : BK);
         const int mt = cdiv(m_hi - m_lo, bm), ntl = cdiv(k.Ntot, bn);
@@ -1334,17 +1522,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         else if (wide) hipLaunchKernelGGL((wgrad_kernel<128, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);
     };
-    // 128-row tiles for the bulk.  When the grid is many rounds deep without split-K (PrimaryCaps: 544 = 4*128 + 32
-    // rows x 527 column tiles), a remainder of at most 64 channels gets its own launch with 64-row tiles instead
-    // of a padded 128-row tile (4.98 vs 5.23 ms); small problems lose more to the second launch than they save
-    const int full = d->Cd / 128 * 128, rem = d->Cd - full;
-    const bool deep = (int64_t)(full / 128) * cdiv(k.Ntot, 128) * (d->nbatch > 1 ? d->nbatch : 1) >= 1024;
-    // 64-row tiles run at ~0.88 of the 128-row tiles' rate: take them when they pad that much less (192 = 3 x 64 vs 2 x 128)
-    const double pad128 = (double)cdiv(d->Cd, 128) * 128, pad64 = (double)cdiv(d->Cd, 64) * 64;
-    if (d->Cd <= 64) launch(0, d->Cd, true);
-    else if (rem != 0 && rem <= 64 && deep) { launch(0, full, false); launch(full, d->Cd, true); }
-    else if (pad128 > 1.15 * pad64) launch(0, d->Cd, true);
-    else launch(0, d->Cd, false);
+    const WgSplit w = wg_generic_split(d);
+    for (int i = 0; i < w.n; ++i) launch(w.lo[i], w.hi[i], w.small_m[i]);
     PC_CHECK_LAUNCH("wgrad_kernel");
     return PC_OK;
 }
@@ -1355,18 +1534,11 @@ namespace {
 
 // the problems pc_conv_wgrad would give to the generic split-K kernel (not the stem / row-segment kernels, not a forced split)
 bool wg_is_generic(const pc_wgrad_desc* d) {
-    if (getenv("PICONS_WGRAD_ABLATE")) return false;
-    const int padw = -d->ioff0[2], nprob = d->nbatch > 1 ? d->nbatch : 1;
-    const bool stem = d->Cs == 4 && d->KW == 7;
-    const bool csb64 = d->Cs % 64 == 0, csb32 = d->Cs % 32 == 0 && d->Cd > 64;
-    const bool row3 = d->KW == 3 && padw == 1 && d->Wq == d->Ws && (csb64 || csb32) && d->Ws % 28 == 0 && nprob == 1 && d->splitk >= 0;
-    const bool row9 = d->KW == 9 && padw == 0 && d->Wq == d->Ws - 8 && d->Wq == 20 && csb64 && d->Tq == 1 && d->Hq == 1;
-    const bool rowseg = d->Td == 0 && d->ntap[2] == d->KW && d->wk0[2] == 0 && d->istr[2] == 1 && d->istep[0] == 1 && d->istep[1] == 1 && d->istep[2] == 1 &&
-                        (row3 || row9);
-    const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
-    const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
-    const bool wide = Ntot >= 512 && P >= 65536;          // long-K launches keep their 256-column tiles
-    return !stem && !rowseg && !wide && d->splitk == 0;
+    if (wg_ablate() || wg_route(d) != WG_GENERIC || d->splitk != 0) return false;
+    const WgSplit w = wg_generic_split(d);
+    for (int i = 0; i < w.n; ++i)
+        if (wg_wide(d, w.small_m[i])) return false;          // long-K launches keep their 256-column tiles
+    return true;
 }
 
 int wg_fill(const pc_wgrad_desc* d, const float* D, const float* S, float* g, WgK& k) {

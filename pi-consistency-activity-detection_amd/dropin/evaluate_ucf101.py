@@ -45,15 +45,17 @@ def iou(split, argv=None):
     args = parser.parse_args(argv)
     random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
 
-    os.environ.setdefault("PICONS_SYNTHETIC", "1")       # also lets CapsNet() start without rgb_charades.pt: every checkpoint
-                                                         # loaded below overwrites the whole state anyway
+    synthetic_mode = os.environ.get("PICONS_SYNTHETIC", "1") == "1"      # read only: the process environment is not written to
     jhmdb = os.environ.get("PICONS_DATASET", "ucf101") == "jhmdb"
     n_classes = 21 if jhmdb else 24
     if jhmdb:
         from models.capsules_jhmdb_semi_sup_pa import CapsNet
     else:
         from models.capsules_ucf101 import CapsNet
-    model = CapsNet().cuda()
+    # every checkpoint loaded below overwrites the whole state, so in synthetic mode a missing rgb_charades.pt (no network) is passed
+    # over EXPLICITLY with pt_path=None; with real data CapsNet() raises for a missing trunk file like the reference does
+    pt_path = '../weights/rgb_charades.pt'
+    model = (CapsNet(pt_path=None) if (synthetic_mode and not os.path.exists(pt_path)) else CapsNet()).cuda()
     clip_batch_size = 14
     model_names, fmap_best, vmap_best, results = [], [], [], []
     files = sorted(glob.glob(osp.join(args.ckpt, 'best_model_' + split + '*.pth')))

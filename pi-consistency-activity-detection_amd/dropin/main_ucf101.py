@@ -262,7 +262,7 @@ def run(args):
     hw = int(os.environ.get("PICONS_HW", "224"))
     fused = os.environ.get("PICONS_FUSED", "1") != "0"
     steps = int(os.environ.get("PICONS_STEPS", "4"))
-    mode = os.environ.setdefault("PICONS_SYNTHETIC", "1")
+    mode = os.environ.get("PICONS_SYNTHETIC", "1")          # read only: the process environment is not written to
     if mode not in ("1", "u8"):
         raise RuntimeError("real UCF101/JHMDB loaders need skvideo/cv2 + the dataset, neither is available here; set PICONS_SYNTHETIC=1 (or u8)")
     n = args.bs // 2
@@ -272,7 +272,14 @@ def run(args):
     val_loader = SyntheticLoader(args.bs, True, 1, rank, NUM_CLASSES, hw, 5)
     print(len(labeled_loader), len(unlabeled_loader), len(val_loader))
 
-    model = CapsNet(num_classes=NUM_CLASSES, hw=hw, seed=args.seed) if NUM_CLASSES != 24 or hw != 224 else CapsNet(seed=args.seed)
+    # the reference's CapsNet() loads ../weights/rgb_charades.pt and raises without it (capsules_ucf101.py:344).  In synthetic mode a
+    # missing file is expected (no network for the download): pt_path=None is passed EXPLICITLY, so a caller who supplies the weights, or
+    # constructs CapsNet() himself, still gets the hard error for a wrong path
+    pt_path = '../weights/rgb_charades.pt'
+    if not os.path.exists(pt_path):
+        print("WARNING: %s not found; synthetic mode (PICONS_SYNTHETIC=%s): the I3D trunk keeps its random initialisation" % (pt_path, mode), file=sys.stderr)
+        pt_path = None
+    model = CapsNet(pt_path=pt_path, num_classes=NUM_CLASSES, hw=hw, seed=args.seed) if NUM_CLASSES != 24 or hw != 224 else CapsNet(pt_path=pt_path, seed=args.seed)
     model = model.cuda()
     criterion_cls = SpreadLoss(num_class=NUM_CLASSES, m_min=0.2, m_max=0.9)
     criterion_seg_1 = nn.BCEWithLogitsLoss()

@@ -145,6 +145,8 @@ class Plan:
         self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
         self.alg_flops = {}       # list name -> conv FLOPs as the layer's own formulation counts them (all taps, padding included)
         self.issued = {}          # (list name, op kind) -> FLOPs the emitted (trimmed) descriptors multiply, real channel counts
+        self.work = {}            # (list name, "mfma" | "executed" | "valid") -> conv / dgrad FLOPs as the kernels run them (pc_conv_work)
+        self.op_work = {}         # id(op's int list) -> pc_conv_work / pc_wgrad_work of that launch
 
     # ------------------------------------------------------------------ memory
     def alloc(self, nfloats, name=""):
@@ -190,7 +192,9 @@ class Plan:
     def emit(self, kind, i=(), f=(), p=(), l=(), lst=None, lane=None):
         if lane is None:
             lane = self.lane if lst in (None, self.cur) else 0
-        self.lists[lst or self.cur].append((kind, list(i), list(f), list(p), list(l), lane))
+        il = list(i)
+        self.lists[lst or self.cur].append((kind, il, list(f), list(p), list(l), lane))
+        return il
 
     def fork(self, mask=None, src=0):
         """The lanes in `mask` (default: the branch lanes) wait for everything enqueued so far on lane `src` (no-op for a
@@ -336,16 +340,23 @@ class Plan:
         self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + (_conv_flops(d) if alg is None else alg)
         t = D.trim_conv(d)
         self.issued[(self.cur, capi.OP_CONV)] = self.issued.get((self.cur, capi.OP_CONV), 0) + _conv_flops(t)
-        self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+        w = conv_work(t)
+        for key, v in (("mfma", w["issued"]), ("executed", w["executed"]), ("valid", w["valid"])):
+            self.work[(self.cur, key)] = self.work.get((self.cur, key), 0) + 2 * v
+        il = self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+        self.op_work[id(il)] = w          # keyed by the op's own int list (it survives the re-laning of finalize()): tools/launch_table.py
 
     def wgrad_op(self, d, p):
         """Emit a weight-gradient launch and book the FLOPs its (already trimmed) descriptor multiplies.  Inside a wgrad_group the
         launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op."""
         self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
+        w = wgrad_work(d)
+        for key, v in (("wg_mfma", w["issued"]), ("wg_executed", w["executed"]), ("wg_valid", w["valid"])):
+            self.work[(self.cur, key)] = self.work.get((self.cur, key), 0) + 2 * v
         if self.wgrad_collect is not None:
             self.wgrad_collect.append((d, list(p)))
             return
-        self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p)
+        self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p))] = w
 
     def wgrad_group_begin(self):
         """Weight gradients emitted until wgrad_group_end() are held back and leave together at the group's end, on the weight-gradient
@@ -361,7 +372,7 @@ class Plan:
         def emit_all():
             if len(jobs) == 1 or os.environ.get("PICONS_WGRAD_MULTI", "0") == "0":
                 for d, p in jobs:
-                    self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p)
+                    self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p))] = wgrad_work(d)
             else:
                 self.wjobs = getattr(self, "wjobs", [])
                 self.wjobs.append(jobs)
@@ -954,7 +965,7 @@ class Plan:
                     self.wjobs.append(jobs)
                     if os.environ.get("PICONS_WGRAD_MULTI_TAIL", "0") == "0":
                         for d_, p_ in jobs:
-                            self.emit(capi.OP_WGRAD, i=D.flatten(d_, D.WGRAD_FIELDS), p=p_)
+                            self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d_, D.WGRAD_FIELDS), p=p_))] = wgrad_work(d_)
                     else:
                         self.emit(capi.OP_WGRAD_MULTI, i=[len(jobs)], p=[("WJOBS", len(self.wjobs) - 1)])
 
@@ -1175,6 +1186,17 @@ class Plan:
         flush()
         return res
 
+    def conv_flops_executed(self):
+        """Per list, FLOPs of the conv / dgrad launches as the kernels run them (pc_conv_work: the host walks every launch's tiles
+        in the kernel's row order): `mfma` = issued to the matrix cores (whole tiles, what an MFMA instruction counter sees),
+        `executed` = on real output rows x columns over the K each tile's block walks -- taps that are padding for a whole tile are
+        skipped by the kernel and are NOT counted, padding taps inside a tile's tap box are --, `valid` = non-padding MACs only."""
+        return {name: {k: self.work.get((name, k), 0) for k in ("mfma", "executed", "valid")} for name in self.lists}
+
+    def wgrad_flops_executed(self):
+        """The same three counts for the weight-gradient launches (pc_wgrad_work)."""
+        return {name: {k: self.work.get((name, "wg_" + k), 0) for k in ("mfma", "executed", "valid")} for name in self.lists}
+
     def flops(self, only_kind=None):
         """FLOPs ISSUED per list (2*M*N*K of the emitted, tap-trimmed descriptors with the real channel counts -- zero-padding
         taps dropped at descriptor level and padded channels are not work).  only_kind: OP_CONV / OP_WGRAD / None (both)."""
@@ -1192,12 +1214,37 @@ def _conv_flops(d):
     return 2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * d.get("Co_real", d["Co"]) * d.get("Ci_real", d["Ci"]) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
 
 
+def conv_work(d):
+    """pc_conv_work of a (trimmed) conv descriptor dict -> dict(issued, executed, valid [MACs], blocks, bm, bn, glds)."""
+    import ctypes as C
+    out = (C.c_double * 7)()
+    capi.check(capi.lib().pc_conv_work(_cdesc(d), int(d.get("Ci_real", 0)), int(d.get("Co_real", 0)), out))
+    return dict(issued=out[0], executed=out[1], valid=out[2], blocks=int(out[3]), bm=int(out[4]), bn=int(out[5]), glds=bool(out[6]))
+
+
+def _wdesc(d):
+    import ctypes as C
+    st = capi.WgradDesc()
+    for name, ctype in st._fields_:
+        v = d.get(name, 0)
+        setattr(st, name, (C.c_int32 * 3)(*[int(x) for x in v]) if isinstance(v, (list, tuple)) else ctype(v))
+    return C.byref(st)
+
+
+def wgrad_work(d):
+    """pc_wgrad_work of a (trimmed) wgrad descriptor dict -> dict(issued, executed, valid [MACs], route)."""
+    import ctypes as C
+    out = (C.c_double * 5)()
+    capi.check(capi.lib().pc_wgrad_work(_wdesc(d), int(d.get("Cd_real", 0)), int(d.get("Cs_real", 0)), out))
+    return dict(issued=out[0], executed=out[1], valid=out[2], route=int(out[3]), launches=int(out[4]))
+
+
 def _wgrad_flops(d):
     return (2 * d["N"] * d["Tq"] * d["Hq"] * d["Wq"] * d.get("Cd_real", d["Cd"]) * d.get("Cs_real", d["Cs"]) * d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
             * max(1, d.get("nbatch", 0)))
 
 
-# --- workspace sizing mirrors of the C side (kept in sync by tests/test_plan_cpu.py on CPU)
+# --- workspace sizes come from the C side itself (host-only entry points of libpicons.so; tests/test_capi_cpu.py checks the symbol set)
 def _bnpart_rows(d):
     return capi.lib().pc_conv_bnpart_rows(_cdesc(d))
 

@@ -92,7 +92,11 @@ class StepEngine:
         # the step waits for THAT copy only, so the host is enqueueing the next step while the backward and Adam still run
         self.scal_host = torch.empty(20, dtype=torch.float32).pin_memory()
         self.scal_stream = torch.cuda.Stream(device=self.dev)
-        self.scal_event = None
+        # both events are created ONCE and re-recorded every step: dropping a torch event that a busy lane has not reached yet stalls the
+        # host (what dist.GradReducer.launch ran into: 0.7 ms per step)
+        self._loss_done = torch.cuda.Event()
+        self._scal_event = torch.cuda.Event()
+        self.scal_event = None                                # set (to _scal_event) once a step has enqueued the copy
         self.load_state(state if state is not None else synthetic.init_state(seed, num_classes))
 
     # ------------------------------------------------------------------ views
@@ -208,14 +212,12 @@ class StepEngine:
             self.nbt[k] += 2           # two forward passes per step
 
     def _send_scalars(self):
-        cur = torch.cuda.current_stream()
-        done = torch.cuda.Event()
-        done.record(cur)
-        self.scal_stream.wait_event(done)
+        self._loss_done.record(torch.cuda.current_stream())
+        self.scal_stream.wait_event(self._loss_done)
         with torch.cuda.stream(self.scal_stream):
             self.scal_host.copy_(self.aview(self.plan.scalars, 20), non_blocking=True)   # spread_out sits at scalars + 16 (plan.build_loss)
-            self.scal_event = torch.cuda.Event()
-            self.scal_event.record(self.scal_stream)
+            self._scal_event.record(self.scal_stream)
+        self.scal_event = self._scal_event
 
     def read_scalars(self):
         """One packed D2H for the step's loss scalars (replaces the reference's five .item() syncs); the copy was enqueued behind
@@ -229,6 +231,17 @@ class StepEngine:
         a = self.args
         return dict(total=a.wt_loc * loc + a.wt_cls * cls + a.wt_cons * cons, loc=loc, cls=cls, cons=cons,
                     bce=float(s[2]), dice=float(s[3]), l2=float(s[4]), lvar=float(s[5]), lgrad=float(s[6]))
+
+    def synchronize(self):
+        """Wait until everything this engine has enqueued (every lane, the loss read-back stream) has finished.  train_step /
+        run_staged return once the LOSS scalars are on the host -- the backward and Adam may still be running; call this before
+        reading G / P / the running statistics through raw pointers or from another stream, or before stopping a clock."""
+        torch.cuda.current_stream(self.dev).synchronize()
+        for st in self.side:
+            st.synchronize()
+        if self.main is not None:
+            self.main.synchronize()
+        self.scal_stream.synchronize()
 
     def outputs(self):
         """(output (bs,1,8,H,W), flip_op, predicted_action (bs,C)) of the last forward, shuffled order."""
@@ -260,7 +273,9 @@ class StepEngine:
 
     def _run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True):
         """One full step on the minibatch already staged in HBM: fwd x2 + losses + bwd (+ all-reduce) +
-        Adam + the packed loss read-back.  collect=False leaves the timing events of a timed step pending (the caller
+        Adam + the packed loss read-back.  RETURNS WITH THE BACKWARD AND ADAM STILL IN FLIGHT: the only host wait is for the loss
+        scalars' copy, which is final before the backward starts.  Stream-ordered consumers (the next step, torch ops on the current
+        stream) need nothing; anything else calls synchronize() first.  collect=False leaves the timing events of a timed step pending (the caller
         reads them with collect_timing() later, e.g. after its timed region: reading 212 events costs ~0.4 ms of host time)."""
         self.forward_backward(epoch, wt_ramp, reducer, timed_kind)
         gscale = 1.0

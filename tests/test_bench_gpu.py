@@ -43,12 +43,18 @@ def test_bench_line_contract():
     assert r["launches_per_step"] > 50 and abs(r["avg_launch_ms"] * r["launches_per_step"] - r["kernel_ms_per_step"]) < 1e-6 * r["kernel_ms_per_step"]
     assert r["kernel_ms_per_step"] < j["ms_per_step"]                                    # event time of the conv kernels fits inside the step
     assert r["traffic"] is None or r["traffic"] > 1e6
+    # the numerator is what the kernels execute (host walk of every launch's tiles); the older, larger bookings stay beside it
+    assert r["frac_valid"] <= r["frac"] <= r["frac_mfma_issued"] < 1.0 and r["frac"] < r["frac_descriptor_counted"] < r["frac_reference_counted"]
+    st = j["staged"]                                        # the same step with per-step input staging inside the timed region
+    assert st["unit"] == "clips/s" and st["steps"] == 3 and abs(st["value"] - 8 * 1000.0 / st["ms_per_step"]) < 1e-6 * st["value"]
+    assert st["ms_per_step"] < 1.5 * j["ms_per_step"] + 5.0 and st["loss_total"] == st["loss_total"]
+    assert j["ranks_observed"] == 1 and "resident" in j["config"]["inputs"]
     assert all(k in j["loss"] for k in ("total", "loc", "cls", "cons")) and j["cpu_baseline"] is None
 
 
 def test_bench_without_timing_leg_is_not_slower():
-    a = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing")
-    assert a["roofline"] is None and a["ms_per_step"] < 60.0
+    a = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-kernel-timing", "--resident-inputs")
+    assert a["roofline"] is None and a["ms_per_step"] < 60.0 and a["staged"] is None
 
 
 def test_bench_dp_schedule_through_rccl_on_one_rank():

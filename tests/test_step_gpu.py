@@ -3,6 +3,7 @@
    reduced frame size the oracle finishes in seconds, every parameter gradient included;
  - against THE REFERENCE'S OWN outputs (tests/golden/step_*.npz) at the full 8x224x224 size.
 Bars (BASELINE.json north_star): logits and localisation masks 1e-3, loss scalars 1e-4 (fp32)."""
+import ast
 import os
 
 import numpy as np
@@ -129,7 +130,7 @@ def test_step_vs_reference_golden_full_size(golden_dir, tag):
     S = np.load(os.path.join(golden_dir, tag + ".npz"))
     ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
     bs = int(S["bs"]) if "bs" in S.files else 2
-    akw = dict(eval(str(S["args"])))
+    akw = dict(ast.literal_eval(str(S["args"])))
     jh = akw.pop("dataset", "ucf101") == "jhmdb"
     for k in ("wt_seg",):
         akw.pop(k, None)
@@ -214,7 +215,7 @@ def test_step_reference_init_vs_reference_fp64(golden_dir):
     S = np.load(os.path.join(golden_dir, "step_refinit_bv5.npz"))
     assert int(S["conditioned"]) == 0
     bs, stepid, epoch = int(S["bs"]), int(S["stepid"]), int(S["epoch"])
-    akw = dict(eval(str(S["args"])))
+    akw = dict(ast.literal_eval(str(S["args"])))
     akw.pop("dataset", None)
     eng = pstep.StepEngine(pstep.default_args(**akw), bs=bs, hw=224, state=synthetic.init_state(47, 24, conditioned=False))
     lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=stepid)

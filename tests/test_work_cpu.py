@@ -1,0 +1,79 @@
+"""CPU: the host-side work accounting behind bench.py's roofline numerator (pc_conv_work / pc_wgrad_work, no GPU call).
+`valid` is checked against an independent count (a torch convolution of ones), `executed` against the closed form for
+launches whose tiles lie inside one t-slice, and the orderings issued >= executed >= valid always."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from picons_amd import capi, desc as D, step as pstep
+from picons_amd.plan import Plan, conv_work, wgrad_work, _conv_flops, _wgrad_flops
+
+
+def _valid_by_torch(N, thw, Ci, Co, k, stride, pad):
+    x = torch.ones(1, 1, *thw)
+    w = torch.ones(1, 1, *k)
+    return float(F.conv3d(x, w, stride=stride, padding=pad).sum()) * N * Ci * Co
+
+
+def test_valid_macs_match_a_convolution_of_ones():
+    for N, thw, Ci, Co, k, s in [(4, (4, 28, 28), 64, 64, (3, 3, 3), (1, 1, 1)), (2, (2, 14, 14), 32, 96, (3, 3, 3), (1, 1, 1)),
+                                 (2, (1, 28, 28), 160, 320, (1, 3, 3), (1, 1, 1)), (2, (8, 56, 56), 4, 64, (7, 7, 7), (2, 2, 2))]:
+        pad = tuple(x // 2 for x in k)
+        othw = tuple((thw[i] + 2 * pad[i] - k[i]) // s[i] + 1 for i in range(3))
+        d = D.trim_conv(D.conv_fwd(N, thw, Ci, Ci, Co, Co, k, s, pad, othw, groups=2))
+        w = conv_work(d)
+        want = _valid_by_torch(N, thw, Ci, Co, k, s, pad)
+        assert w["valid"] == want, (thw, k, w, want)
+        assert w["issued"] >= w["executed"] >= w["valid"] > 0
+        assert 2 * w["executed"] <= _conv_flops(d)
+        wd = D.trim_wgrad(D.wgrad(N, othw, Co, Co, thw, Ci, Ci, k, s, pad))
+        ww = wgrad_work(wd)
+        assert ww["valid"] == want and ww["issued"] >= ww["executed"] >= ww["valid"]
+        assert 2 * ww["executed"] <= _wgrad_flops(wd)
+
+
+def test_tap_box_of_tiles_inside_one_t_slice():
+    """conv112 (64 -> 64, 3x3x3, 4x112x112, 16 clip-passes in 2 groups): 128-row tiles never straddle a t-slice (112*112 = 98 * 128)
+    and always span two image rows, so each tile walks 2 of 3 kt taps at t = 0, 3 and all 27 taps otherwise: 10/12 of the descriptor."""
+    d = D.trim_conv(D.conv_fwd(16, (4, 112, 112), 64, 64, 64, 64, (3, 3, 3), (1, 1, 1), (1, 1, 1), (4, 112, 112), groups=2))
+    w = conv_work(d)
+    assert (w["bm"], w["bn"], w["glds"]) == (128, 64, True) and w["blocks"] == 6272
+    assert 2 * w["executed"] * 12 == _conv_flops(d) * 10
+    assert w["issued"] == w["executed"]                       # no row / column padding on this shape
+    # T = 2 (Conv3d_2c): every tile sees 2 of 3 kt taps
+    d = D.trim_conv(D.conv_fwd(16, (2, 56, 56), 64, 64, 192, 192, (3, 3, 3), (1, 1, 1), (1, 1, 1), (2, 56, 56), groups=2))
+    w = conv_work(d)
+    assert abs(2 * w["executed"] / _conv_flops(d) - 4.0 / 6.0) < 0.02
+    # no padding at all: executed == valid == descriptor
+    d = D.trim_conv(D.conv_fwd(16, (1, 28, 28), 832, 832, 256, 256, (1, 1, 1), (1, 1, 1), (0, 0, 0), (1, 28, 28), groups=2))
+    w = conv_work(d)
+    assert 2 * w["executed"] == 2 * w["valid"] == _conv_flops(d)
+
+
+def test_stem_counts_three_real_channels():
+    """The RGB stem: Ci = 4 in the kernel (16-byte pieces), 3 real; with PC_F_CI3 the padding channel's MFMA is not issued."""
+    d = D.conv_fwd(16, (8, 224, 224), 4, 4, 64, 64, (7, 7, 7), (2, 2, 2), (2, 2, 2), (4, 112, 112), groups=2)     # SAME: pad 5 -> front 2
+    d = D.trim_conv(d)
+    d["Ci_real"] = 3
+    d["flags"] = capi.F_CI3
+    w3 = conv_work(d)
+    d4 = dict(d, flags=0)
+    w4 = conv_work(d4)
+    assert w3["executed"] == w4["executed"] and w3["issued"] * 4 == w4["issued"] * 3
+    assert w3["issued"] >= w3["executed"] and w3["executed"] * 4 <= _conv_flops(dict(d, Ci_real=4)) * 3 / 2 + 1
+
+
+def test_step_totals_are_consistent():
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    p = Plan(24, 112, n=2, groups=2, lanes=1)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    fe, fw = p.conv_flops_executed(), p.wgrad_flops_executed()
+    fc, fg = p.flops(capi.OP_CONV), p.flops(capi.OP_WGRAD)
+    for n in ("fwd", "bwd"):
+        assert fe[n]["mfma"] >= fe[n]["executed"] >= fe[n]["valid"] and fe[n]["executed"] <= fc[n]
+        assert fw[n]["mfma"] >= fw[n]["executed"] >= fw[n]["valid"] and fw[n]["executed"] <= fg[n]
+    assert fe["fwd"]["executed"] > 0 and fw["bwd"]["executed"] > 0
+    # every conv / wgrad op carries its work record (tools/launch_table.py pairs them with the trace)
+    p.finalize()
+    ops = [op for n in p.lists for op in p.lists[n] if op[0] in (capi.OP_CONV, capi.OP_WGRAD)]
+    assert ops and all(id(op[1]) in p.op_work for op in ops)

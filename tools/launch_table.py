@@ -35,26 +35,15 @@ def main():
     args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
     p = Plan(24, 224, n=8, groups=2, lanes=1)
     p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    p.finalize()
     ops = [(name, op) for name in ("prep", "fwd", "loss", "bwd") for op in p.lists[name] if op[0] in (capi.OP_CONV, capi.OP_WGRAD)]
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
     st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad4_kernel" in r["Kernel_Name"]]
     def n_kernels(op):
-        """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (csrc/conv.hip)."""
-        if op[0] != capi.OP_WGRAD:
-            return 1
-        d = unflat(op[1], D.WGRAD_FIELDS)
-        padw = -d["ioff0"][2]
-        row3 = (d["KW"] == 3 and padw == 1 and d["Wq"] == d["Ws"] and (d["Cs"] % 64 == 0 or (d["Cs"] % 32 == 0 and d["Cd"] > 64))
-                and d["Ws"] % 28 == 0 and d.get("nbatch", 0) <= 1 and d.get("splitk", 0) >= 0)
-        row9 = d["KW"] == 9 and padw == 0 and d["Wq"] == 20 and d["Ws"] == 28 and d["Cs"] % 64 == 0 and d["Tq"] == 1 and d["Hq"] == 1
-        if (row3 or row9) and d.get("Td", 0) == 0 and d["ntap"][2] == d["KW"] and d["istr"][2] == 1 and d["istep"] == [1, 1, 1]:
-            return 1        # row-segment kernel: one launch
-        full, rem = d["Cd"] // 128 * 128, d["Cd"] % 128
-        ntot = d["ntap"][0] * d["ntap"][1] * d["ntap"][2] * d["Cs"]
-        deep = (full // 128) * -(-ntot // 128) * max(1, d.get("nbatch", 0)) >= 1024
-        return 2 if (d["Cd"] > 64 and 0 < rem <= 64 and deep) else 1
+        """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (pc_wgrad_work's launch count)."""
+        return p.op_work[id(op[1])]["launches"] if op[0] == capi.OP_WGRAD else 1
     if len(st) != sum(n_kernels(op) for _n, op in ops):
         raise SystemExit("trace has %d GEMM launches per step, plan expects %d (lanes / version mismatch?)" %
                          (len(st), sum(n_kernels(op) for _n, op in ops)))
@@ -66,29 +55,38 @@ def main():
         dur = sum((int(q["End_Timestamp"]) - int(q["Start_Timestamp"])) / 1e6 for q in rs)
         kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         blocks = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_X"])
+        w = p.op_work[id(op[1])]          # host-side walk of the launch's tiles (pc_conv_work / pc_wgrad_work): MACs as the kernel runs them
         if op[0] == capi.OP_CONV:
             if "wgrad" in kn:
                 raise SystemExit("order mismatch: conv op paired with " + kn)
             d = unflat(op[1], D.CONV_FIELDS)
             M = d["N"] * d["Tq"] * d["Hq"] * d["Wq"]
-            taps = d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
-            fl = 2 * M * d["Co"] * d["Ci"] * taps
             what = "conv  M=%-7d Co=%-5d Ci=%-4d taps=%s" % (M, d["Co"], d["Ci"], "x".join(map(str, d["ntap"])))
         else:
             if "wgrad" not in kn:
                 raise SystemExit("order mismatch: wgrad op paired with " + kn)
             d = unflat(op[1], D.WGRAD_FIELDS)
             M = d["N"] * d["Tq"] * d["Hq"] * d["Wq"]
-            taps = d["ntap"][0] * d["ntap"][1] * d["ntap"][2]
-            fl = 2 * M * d["Cd"] * d["Cs"] * taps * max(1, d.get("nbatch", 0))
             what = "wgrad K=%-7d Cd=%-5d Cs=%-4d taps=%s" % (M, d["Cd"], d["Cs"], "x".join(map(str, d["ntap"])))
-        out.append((dur, fl, name, kn, blocks, what))
-    print("%7s %7s %7s %-4s %6s %-34s %s" % ("ms", "TF/s", "lost", "list", "blocks", "kernel", "launch (issued shape, trimmed taps)"))
-    for dur, fl, name, kn, blocks, what in sorted(out, key=lambda x: -(x[0] - x[1] / PEAK))[:top]:
-        print("%7.3f %7.1f %7.3f %-4s %6d %-34s %s" % (dur, fl / dur / 1e9, dur - fl / PEAK, name, blocks, kn[:34], what))
-    tot = sum(d for d, *_ in out)
-    print("GEMM launches: %d, %.2f ms/step, %.2f ms above the fp32 MFMA peak time of the issued FLOPs" %
-          (len(out), tot, sum(d - f / PEAK for d, f, *_ in out)))
+        out.append((dur, 2 * w["executed"], 2 * w["issued"], 2 * w["valid"], name, kn, blocks, what))
+    print("FLOPs per launch as the kernel runs it (host walk of its tiles, pc_conv_work / pc_wgrad_work): TF/s = executed (real rows x columns over the "
+          "K each block walks; taps that are padding for a whole tile are skipped by the kernel and not counted), mfma = issued to the matrix "
+          "cores (whole tiles), valid = non-padding MACs only; lost = time above the fp32 MFMA peak time of the executed FLOPs")
+    print("%7s %7s %7s %7s %7s %-4s %6s %-34s %s" % ("ms", "TF/s", "mfma", "valid", "lost", "list", "blocks", "kernel", "launch (trimmed descriptor)"))
+    for dur, fl, fm, fv, name, kn, blocks, what in sorted(out, key=lambda x: -(x[0] - x[1] / PEAK))[:top]:
+        print("%7.3f %7.1f %7.1f %7.1f %7.3f %-4s %6d %-34s %s" % (dur, fl / dur / 1e9, fm / dur / 1e9, fv / dur / 1e9, dur - fl / PEAK, name, blocks, kn[:34], what))
+    over = [x for x in out if x[2] / x[0] / 1e9 > 157.3]
+    if over:
+        raise SystemExit("%d launches above the 157.3 TF/s peak even by issued MFMA FLOPs: accounting error" % len(over))
+    tot = sum(x[0] for x in out)
+    for label, sel in (("conv / dgrad", lambda x: "wgrad" not in x[5]), ("weight gradients", lambda x: "wgrad" in x[5])):
+        xs = [x for x in out if sel(x)]
+        t = sum(x[0] for x in xs)
+        print("%-16s %3d launches %6.2f ms/step: executed %.1f GF = %.1f TF/s (%.3f of peak), mfma-issued %.1f TF/s (%.3f), valid %.1f TF/s (%.3f)" %
+              (label, len(xs), t, sum(x[1] for x in xs) / 1e9, sum(x[1] for x in xs) / t / 1e9, sum(x[1] for x in xs) / t / PEAK,
+               sum(x[2] for x in xs) / t / 1e9, sum(x[2] for x in xs) / t / PEAK, sum(x[3] for x in xs) / t / 1e9, sum(x[3] for x in xs) / t / PEAK))
+    print("GEMM launches: %d, %.2f ms/step, %.2f ms above the fp32 MFMA peak time of the executed FLOPs" %
+          (len(out), tot, sum(x[0] - x[1] / PEAK for x in out)))
 
 
 if __name__ == "__main__":
