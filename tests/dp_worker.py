@@ -26,6 +26,13 @@ from picons_amd import dist as pdist, step as pstep, synthetic  # noqa: E402
 
 HW, BS, EPOCH, LR = 112, 2, 1, 1e-4
 AKW = dict(bv=True, n_frames=5, wt_cons=0.1)
+LANES = 2
+# PICONS_DP_FULL=1: the product default -- four lanes, 8x224x224, bs = 8 per rank (what bench.py runs on every rank at N > 1).  Every
+# engine-against-engine check runs; the CPU-oracle comparison stays with the 112^2 case (two fp32 + two fp64 oracle steps at bs = 8 take
+# minutes, and tests/test_step_gpu.py holds the bs = 8 oracle bars for the single-rank step)
+FULL = os.environ.get("PICONS_DP_FULL", "0") == "1"
+if FULL:
+    HW, BS, LANES = 224, 8, None
 
 
 def main():
@@ -43,7 +50,7 @@ def main():
 
     ramp = pstep.exp_rampup(100)(EPOCH)
     args = pstep.default_args(lr=LR, **AKW)
-    eng = pstep.StepEngine(args, bs=BS, hw=HW, lanes=2, device="cuda:0")
+    eng = pstep.StepEngine(args, bs=BS, hw=HW, lanes=LANES, device="cuda:0")
     red = eng.make_reducer(target_floats=3_000_000)
     check("host_staged_reducer", red.world == 2 and red.host_staged and len(red.buckets) >= 3, [red.world, len(red.buckets)])
     mine = synthetic.make_step_inputs(BS, rank=rank, step=0, hw=HW)
@@ -56,7 +63,7 @@ def main():
     scal = eng.read_scalars()
 
     # the same two minibatches through independent single-rank engines on this device
-    solo = pstep.StepEngine(args, bs=BS, hw=HW, lanes=2, device="cuda:0")
+    solo = pstep.StepEngine(args, bs=BS, hw=HW, lanes=LANES, device="cuda:0")
     g, r_stats = [], []
     for r in range(world):
         solo.load_state(synthetic.init_state(47, 24))
@@ -85,7 +92,8 @@ def main():
     dist.all_reduce(ones)
     check("rank_count_observed", int(ones.item()) == 2, int(ones.item()))
 
-    if rank == 0:
+    check("lanes", eng.plan.lanes == (4 if FULL else 2) and len(eng.side) == eng.plan.lanes - 1, eng.plan.lanes)
+    if rank == 0 and not FULL:
         # mean of two oracle steps, fp32 and fp64 (the anchor): whole-gradient and per-tensor bars of tests/test_step_gpu.py
         from oracle import step as ostep
         oa = ostep.default_args(**AKW)

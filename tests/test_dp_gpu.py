@@ -22,13 +22,16 @@ def _free_port():
     return port
 
 
-def test_two_rank_dp_step_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("full", [False, True])
+def test_two_rank_dp_step_on_one_gpu(tmp_path, full):
+    """full=True: the product default (four lanes, 8x224x224, bs = 8 per rank) -- every engine-against-engine check; the oracle
+    comparison runs in the small case."""
     port = _free_port()
     out = str(tmp_path / "dp")
     procs = []
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", PICONS_DP_FULL="1" if full else "0")
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), out], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     logs = []
@@ -46,12 +49,13 @@ def test_two_rank_dp_step_on_one_gpu(tmp_path):
         path = "%s.%d" % (out, rank)
         assert os.path.exists(path), "rank %d wrote no verdict:\n%s" % (rank, logs[rank][-3000:])
         verdicts.append(json.load(open(path)))
-    with open(os.path.join(ROOT, "gpurun_out", "dp_two_rank_checks.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "dp_two_rank_checks%s.json" % ("_full" if full else "")), "w") as f:
         json.dump(verdicts, f, indent=1)
     for rank, v in enumerate(verdicts):
         failed = {k: c for k, c in v["checks"].items() if not c["ok"]}
         assert not failed and procs[rank].returncode == 0, (rank, failed, logs[rank][-2000:])
-    assert "mean_gradient_vs_mean_of_oracle_steps" in verdicts[0]["checks"]
+    assert full or "mean_gradient_vs_mean_of_oracle_steps" in verdicts[0]["checks"]
+    assert verdicts[0]["checks"]["lanes"]["info"] == (4 if full else 2)
 
 
 RCCL_ONE_RANK = r"""

@@ -1,5 +1,6 @@
 """Pin the CPU oracle against outputs of the reference itself (tests/golden/*.npz, produced
 by tools/make_goldens.py in the authoring container).  CPU only."""
+import ast
 import os
 
 import numpy as np
@@ -149,7 +150,7 @@ def test_state_keys():
     assert len(spec.param_shapes(24)) == 158
 
 
-STEP_CASES = ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8", "step_refinit_bv5"]
+STEP_CASES = ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8", "step_jhmdb_bv_bs8", "step_gv_pseudo_bs8", "step_refinit_bv5"]
 
 
 @pytest.mark.parametrize("tag", STEP_CASES)
@@ -161,7 +162,7 @@ def test_full_step(golden_dir, tag):
         pytest.skip("slow (40 s each, 3 min for the bs = 8 cases): set PICONS_SLOW=1")
     S = np.load(path)
     ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
-    akw = dict(eval(str(S["args"])))
+    akw = dict(ast.literal_eval(str(S["args"])))
     args = ostep.default_args(**akw)
     bs = int(S["bs"]) if "bs" in S.files else 2
     conditioned = bool(int(S["conditioned"])) if "conditioned" in S.files else True

@@ -121,12 +121,15 @@ def test_step_vs_oracle_other_batch_and_frame_sizes(bs, hw):
 GSAMPLE_STRIDE = {"upsample3.weight": 7, "upsample4.weight": 13, "primary_caps.pose.weight": 997, "primary_caps.a.weight": 97}
 
 
-@pytest.mark.parametrize("tag", ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8"])
+@pytest.mark.parametrize("tag", ["step_bv5", "step_gv_pseudo", "step_bvgv3", "step_jhmdb_bv", "step_bv5_bs8", "step_gv_bs8",
+                                 "step_jhmdb_bv_bs8", "step_gv_pseudo_bs8"])
 def test_step_vs_reference_golden_full_size(golden_dir, tag):
     """HIP step against THE REFERENCE'S OWN outputs.  The two *_bs8 fixtures are BASELINE configs[1] (--bv --n_frames 5)
     and configs[2] (--gv, thresholds None) at the batch size the metric is quoted on: 4 labeled + 4 unlabeled clips, i.e. the
     B-dependent semantics (gv (B,B,...) broadcast utils/losses.py:74-76, joint Dice :44-57, Spread /b^2 :34-35, BN statistics
-    over 8 clips per pass pytorch_i3d.py:116-119)."""
+    over 8 clips per pass pytorch_i3d.py:116-119); step_jhmdb_bv_bs8 is BASELINE configs[4]'s per-rank workload (21 classes,
+    main_jhmdb.py:50-140) and step_gv_pseudo_bs8 the epoch >= thresh_epoch branch (argmax pseudo-labels, capsules_ucf101.py:463),
+    the two other workloads bench.py times at bs = 8."""
     S = np.load(os.path.join(golden_dir, tag + ".npz"))
     ncls = int(S["num_classes"]); epoch = int(S["epoch"]); stepid = int(S["stepid"])
     bs = int(S["bs"]) if "bs" in S.files else 2
@@ -173,16 +176,20 @@ def test_step_vs_reference_golden_full_size(golden_dir, tag):
             assert np.abs(eng.R[o:o + S[k].size].cpu().numpy() - S[k]).max() <= 1e-5, k
 
 
-BS8 = [("bv5_bs8", dict(bv=True, n_frames=5, wt_cons=0.1), 4), ("gv_bs8", dict(gv=True, wt_cons=0.1), 5)]
+BS8 = [("bv5_bs8", dict(bv=True, n_frames=5, wt_cons=0.1), 4, 1, 24, False), ("gv_bs8", dict(gv=True, wt_cons=0.1), 5, 1, 24, False),
+       # configs[4] per rank (21-class JHMDB step) and the pseudo-label branch (epoch 12 >= thresh_epoch 11), as bench.py --jhmdb /
+       # --epoch 12 time them
+       ("jhmdb_bv_bs8", dict(bv=True, n_frames=5, wt_cons=0.1), 7, 1, 21, True),
+       ("gv_pseudo_bs8", dict(gv=True, lower_thresh=0.2, upper_thresh=0.9, wt_cons=0.1), 8, 12, 24, False)]
 
 
-@pytest.mark.parametrize("tag,akw,stepid", BS8)
-def test_step_bs8_full_size_vs_oracle(tag, akw, stepid):
+@pytest.mark.parametrize("tag,akw,stepid,epoch,ncls,jhmdb", BS8)
+def test_step_bs8_full_size_vs_oracle(tag, akw, stepid, epoch, ncls, jhmdb):
     """BASELINE configs[1] / configs[2] exactly as bench.py runs them (bs = 8, 8x224x224, epoch 1) against the CPU oracle on
     the same clips: loss scalars 1e-4, logits / masks 1e-3, and EVERY parameter gradient per tensor against an fp64 run of
     the oracle -- this is where the 224-only kernels (the stem's wgrad4, conv112's row-segment wgrad, the 256-column
     wgrad tiles, upsample3 / the merged tail, the spectral PrimaryCaps at M = 6400) meet a per-tensor bar."""
-    eng, ref, P, P64 = run_pair(akw, 224, 8, 1, stepid=stepid)
+    eng, ref, P, P64 = run_pair(akw, 224, 8, epoch, ncls, jhmdb, stepid=stepid)
     got = eng.read_scalars()
     out, flip, pred = eng.outputs()
     for k in ("total", "loc", "cls", "cons"):

@@ -189,6 +189,11 @@ def gen_steps(only_tags=None):
         # BASELINE configs[1] / configs[2] at the batch size the metric is quoted on (4 labeled + 4 unlabeled)
         ("step_bv5_bs8", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 4, 8, True, False),
         ("step_gv_bs8", "main_ucf101", 24, dict(gv=True, wt_cons=0.1), 1, 5, 8, True, False),
+        # the two other per-rank workloads bench.py times, at that batch size too: BASELINE configs[4]'s 21-class JHMDB step
+        # (main_jhmdb.py:50-140: synthesised labels :68-70, gv overrides bv :121,132) and the epoch >= thresh_epoch branch
+        # (argmax pseudo-labels for the unlabeled rows, capsules_ucf101.py:463)
+        ("step_jhmdb_bv_bs8", "main_jhmdb", 21, dict(bv=True, n_frames=5, wt_cons=0.1, dataset="jhmdb"), 1, 7, 8, True, False),
+        ("step_gv_pseudo_bs8", "main_ucf101", 24, dict(gv=True, lower_thresh=0.2, upper_thresh=0.9, wt_cons=0.1), 12, 8, 8, True, False),
         # the reference's own initialisation (PrimaryCaps std 0.1, ConvCaps.weights randn: capsules_ucf101.py:36,39,103),
         # fp32 and fp64 runs of the reference (SURVEY 8c "reference-init case")
         ("step_refinit_bv5", "main_ucf101", 24, dict(bv=True, n_frames=5, wt_cons=0.1), 1, 6, 2, False, True),
