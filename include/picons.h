@@ -94,6 +94,31 @@ int pc_conv_bnpart_rows(const pc_conv_desc* d);
  * ci_real / co_real: channels that are not padding (0 = Ci / Co). */
 int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, double* out);
 
+/* ------------------------------------------------------------------------------------------
+ * Winograd F(2x2, 3x3) form of the stride-1, "same"-padded KT x 3 x 3 convolutions (KT = 3 with temporal padding 1, or 1):
+ *   out[n,t,h,w,co] = act( bias[co] + sum_{kt,kh,kw,ci} in[n, t+kt-KT/2, h+kh-1, w+kw-1, ci] * g[co][kt][kh][kw][ci] )   (zero padding)
+ * 2.25x fewer multiply-accumulates than pc_conv_fwd for the same result (equal in exact arithmetic; fp32 rounding differs at the
+ * 1e-6 level).  Used for the decoder's skip convs and Conv3d_2c and for their input gradients (nn.Conv3d forward / ATen
+ * convolution_backward's input branch: capsules_ucf101.py:497,501; pytorch_i3d.py:236-238).  H, W even; Ci % 8 == 0.
+ * The weights are passed in the transform domain: pc_wino_weights builds U (pc_wino_u_floats(O, I, KT) floats) from any strided
+ * weight tensor w[o*sO + ((kt*3+kh)*3+kw)*sT + i*sI] -- the master OIDHW tensor directly (sO = I*KT*9, sT = 1, sI = KT*9), or, with
+ * flip = 1 and O / I exchanged (sO = KT*9, sI = Cout*KT*9), the mirrored / transposed weights of the input gradient.
+ * flags: PC_F_BIAS, PC_F_ACCUM, PC_F_BNPART (partials [pc_wino_bnpart_rows(d)][2][Co]; rows of one sample are consecutive, samples
+ * in order, so the rows of a batch group are one contiguous range). */
+typedef struct pc_wino_desc {
+    int32_t N, T, H, W;             /* input = output positions (stride 1, same padding) */
+    int32_t Ci, ldi, Co, ldo;
+    int32_t KT;                     /* temporal taps: 3 (padding 1) or 1 */
+    int32_t act, flags;             /* PC_ACT_NONE / PC_ACT_RELU */
+    int32_t reserved;
+} pc_wino_desc;
+int64_t pc_wino_u_floats(int O, int I, int KT);
+int pc_wino_weights(const float* w, int64_t sO, int64_t sT, int64_t sI, int O, int I, int KT, int flip, float* U, pc_stream s);
+int pc_wino_conv(const pc_wino_desc* d, const float* in, const float* U, const float* bias, float* out, float* bnpart, pc_stream s);
+int pc_wino_bnpart_rows(const pc_wino_desc* d);
+/* host-only work accounting (see pc_conv_work): out[0] issued, out[1] executed multiply-accumulates, out[2] blocks */
+int pc_wino_work(const pc_wino_desc* d, double* out);
+
 /* Weight gradient:  g[m][ (a,b,c) , cs ] += sum_{n,q} D[n,q,m] * S[n, q*istr+ioff0+(a,b,c)*istep, cs]
  * D dense over the lattice (Tq,Hq,Wq), S gathered.  g layout [Cd][KT*KH*KW][Cs], tap (a,b,c) -> wk0+(a,b,c),
  * accumulated with fp32 atomics (g must be initialised).  Conv3d wgrad: D=dY, S=X;

@@ -26,6 +26,10 @@ class WgradDesc(C.Structure):
 AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "accum", "in_sr", "in_hi", "in_lo", "out_sr", "out_hi", "out_lo"]
 
 
+class WinoDesc(C.Structure):
+    _fields_ = [(n, i32) for n in ("N", "T", "H", "W", "Ci", "ldi", "Co", "ldo", "KT", "act", "flags", "reserved")]
+
+
 class AxisDesc(C.Structure):
     _fields_ = [(n, i32) for n in AXIS_FIELDS]
 
@@ -71,6 +75,11 @@ _SIGS = {
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
     "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),
     "pc_wgrad_work": (i32, [C.POINTER(WgradDesc), i32, i32, C.POINTER(C.c_double)]),
+    "pc_wino_u_floats": (i64, [i32, i32, i32]),
+    "pc_wino_weights": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
+    "pc_wino_conv": (i32, [C.POINTER(WinoDesc), vp, vp, vp, vp, vp, vp]),
+    "pc_wino_bnpart_rows": (i32, [C.POINTER(WinoDesc)]),
+    "pc_wino_work": (i32, [C.POINTER(WinoDesc), C.POINTER(C.c_double)]),
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
     "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),

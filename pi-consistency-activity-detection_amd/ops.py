@@ -44,6 +44,27 @@ def conv_fwd(d, x, w, out, bias=None, cscale=None, bnpart=None):
     return out
 
 
+def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0):
+    st = capi.WinoDesc()
+    st.N, st.T, st.H, st.W, st.Ci, st.ldi, st.Co, st.ldo, st.KT, st.act, st.flags, st.reserved = N, T, H, W, Ci, ldi, Co, ldo, KT, act, flags, 0
+    return st
+
+
+def wino_weights(w, O, I, KT=3, flip=False, strides=None, out=None):
+    """Transform-domain weights of pc_wino_conv from a weight tensor addressed as w[o*sO + tap*sT + i*sI] (default: contiguous
+    OIDHW, i.e. (O, I, KT, 3, 3))."""
+    sO, sT, sI = strides if strides is not None else (I * KT * 9, 1, KT * 9)
+    n = capi.lib().pc_wino_u_floats(O, I, KT)
+    U = out if out is not None else torch.empty(n, device=w.device, dtype=torch.float32)
+    capi.call("pc_wino_weights", ptr(w), int(sO), int(sT), int(sI), O, I, KT, int(flip), ptr(U), stream())
+    return U
+
+
+def wino_conv(d, x, U, out, bias=None, bnpart=None):
+    capi.call("pc_wino_conv", C.byref(d), ptr(x), ptr(U), ptr(bias), ptr(out), ptr(bnpart), stream())
+    return out
+
+
 def conv_wgrad(d, Dt, St, g):
     capi.call("pc_conv_wgrad", C.byref(_fill_struct(capi.WgradDesc(), d)), ptr(Dt), ptr(St), ptr(g), stream())
     return g

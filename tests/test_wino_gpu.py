@@ -1,0 +1,107 @@
+"""GPU: the Winograd F(2x2, 3x3) convolution (csrc/wino.hip) against plain fp32/fp64 torch convolutions of the same op --
+forward with bias / ReLU / BatchNorm partial sums, the input gradient through mirrored + transposed weights (flip), accumulate,
+ragged tile blocks (tiles per side not a multiple of the block rectangle), channel counts that are not multiples of 64 -- and,
+at the real conv112 / Conv3d_2c shapes, against the gather-GEMM kernel it replaces."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from picons_amd import capi, desc as D, ops
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(x, w, b=None, kt=3):
+    """x (N,T,H,W,Ci) fp64 cpu, w (Co,Ci,kt,3,3) -> (N,T,H,W,Co)."""
+    y = F.conv3d(x.permute(0, 4, 1, 2, 3), w, b, padding=(kt // 2, 1, 1))
+    return y.permute(0, 2, 3, 4, 1).contiguous()
+
+
+@pytest.mark.parametrize("N,T,H,W,Ci,Co,KT", [(2, 3, 12, 20, 16, 40, 3), (1, 1, 8, 8, 8, 4, 1), (3, 2, 28, 28, 24, 96, 3), (2, 4, 18, 34, 32, 64, 3)])
+def test_wino_forward_matches_torch(N, T, H, W, Ci, Co, KT):
+    g = torch.Generator().manual_seed(N * 100 + H)
+    x = torch.randn(N, T, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, KT, 3, 3, generator=g) * (1.0 / np.sqrt(Ci * KT * 9))
+    b = torch.randn(Co, generator=g)
+    ref = _ref(x.double(), w.double(), b.double(), KT)
+    xd, wd, bd = x.cuda(), w.cuda().contiguous(), b.cuda()
+    U = ops.wino_weights(wd, Co, Ci, KT)
+    out = torch.full((N, T, H, W, Co), float("nan"), device="cuda")
+    d = ops.wino_desc(N, T, H, W, Ci, Ci, Co, Co, KT, act=capi.ACT_NONE, flags=capi.F_BIAS)
+    ops.wino_conv(d, xd, U, out, bias=bd)
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= 2e-5 * max(1.0, ref.abs().max().item()), err
+    # ReLU + accumulate into an existing tensor (the input-gradient epilogue)
+    base = torch.randn(N, T, H, W, Co, generator=g)
+    out2 = base.cuda().clone()
+    d2 = ops.wino_desc(N, T, H, W, Ci, Ci, Co, Co, KT, act=capi.ACT_NONE, flags=capi.F_ACCUM)
+    ops.wino_conv(d2, xd, U, out2)
+    ref2 = base.double() + _ref(x.double(), w.double(), None, KT)
+    assert (out2.cpu().double() - ref2).abs().max().item() <= 2e-5 * max(1.0, ref2.abs().max().item())
+    d3 = ops.wino_desc(N, T, H, W, Ci, Ci, Co, Co, KT, act=capi.ACT_RELU, flags=capi.F_BIAS)
+    ops.wino_conv(d3, xd, U, out, bias=bd)
+    assert (out.cpu().double() - ref.clamp_min(0)).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+
+
+def test_wino_channel_slices_and_bn_partials():
+    """Reads a channel slice of a wider tensor (ldi > Ci), writes a slice of a wider one (ldo > Co), and leaves BatchNorm partial
+    sums whose totals are the column sums / sums of squares of the output (per sample: rows of a sample are consecutive)."""
+    N, T, H, W, Ci, Co, ldi, ldo = 4, 2, 12, 12, 16, 32, 40, 48
+    g = torch.Generator().manual_seed(5)
+    xw = torch.randn(N, T, H, W, ldi, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1
+    x = xw[..., 8:8 + Ci].contiguous()
+    ref = _ref(x.double(), w.double(), None, 3)
+    xd = xw.cuda()
+    U = ops.wino_weights(w.cuda().contiguous(), Co, Ci, 3)
+    outw = torch.zeros(N, T, H, W, ldo, device="cuda")
+    d = ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, 3, flags=capi.F_BNPART)
+    rows = capi.lib().pc_wino_bnpart_rows(d)
+    part = torch.zeros(rows, 2, Co, device="cuda")
+    ops.wino_conv(d, xd[..., 8:], U, outw[..., 4:], bnpart=part)
+    assert (outw[..., 4:4 + Co].cpu().double() - ref).abs().max().item() <= 2e-5
+    assert outw[..., :4].abs().max().item() == 0 and outw[..., 4 + Co:].abs().max().item() == 0
+    per = rows // N
+    for n in range(N):
+        s = part[n * per:(n + 1) * per].sum(0).cpu().double()
+        assert (s[0] - ref[n].sum(dim=(0, 1, 2))).abs().max().item() <= 1e-3
+        assert (s[1] - (ref[n] ** 2).sum(dim=(0, 1, 2))).abs().max().item() <= 1e-3 * max(1.0, (ref[n] ** 2).sum(dim=(0, 1, 2)).max().item())
+
+
+@pytest.mark.parametrize("KT", [3, 1])
+def test_wino_input_gradient_through_flipped_weights(KT):
+    """d(x) of y = conv(x, w) is the same correlation of d(y) with the taps mirrored and the channel roles exchanged:
+    pc_wino_weights(flip=1) reads the master OIDHW weights through strides (O' = Ci, I' = Co)."""
+    N, T, H, W, Ci, Co = 2, 3, 10, 14, 24, 16
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, T, H, W, Ci, generator=g, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(Co, Ci, KT, 3, 3, generator=g, dtype=torch.float64) * 0.1)
+    dy = torch.randn(N, T, H, W, Co, generator=g, dtype=torch.float64)
+    y = _ref(x, w, None, KT)
+    (y * dy).sum().backward()
+    wd = w.float().cuda().contiguous()
+    U = ops.wino_weights(wd, Ci, Co, KT, flip=True, strides=(KT * 9, 1, Ci * KT * 9))
+    dx = torch.empty(N, T, H, W, Ci, device="cuda")
+    d = ops.wino_desc(N, T, H, W, Co, Co, Ci, Ci, KT)
+    ops.wino_conv(d, dy.float().cuda(), U, dx)
+    assert (dx.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("thw,Ci,Co", [((4, 112, 112), 64, 64), ((2, 56, 56), 64, 192), ((2, 56, 56), 192, 64)])
+def test_wino_real_shapes_vs_gather_gemm(thw, Ci, Co):
+    N = 16
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.randn(N, *thw, Ci, device="cuda", generator=g).clamp_min(0)           # post-ReLU activations, as in the step
+    w = torch.randn(Co, Ci, 3, 3, 3, device="cuda", generator=g) * (1.0 / np.sqrt(27 * Ci))
+    b = torch.randn(Co, device="cuda", generator=g) * 0.1
+    wk = w.permute(0, 2, 3, 4, 1).reshape(Co, 27, Ci).contiguous()
+    dd = D.trim_conv(D.conv_fwd(N, thw, Ci, Ci, Co, Co, (3, 3, 3), (1, 1, 1), (1, 1, 1), thw, act=capi.ACT_RELU, flags=capi.F_BIAS, groups=2))
+    ref = torch.empty(N, *thw, Co, device="cuda")
+    ops.conv_fwd(dd, x, wk, ref, bias=b)
+    U = ops.wino_weights(w, Co, Ci, 3)
+    out = torch.empty_like(ref)
+    ops.wino_conv(ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3, act=capi.ACT_RELU, flags=capi.F_BIAS), x, U, out, bias=b)
+    torch.cuda.synchronize()
+    err = (out - ref).abs().max().item()
+    assert err <= 5e-5 * max(1.0, ref.abs().max().item()), err
