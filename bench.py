@@ -356,7 +356,9 @@ def main():
     conv_desc = sum(fc[n] for n in lists)                # 2*M*N*K of the trimmed descriptors: round 2's numerator (over-books: the kernel
                                                          # skips, per tile, every tap that is padding for the whole tile)
     conv_ref = sum(fr[n] for n in lists)                 # all taps incl. zero padding, dgrad at its layer's forward FLOPs
-    step_exec = conv_exec + sum(fw[n]["executed"] for n in lists)
+    fz = eng.plan.wino_flops_executed()                  # the Winograd launches: transform-domain FLOPs (2.25x fewer than the direct form's)
+    wino_exec = sum(fz[n]["executed"] for n in lists)
+    step_exec = conv_exec + wino_exec + sum(fw[n]["executed"] for n in lists)
     # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
     # FETCH_SIZE / WRITE_SIZE in their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run, so this
     # is OFFLINE data from the named file, not a measurement of this run
@@ -389,8 +391,9 @@ def main():
     roof_step = {"executed_gflop_per_step": step_exec / 1e9, "achieved": step_exec / (ms_step * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": step_exec / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                  "descriptor_gflop_per_step": sum(fl[n] for n in lists) / 1e9,
+                 "gflop_by_family": {"conv_gemm": conv_exec / 1e9, "winograd_conv": wino_exec / 1e9, "wgrad": sum(fw[n]["executed"] for n in lists) / 1e9},
                  "note": "whole step (all kernels, host gaps and the loss read-back included) against the fp32 MFMA roof, executed GEMM FLOPs "
-                         "(conv / dgrad / wgrad; pc_conv_work + pc_wgrad_work); the reference's own formulation would need 6 185 GFLOP/step, "
+                         "(gather-GEMM conv / dgrad, Winograd conv / dgrad in the transform domain, wgrad; pc_conv_work + pc_wino_work + pc_wgrad_work); the reference's own formulation would need 6 185 GFLOP/step, "
                          "most of which are removed algebraically (DESIGN.md 3)"}
     out = {
         "metric": METRIC,

@@ -106,11 +106,14 @@ int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, double* out);
  * flags: PC_F_BIAS, PC_F_ACCUM, PC_F_BNPART (partials [pc_wino_bnpart_rows(d)][2][Co]; rows of one sample are consecutive, samples
  * in order, so the rows of a batch group are one contiguous range). */
 typedef struct pc_wino_desc {
-    int32_t N, T, H, W;             /* input = output positions (stride 1, same padding) */
+    int32_t N, T, H, W;             /* output frames / positions (H, W: stride 1, same padding, so input = output size) */
     int32_t Ci, ldi, Co, ldo;
-    int32_t KT;                     /* temporal taps: 3 (padding 1) or 1 */
+    int32_t KT;                     /* temporal taps: 3 or 1 */
     int32_t act, flags;             /* PC_ACT_NONE / PC_ACT_RELU */
-    int32_t reserved;
+    int32_t Ti;                     /* input frames */
+    int32_t ta, tc, tden;           /* tap kt of output frame t reads input frame (t*ta + kt + tc) / tden when that is an integer in
+                                     * [0, Ti): forward with temporal stride s and front padding p: (s, -p, 1); input gradient of that
+                                     * layer (weights mirrored): (1, p - (KT-1), s).  Stride 1, padding KT/2: (1, -(KT/2), 1) both ways */
 } pc_wino_desc;
 int64_t pc_wino_u_floats(int O, int I, int KT);
 int pc_wino_weights(const float* w, int64_t sO, int64_t sT, int64_t sI, int O, int I, int KT, int flip, float* U, pc_stream s);
@@ -435,6 +438,8 @@ enum {
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued so far on lane i[1] (0 by default) */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP_WGRAD_MULTI,              /* p[0] = HOST pointer to pc_wgrad_job[i[0]] (kept alive by the owner of the list): pc_conv_wgrad_multi */
+    PC_OP_WINO_CONV,                /* i[0..11] = pc_wino_desc; p = in, U, bias, out, bnpart */
+    PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip; l = sO, sT, sI; p = w, U */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

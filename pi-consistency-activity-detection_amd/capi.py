@@ -27,7 +27,7 @@ AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "ac
 
 
 class WinoDesc(C.Structure):
-    _fields_ = [(n, i32) for n in ("N", "T", "H", "W", "Ci", "ldi", "Co", "ldo", "KT", "act", "flags", "reserved")]
+    _fields_ = [(n, i32) for n in ("N", "T", "H", "W", "Ci", "ldi", "Co", "ldo", "KT", "act", "flags", "Ti", "ta", "tc", "tden")]
 
 
 class AxisDesc(C.Structure):
@@ -52,7 +52,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
  OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI) = range(1, 43)
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS) = range(1, 45)
 MAX_LANES = 8
 
 # numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 42 int32, then D, S, g)

@@ -133,6 +133,13 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
         case PC_OP_WGRAD_MULTI:
             return pc_conv_wgrad_multi(P(const pc_wgrad_job*, 0), op.i[0], s);
+        case PC_OP_WINO_CONV: {
+            pc_wino_desc d;
+            memcpy(&d, op.i, sizeof(d));
+            return pc_wino_conv(&d, P(const float*, 0), P(const float*, 1), P(const float*, 2), P(float*, 3), P(float*, 4), s);
+        }
+        case PC_OP_WINO_WEIGHTS:
+            return pc_wino_weights(P(const float*, 0), op.l[0], op.l[1], op.l[2], op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);
             return PC_E_ARG;

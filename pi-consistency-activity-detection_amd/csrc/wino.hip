@@ -10,13 +10,15 @@
 //   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],  G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],  A^T = [1 1 1 0; 0 1 -1 -1]
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 __device__ __attribute__((aligned(16))) float w_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
+template <bool ON = true>
 __device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+    if (ON) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
 struct WinoK {
@@ -24,6 +26,7 @@ struct WinoK {
     int N, T, H, W, Ci, ldi, Co, ldo;
     int TH, TW, BTH, BTW, nbh, nbw, nct, nc8;
     int KT, act, flags;
+    int Ti, ta, tc, tden;
 };
 
 constexpr int WT = 64;            // tiles per block (rows of the transform-domain GEMMs)
@@ -71,14 +74,27 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, long long sO, l
 
 // ---- the fused convolution.  Block = 64 tiles (a BTH x BTW rectangle of 2x2-output tiles of one (n, t) plane) x 64 output channels,
 // four waves as 2 (tile halves) x 2 (channel halves), one wave per SIMD with all 16 transform-domain accumulators (256 registers).
-// K chunk = 8 input channels of one temporal tap: V (transformed input, 32 KB) is produced by the block itself -- thread =
-// (tile, 4-channel half, two of the four B^T rows): 12 global_load_dwordx4, 16 float4 adds, 8 ds_write_b128 -- and U (32 KB, contiguous
-// in HBM by construction) arrives by LDS-DMA; both double-buffered, one barrier per chunk.
+// K chunk = 8 input channels of one temporal tap.  Three LDS images per chunk, all filled by LDS-DMA or by the block itself:
+//   R  the raw (2 BTH + 2) x (2 BTW + 2) input patch of the block, [position][8 channels] (32 B per position, zero line for padding):
+//      each input element is fetched ONCE per block (per-tile register loads fetched it ~4.5 times as 16-byte pieces of 64 different
+//      cache lines per instruction, and cost a third of the kernel),
+//   V  the transformed patch B^T d B, [xi*4+nu][k half][tile][4], written by the block: thread = (tile, 4-channel half, two of the
+//      four B^T rows): 12 ds_read_b128 of R, 16 float4 adds, 8 ds_write_b128,
+//   U  the transformed weights, contiguous in HBM by construction.
+// R runs two chunks ahead (its DMA has a whole chunk to land), U one; one barrier per chunk.
+// VAR (diagnostics, PICONS_WINO_VARIANT; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no U DMA, 4 = no transform stores,
+// 8 = no output stores, 32 = s_memtime stamps of prologue / K loop / epilogue per block into bnpart (4 x u64 per block).
+constexpr int RMAX = 12;          // 1 KiB DMA pieces of one raw patch image (three per wave): up to 384 positions (an 8 x 8 tile block has 18 x 18 = 324)
+constexpr int RPLANE = RMAX * 256;
+
+template <int VAR>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vs = smem;                  // [2][PLANE]
     float* Us = smem + 2 * PLANE;      // [2][PLANE]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* Rs = smem + 4 * PLANE;      // [2][RPLANE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform by construction: keeps LDS bases / role selects in SGPRs
     const int wm = wave >> 1, wn = wave & 1;
     int sb = xcd_remap(blockIdx.x, gridDim.x);
     const int ct = sb % p.nct; sb /= p.nct;
@@ -86,121 +102,181 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int bw = sb % p.nbw; sb /= p.nbw;
     const int bh = sb % p.nbh; sb /= p.nbh;
     const int t = sb % p.T, n = sb / p.T;
+    const int PW = 2 * p.BTW + 2, PH = 2 * p.BTH + 2, npos = PH * PW;
+    const int h0 = 2 * bh * p.BTH - 1, w0 = 2 * bw * p.BTW - 1;          // image position of patch position (0, 0)
 
-    // transform role: thread = (tile, k half, row pair)
-    const int ttile = tid & 63, tkh = (tid >> 6) & 1, thalf = tid >> 7;
+    // raw-patch DMA role: piece j of this wave is piece wave + 4 j of the image; lane -> (position q = piece * 32 + lane / 2, 4-channel half)
+    int roff[3];
+    unsigned rmask = 0;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = (wave + 4 * j) * 32 + (lane >> 1);
+        const int pr = q / PW, pc = q - pr * PW;
+        const int h = h0 + pr, w = w0 + pc;
+        const bool ok = q < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        roff[j] = ok ? (h * p.W + w) * p.ldi + (lane & 1) * 4 : 0;
+        rmask |= (ok ? 1u : 0u) << j;
+    }
+
+    // transform role: thread = (tile, k half, row pair); reads 3 rows x 4 columns of R
+    const int ttile = lane, tkh = wave & 1, thalf = wave >> 1;
     const int tli = ttile / p.BTW, tlj = ttile - tli * p.BTW;
-    const int ti = bh * p.BTH + tli, tj = bw * p.BTW + tlj;
-    const bool tval = ttile < p.BTH * p.BTW && ti < p.TH && tj < p.TW;
-    int poff[12];
-    unsigned pm = 0;
-#pragma unroll
-    for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const int h = 2 * ti - 1 + thalf + rr, w = 2 * tj - 1 + c;
-            const bool ok = tval && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-            poff[rr * 4 + c] = ok ? (h * p.W + w) * p.ldi + tkh * 4 : 0;
-            pm |= (ok ? 1u : 0u) << (rr * 4 + c);
-        }
-    // temporal taps whose source plane exists: tt = t + kt - (KT >> 1)
-    const int tpad = p.KT >> 1;
-    const int kt_lo = max(0, tpad - t), kt_hi = min(p.KT - 1, p.T - 1 - t + tpad);
-    const int nchunks = (kt_hi - kt_lo + 1) * p.nc8;
+    const bool tval = ttile < p.BTH * p.BTW;       // (tiles beyond the image read zero lines: their patch positions are padding)
+    const int rbase = tval ? (((2 * tli + thalf) * PW + 2 * tlj) * 2 + tkh) * 4 : 0;      // float offset of patch (row thalf, col 0) in R
+    // temporal taps whose source frame exists: tap kt reads input frame (t * ta + kt + tc) / tden when that is an integer in [0, Ti)
+    int nkt = 0, ktl0 = 0, ktl1 = 0, ktl2 = 0, ttl0 = 0, ttl1 = 0, ttl2 = 0;
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int num = t * p.ta + kt + p.tc;
+        if (num < 0 || num % p.tden) continue;
+        const int tt = num / p.tden;
+        if (tt >= p.Ti) continue;
+        if (nkt == 0) { ktl0 = kt; ttl0 = tt; } else if (nkt == 1) { ktl1 = kt; ttl1 = tt; } else { ktl2 = kt; ttl2 = tt; }
+        ++nkt;
+    }
+    const int nchunks = nkt * p.nc8;
     const size_t plane_in = (size_t)p.H * p.W * p.ldi;
+    auto tap_of = [&](int c, int& kt, int& tt, int& c8) {          // chunk -> (weight tap, source frame, 8-channel slice)
+        const int q = c / p.nc8;
+        c8 = c - q * p.nc8;
+        kt = q == 0 ? ktl0 : (q == 1 ? ktl1 : ktl2);
+        tt = q == 0 ? ttl0 : (q == 1 ? ttl1 : ttl2);
+    };
 
-    // Chunk c -> (temporal tap, 8-channel slice).  The fetch of chunk c + 1 and its transform are spread over the 16 MFMA groups of chunk
-    // c (one wave per SIMD: nothing else hides them): the eight LDS-DMA pieces of U ride in groups 0..1, the twelve patch loads in groups
-    // 2..4 and transform row j (one ds_write_b128) in group 8 + j.  The DMA is issued BEFORE the loads because the compiler waits for
-    // the loaded registers with s_waitcnt vmcnt(0), i.e. also for every younger LDS-DMA piece.  After the last chunk the same slots
-    // re-fetch that chunk (harmless).
-    f32x4 d[12];
-    const float* pbase = nullptr;
+    const float* rnext = nullptr;                 // source plane / channel slice of the chunk whose raw patch the loop fetches
+    auto r_base = [&](int c) -> const float* {
+        int kt, tt, c8;
+        tap_of(min(c, nchunks - 1), kt, tt, c8);
+        return p.in + ((size_t)n * p.Ti + tt) * plane_in + c8 * WK;
+    };
+    auto issue_r = [&](int c, int rb) {           // raw patch of chunk c -> R[rb] (prologue)
+        const float* base = r_base(c);
+        float* rl = Rs + rb * RPLANE + wave * 256;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const float* src = ((rmask >> j) & 1u) ? base + roff[j] : w_zero16;
+            glds16<!(VAR & 1)>(src, rl + j * 4 * 256);
+        }
+    };
     const float* ug = nullptr;
     float* ul = nullptr;
-    float* vb = nullptr;
-    auto set_chunk = [&](int c, int buf) {
-        const int kt = kt_lo + c / p.nc8, c8 = c - (c / p.nc8) * p.nc8;
-        pbase = p.in + ((size_t)n * p.T + (t + kt - tpad)) * plane_in + c8 * WK;
+    auto set_u = [&](int c, int buf) {
+        int kt, tt, c8;
+        tap_of(min(c, nchunks - 1), kt, tt, c8);
         ug = p.U + (((size_t)kt * p.nct + ct) * p.nc8 + c8) * PLANE + wave * 8 * 256 + lane * 4;
         ul = Us + buf * PLANE + wave * 8 * 256;
-        vb = Vs + buf * PLANE + (tkh * 64 + ttile) * 4;
     };
-    auto load2 = [&](int g) {
-#pragma unroll
-        for (int k = 2 * g; k < 2 * g + 2; ++k) {
-            const float* src = ((pm >> k) & 1u) ? pbase + poff[k] : w_zero16;
-            d[k] = *(const f32x4*)src;
-        }
+    f32x4 d[12], x0[4], x1[4];
+    const float* rsrc = nullptr;
+    float* vb = nullptr;
+    const float* zl = w_zero16;                   // the zero line's address once, in registers (the compiler otherwise re-loads it from the
+    asm volatile("" : "+v"(zl));                  // GOT per use: an s_load per DMA piece, and every s_waitcnt lgkmcnt becomes (0))
+    auto read2 = [&](int g, int c0) {             // two columns of patch row g of this thread's three rows (tiles beyond the block's
+#pragma unroll                                    // rectangle read some valid position: their rows are never stored)
+        for (int c = c0; c < c0 + 2; ++c) d[g * 4 + c] = *(const f32x4*)(rsrc + (g * PW + c) * 8);
     };
-    // transform row j = q * 4 + nu: rows r0, r1, r2 of the patch held by this thread; half 0 -> B^T rows 0, 1 (d0 - d2, d1 + d2),
-    // half 1 -> rows 3, 2 (d1 - d3, d2 - d1)
-    auto xrow = [&](int q, int c) -> f32x4 {
-        if (q == 0) return d[c] - d[8 + c];
-        return thalf ? (d[4 + c] - d[c]) : (d[4 + c] + d[8 + c]);
+    // B^T rows held by this thread: half 0 -> rows 0, 1 (d0 - d2, d1 + d2) of patch rows (d0, d1, d2); half 1 -> rows 3, 2 (d1 - d3, d2 - d1)
+    // of patch rows (d1, d2, d3).  q = 0: first of the pair; q = 1: second, as d[1] + ca * d[0] + cb * d[2] with wave-uniform (ca, cb) =
+    // (0, 1) / (-1, 0): no branch inside the K loop (a branch splits the loop into blocks and every s_waitcnt degrades to (0))
+    const float ca = thalf ? -1.f : 0.f, cb = thalf ? 0.f : 1.f;
+    auto xcol = [&](int q, int c) {
+        if (q == 0) x0[c] = d[c] - d[8 + c];
+        else x1[c] = d[4 + c] + ca * d[c] + cb * d[8 + c];
     };
-    auto store_row = [&](int j) {
-        const int q = j >> 2, nu = j & 3;
+    auto store_out = [&](int q, int nu) {
         const int xi = thalf ? (q == 0 ? 3 : 2) : q;
+        const f32x4* x = q == 0 ? x0 : x1;
         f32x4 v;
-        if (nu == 0) v = xrow(q, 0) - xrow(q, 2);
-        else if (nu == 1) v = xrow(q, 1) + xrow(q, 2);
-        else if (nu == 2) v = xrow(q, 2) - xrow(q, 1);
-        else v = xrow(q, 1) - xrow(q, 3);
-        *(f32x4*)(vb + (xi * 4 + nu) * 512) = v;
+        if (nu == 0) v = x[0] - x[2];
+        else if (nu == 1) v = x[1] + x[2];
+        else if (nu == 2) v = x[2] - x[1];
+        else v = x[1] - x[3];
+        if (!(VAR & 4)) *(f32x4*)(vb + (xi * 4 + nu) * 512) = v;
     };
-
+    // The side work of one K chunk, one small piece per MFMA gap (step s = 4 * group + slot).  Slot 0 carries the LDS side work (two reads
+    // of R or one transform-row store) and, behind it, the NEXT group's fragment reads -- so the s_waitcnt lgkmcnt(0) in front of a group's first
+    // MFMA waits for nothing younger than those fragments --, slot 2 one LDS-DMA piece, slots 2 / 3 the transform arithmetic.
+    auto side = [&](auto S, int buf) {
+        constexpr int s_ = decltype(S)::value;
+        constexpr int g = s_ >> 2, e = s_ & 3;
+        if constexpr (e == 0 && g < 6) read2(g >> 1, (g & 1) * 2);                                     // patch rows of chunk c + 1 out of R
+        if constexpr (e == 0 && g >= 8 && g < 12) store_out(0, g - 8);
+        if constexpr (e == 0 && g >= 12) store_out(1, g - 12);
+        if constexpr (e == 2 && g < 8) glds16<!(VAR & 2)>(ug + g * 256, ul + g * 256);                 // U piece g of chunk c + 1
+        if constexpr (e == 2 && g >= 8 && g < 11) {                                                   // R piece g - 8 of chunk c + 2
+            const float* src = ((rmask >> (g - 8)) & 1u) ? rnext + roff[g - 8] : zl;
+            glds16<!(VAR & 1)>(src, Rs + buf * RPLANE + (wave + 4 * (g - 8)) * 256);
+        }
+        if constexpr (g == 6 && e >= 2) { xcol(0, (e - 2) * 2); xcol(0, (e - 2) * 2 + 1); }
+        if constexpr (g == 7 && e >= 2) { xcol(1, (e - 2) * 2); xcol(1, (e - 2) * 2 + 1); }
+    };
     f32x16 acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    unsigned long long stamp[4] = {0, 0, 0, 0};
+    if (VAR & 32) stamp[0] = __builtin_amdgcn_s_memtime();
 
     const int kh = lane >> 5;
     const int aoff = (kh * 64 + wm * 32 + (lane & 31)) * 4, boff = (kh * 64 + wn * 32 + (lane & 31)) * 4;
+    // prologue: R(0), R(1), U(0) in flight; V(0) from R(0)
     if (nchunks > 0) {
-        set_chunk(0, 0);
+        issue_r(0, 0);
+        issue_r(1, 1);
+        set_u(0, 0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds16(ug + j * 256, ul + j * 256);
-#pragma unroll
-        for (int g = 0; g < 6; ++g) load2(g);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) store_row(j);
+        for (int j = 0; j < 8; ++j) glds16<!(VAR & 2)>(ug + j * 256, ul + j * 256);
     }
     __syncthreads();
+    if (nchunks > 0) {
+        rsrc = Rs + rbase;
+        vb = Vs + (tkh * 64 + ttile) * 4;
+#pragma unroll
+        for (int g = 0; g < 3; ++g) { read2(g, 0); read2(g, 2); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) xcol(q, c);
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) store_out(q, nu);
+        }
+    }
+    __syncthreads();
+    if (VAR & 32) stamp[1] = __builtin_amdgcn_s_memtime();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        set_chunk(min(c + 1, nchunks - 1), buf ^ 1);
+        // during chunk c: U(c+1) -> U[buf^1], R(c+2) -> R[buf] (R[buf] held chunk c, transformed one iteration ago), V(c+1) from R[buf^1]
+        set_u(c + 1, buf ^ 1);
+        rsrc = Rs + (buf ^ 1) * RPLANE + rbase;
+        vb = Vs + (buf ^ 1) * PLANE + (tkh * 64 + ttile) * 4;
         const float* va = Vs + buf * PLANE + aoff;
         const float* ub = Us + buf * PLANE + boff;
         f32x4 a0 = *(const f32x4*)va, b0 = *(const f32x4*)ub, a1, b1;
-        // one group = the four MFMAs of one transform-domain position; the side work of the group is pinned between them
-        // (sched_barrier: the compiler otherwise gathers the loads, waits for them at once and strands the matrix pipe)
+        rnext = r_base(c + 2);
+        // one group = the four MFMAs of one transform-domain position, with one piece of side work pinned behind each of them
+        // (sched_barrier: the compiler otherwise gathers the side work, waits for it at once and strands the matrix pipe)
+#define WINO_STEP(I, E, A, B)                                                                                  \
+            acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[E], B[E], acc[I], 0, 0, 0);                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            side(std::integral_constant<int, 4 * (I) + (E)>{}, buf);                                           \
+            __builtin_amdgcn_sched_barrier(0);
 #define WINO_GROUP(I, A, B, AN, BN)                                                                            \
         {                                                                                                      \
+            WINO_STEP(I, 0, A, B)                                                                              \
             if ((I) + 1 < 16) { AN = *(const f32x4*)(va + ((I) + 1) * 512); BN = *(const f32x4*)(ub + ((I) + 1) * 512); } \
-            acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[0], B[0], acc[I], 0, 0, 0);                        \
             __builtin_amdgcn_sched_barrier(0);                                                                 \
-            if ((I) < 2) { glds16(ug + (4 * (I)) * 256, ul + (4 * (I)) * 256); glds16(ug + (4 * (I) + 1) * 256, ul + (4 * (I) + 1) * 256); } \
-            if ((I) >= 2 && (I) < 5) load2(2 * ((I) - 2));                                                     \
-            acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[1], B[1], acc[I], 0, 0, 0);                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
-            if ((I) < 2) { glds16(ug + (4 * (I) + 2) * 256, ul + (4 * (I) + 2) * 256); glds16(ug + (4 * (I) + 3) * 256, ul + (4 * (I) + 3) * 256); } \
-            if ((I) >= 2 && (I) < 5) load2(2 * ((I) - 2) + 1);                                                 \
-            acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[2], B[2], acc[I], 0, 0, 0);                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
-            if ((I) >= 8) store_row((I) - 8);                                                                  \
-            acc[I] = __builtin_amdgcn_mfma_f32_32x32x2f32(A[3], B[3], acc[I], 0, 0, 0);                        \
-            __builtin_amdgcn_sched_barrier(0);                                                                 \
+            WINO_STEP(I, 1, A, B) WINO_STEP(I, 2, A, B) WINO_STEP(I, 3, A, B)                                  \
         }
         WINO_GROUP(0, a0, b0, a1, b1)   WINO_GROUP(1, a1, b1, a0, b0)   WINO_GROUP(2, a0, b0, a1, b1)   WINO_GROUP(3, a1, b1, a0, b0)
         WINO_GROUP(4, a0, b0, a1, b1)   WINO_GROUP(5, a1, b1, a0, b0)   WINO_GROUP(6, a0, b0, a1, b1)   WINO_GROUP(7, a1, b1, a0, b0)
         WINO_GROUP(8, a0, b0, a1, b1)   WINO_GROUP(9, a1, b1, a0, b0)   WINO_GROUP(10, a0, b0, a1, b1)  WINO_GROUP(11, a1, b1, a0, b0)
         WINO_GROUP(12, a0, b0, a1, b1)  WINO_GROUP(13, a1, b1, a0, b0)  WINO_GROUP(14, a0, b0, a1, b1)  WINO_GROUP(15, a1, b1, a0, b0)
+#undef WINO_STEP
 #undef WINO_GROUP
         __syncthreads();
     }
 
+    if (VAR & 32) stamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: Y = A^T M A per (tile, channel), register-local: accumulator register r is tile row (r&3) + 8*(r>>2) + 4*(lane>>5) of
     // this wave's 32 tiles, the lane's column is the output channel
     const int co = ct * WC + wn * 32 + (lane & 31);
@@ -238,8 +314,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
                 if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
                 float* o = obase + ((size_t)(2 * oi + a) * p.W + 2 * oj + b) * p.ldo;
                 if (accum) v += *o;
-                *o = v;
+                if (!(VAR & 8) || v == 12345.678f) *o = v;
             }
+    }
+    if (VAR & 32) {
+        stamp[3] = __builtin_amdgcn_s_memtime();
+        if (tid == 0) {
+            unsigned long long* dbg = (unsigned long long*)p.bnpart + (size_t)blockIdx.x * 4;
+            dbg[0] = stamp[1] - stamp[0]; dbg[1] = stamp[2] - stamp[1]; dbg[2] = stamp[3] - stamp[2]; dbg[3] = (unsigned long long)nchunks;
+        }
+        return;
     }
     if (p.flags & PC_F_BNPART) {
         s1 += __shfl_xor(s1, 32, 64);
@@ -256,6 +340,7 @@ void choose_block(int TH, int TW, int& bth, int& btw) {
         int h = 64 / w;
         if (h > TH) h = TH;
         if (h < 1) continue;
+        if ((2 * h + 2) * (2 * w + 2) * 2 > RMAX * 64) continue;          // the raw patch image must fit its LDS-DMA pieces
         const double blocks = (double)cdiv(TH, h) * cdiv(TW, w);
         const double waste = blocks * 64.0 / ((double)TH * TW);
         const double aspect = (double)(2 * w + 2) * (2 * h + 2) / (4.0 * w * h);      // patch read amplification: prefer square-ish
@@ -269,7 +354,7 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     PC_CHECK_ARG(d->N >= 1 && d->T >= 1 && d->H >= 2 && d->W >= 2 && d->H % 2 == 0 && d->W % 2 == 0, "pc_wino: H, W must be even (H=%d W=%d)", d->H, d->W);
     PC_CHECK_ARG(d->Ci >= 8 && d->Ci % 8 == 0 && d->ldi % 4 == 0 && d->Co >= 1 && d->ldo >= d->Co, "pc_wino: Ci %% 8, ldi %% 4 (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
     PC_CHECK_ARG(d->KT == 1 || d->KT == 3, "pc_wino: KT must be 1 or 3");
-    PC_CHECK_ARG((int64_t)d->N * d->T * d->H * d->W * (int64_t)(d->ldi > d->ldo ? d->ldi : d->ldo) < (1ll << 40), "pc_wino: tensor too large");
+    PC_CHECK_ARG((int64_t)d->N * (d->T > d->Ti ? d->T : d->Ti) * d->H * d->W * (int64_t)(d->ldi > d->ldo ? d->ldi : d->ldo) < (1ll << 40), "pc_wino: tensor too large");
     PC_CHECK_ARG((int64_t)d->H * d->W * d->ldi < (1ll << 31), "pc_wino: plane too large");
     k.N = d->N; k.T = d->T; k.H = d->H; k.W = d->W; k.Ci = d->Ci; k.ldi = d->ldi; k.Co = d->Co; k.ldo = d->ldo;
     k.TH = d->H / 2; k.TW = d->W / 2;
@@ -277,6 +362,8 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     k.nbh = cdiv(k.TH, k.BTH); k.nbw = cdiv(k.TW, k.BTW);
     k.nct = cdiv(d->Co, WC); k.nc8 = d->Ci / WK;
     k.KT = d->KT; k.act = d->act; k.flags = d->flags;
+    PC_CHECK_ARG(d->Ti >= 1 && d->ta >= 1 && d->tden >= 1, "pc_wino: Ti / ta / tden must be >= 1 (Ti=%d ta=%d tden=%d)", d->Ti, d->ta, d->tden);
+    k.Ti = d->Ti; k.ta = d->ta; k.tc = d->tc; k.tden = d->tden;
     return PC_OK;
 }
 
@@ -311,7 +398,7 @@ extern "C" int pc_wino_work(const pc_wino_desc* d, double* out) {
     PC_CHECK_ARG(out, "pc_wino_work: null pointer");
     double taps = 0;                                       // valid temporal taps summed over t
     for (int t = 0; t < k.T; ++t)
-        for (int a = 0; a < k.KT; ++a) { const int tt = t + a - (k.KT >> 1); taps += tt >= 0 && tt < k.T; }
+        for (int a = 0; a < k.KT; ++a) { const int num = t * k.ta + a + k.tc; taps += num >= 0 && num % k.tden == 0 && num / k.tden < k.Ti; }
     const double blocks = (double)k.N * k.nbh * k.nbw * k.nct;
     out[0] = blocks * taps * 16.0 * WT * WC * k.Ci;                                  // issued: 16 transform-domain GEMMs of 64 x 64 x Ci per tap
     out[1] = (double)k.N * taps * 16.0 * ((double)k.TH * k.TW) * k.Co * k.Ci;        // executed on real tiles / channels
@@ -330,15 +417,28 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     PC_CHECK_ARG(!(d->flags & ~(PC_F_BIAS | PC_F_ACCUM | PC_F_BNPART)), "pc_wino_conv: unsupported flag");
     PC_CHECK_ARG(d->act == PC_ACT_NONE || d->act == PC_ACT_RELU, "pc_wino_conv: activation");
     k.in = in; k.U = U; k.bias = bias; k.out = out; k.bnpart = bnpart;
-    static bool attr_set = false;
-    const size_t lds = (size_t)4 * PLANE * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)wino_conv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    static const int var = getenv("PICONS_WINO_VARIANT") ? atoi(getenv("PICONS_WINO_VARIANT")) : 0;
+    const size_t lds = (size_t)(4 * PLANE + 2 * RPLANE) * sizeof(float);
     const dim3 grid((unsigned)((int64_t)k.N * k.T * k.nbh * k.nbw * k.nct));
-    if (pc_tl_ev_start) hipExtLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds, (hipStream_t)s, pc_tl_ev_start, pc_tl_ev_stop, 0, k);
-    else hipLaunchKernelGGL(wino_conv_kernel, grid, dim3(256), lds, (hipStream_t)s, k);
+#define WINO_LAUNCH(V)                                                                                                            \
+    {                                                                                                                             \
+        static bool attr_set = false;                                                                                             \
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)wino_conv_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+        if (pc_tl_ev_start) hipExtLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, pc_tl_ev_start, pc_tl_ev_stop, 0, k); \
+        else hipLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, k);                                   \
+    }
+    switch (var) {
+        case 1: WINO_LAUNCH(1) break;
+        case 2: WINO_LAUNCH(2) break;
+        case 3: WINO_LAUNCH(3) break;
+        case 4: WINO_LAUNCH(4) break;
+        case 7: WINO_LAUNCH(7) break;
+        case 8: WINO_LAUNCH(8) break;
+        case 15: WINO_LAUNCH(15) break;
+        case 32: WINO_LAUNCH(32) break;
+        default: WINO_LAUNCH(0) break;
+    }
+#undef WINO_LAUNCH
     PC_CHECK_LAUNCH("wino_conv_kernel");
     return PC_OK;
 }

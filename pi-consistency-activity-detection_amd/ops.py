@@ -44,9 +44,11 @@ def conv_fwd(d, x, w, out, bias=None, cscale=None, bnpart=None):
     return out
 
 
-def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0):
+def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0, Ti=None, ta=1, tc=None, tden=1):
+    """pc_wino_desc; defaults = temporal stride 1 with padding KT // 2 (see include/picons.h for (ta, tc, tden))."""
     st = capi.WinoDesc()
-    st.N, st.T, st.H, st.W, st.Ci, st.ldi, st.Co, st.ldo, st.KT, st.act, st.flags, st.reserved = N, T, H, W, Ci, ldi, Co, ldo, KT, act, flags, 0
+    st.N, st.T, st.H, st.W, st.Ci, st.ldi, st.Co, st.ldo, st.KT, st.act, st.flags = N, T, H, W, Ci, ldi, Co, ldo, KT, act, flags
+    st.Ti, st.ta, st.tc, st.tden = (T if Ti is None else Ti), ta, (-(KT // 2) if tc is None else tc), tden
     return st
 
 

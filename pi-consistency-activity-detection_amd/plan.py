@@ -332,6 +332,66 @@ class Plan:
             self.final_at[nm] = len(self.lists["bwd"])
             self.final_lane[nm] = self.lane
 
+    # ------------------------------------------------------------------ Winograd F(2x2, 3x3) form of the stride-1 3x3x3 layers
+    def wino_ok(self, x, cout, k, stride, pad=None):
+        """The layers that run in Winograd form (csrc/wino.hip, 2.25x fewer multiply-accumulates, measured 1.5 - 2.2x faster than
+        the gather-GEMM kernel on them; 1x3x3 at 28x28 measured slower and stays): 3x3x3 convs with spatial stride 1 (any temporal
+        stride: the temporal taps stay direct) and same padding over >= 2 frames, even H, W and enough channels to fill the kernel's
+        64 x 64 (tiles x channels) block.  PICONS_WINO=0: off."""
+        if os.environ.get("PICONS_WINO", "1") == "0":
+            return False
+        if tuple(k) != (3, 3, 3) or tuple(stride[1:]) != (1, 1) or stride[0] not in (1, 2) or (pad is not None and tuple(pad) != (1, 1, 1)):
+            return False
+        T, H, W = x.thw
+        return T >= 2 and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= 32 and cout >= 64 and x.ld % 4 == 0
+
+    def wino_weights(self, wname, O, I, need_tr):
+        """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
+        gradient, from its transpose with mirrored taps: strides + flip, no intermediate layout)."""
+        nU = capi.lib().pc_wino_u_floats(O, I, 3)
+        u = dict(fwd=self.alloc(nU))
+        src = self.P(wname)
+        saved_target = self.prep_target
+        if self.late_prep and wname.startswith("conv1.Conv3d_2c_3x3"):
+            self.prep_target = "prep"          # needed before the late-prep list has run
+        pl = self.next_prep_lane()
+        self.emit(capi.OP_WINO_WEIGHTS, i=[O, I, 3, 0], l=[I * 27, 1, 27], p=[src, u["fwd"]], lst=self.prep_target, lane=pl)
+        if need_tr:
+            u["tr"] = self.alloc(capi.lib().pc_wino_u_floats(I, O, 3))
+            self.emit(capi.OP_WINO_WEIGHTS, i=[I, O, 3, 1], l=[27, 1, I * 27], p=[src, u["tr"]], lst=self.prep_target, lane=pl)
+        self.prep_target = saved_target
+        if wname in self.kw:               # finalize() lays a skip conv's weights out on the skip lane, in front of the conv
+            self.kw[wname]["wino_fwd"], self.kw[wname]["wino_tr"] = u["fwd"], u.get("tr")
+        return u
+
+    @staticmethod
+    def _wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act=0, flags=0):
+        d = capi.WinoDesc()
+        d.N, d.T, d.H, d.W, d.Ci, d.ldi, d.Co, d.ldo, d.KT, d.act, d.flags = N, othw[0], othw[1], othw[2], Ci, ldi, Co, ldo, 3, act, flags
+        d.Ti, d.ta, d.tc, d.tden = Ti, tmap[0], tmap[1], tmap[2]
+        return d
+
+    def wino_op(self, x_ref, N, othw, Ti, Ci, ldi, Co, ldo, tmap, U, out_ref, bias=None, bnpart=None, act=0, flags=0):
+        """One pc_wino_conv launch: output frames / positions othw, Ti input frames, tmap = (ta, tc, tden) of pc_wino_desc."""
+        import ctypes as C
+        d = self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act, flags)
+        out = (C.c_double * 3)()
+        capi.check(capi.lib().pc_wino_work(C.byref(d), out))
+        for key, v in (("wino_mfma", out[0]), ("wino_executed", out[1])):
+            self.work[(self.cur, key)] = self.work.get((self.cur, key), 0) + 2 * v
+        il = self.emit(capi.OP_WINO_CONV, i=[getattr(d, f) for f, _t in capi.WinoDesc._fields_], p=[x_ref, U, bias, out_ref, bnpart])
+        self.op_work[id(il)] = dict(issued=out[0], executed=out[1], valid=out[1], blocks=int(out[2]), wino=True)
+        return d
+
+    def wino_bnpart_rows(self, N, othw, Ti, Ci, ldi, Co, ldo, tmap):
+        import ctypes as C
+        return capi.lib().pc_wino_bnpart_rows(C.byref(self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap)))
+
+    def wino_flops_executed(self):
+        """Per list: FLOPs of the Winograd launches -- `mfma` issued to the matrix cores (whole 64 x 64 blocks), `executed` on real tiles
+        and channels (transform-domain multiply-accumulates: 16 per 2x2 output tile, tap and channel pair, where the direct form does 36)."""
+        return {name: {k: self.work.get((name, "wino_" + k), 0) for k in ("mfma", "executed")} for name in self.lists}
+
     # ------------------------------------------------------------------ layers
     def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None):
         """alg: algorithmic FLOPs to book for this launch (default: the descriptor's own 2*M*N*K with all taps).
@@ -404,7 +464,26 @@ class Plan:
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
-        if self.training:
+        wino = len(pres) == 1 and Ci == Ci_real and self.wino_ok(x, cout, k, stride)
+        wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training) if wino else None
+        tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
+        tmap_b = (1, pf[0] - 2, stride[0])                 # input gradient (mirrored taps): frame (t + pad_front - 2 + kt) / s
+        if self.training and wino:
+            nrows = self.wino_bnpart_rows(x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f)
+            part = self.alloc(nrows * 2 * cout)
+            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART)
+            self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
+                      f=[spec.BN_EPS, spec.BN_MOMENTUM],
+                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
+            g_apply = self.groups
+        elif wino:
+            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref)
+            self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
+                      p=[gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
+            g_apply = 1
+        elif self.training:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART | (capi.F_CI3 if ci3 else 0), groups=self.groups)
             d["Ci_real"] = Ci_real
             nrows = _bnpart_rows(d)
@@ -443,8 +522,11 @@ class Plan:
                 dz = st["dz"]
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd)
-                for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
-                    self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
+                if wino:      # the input gradient of a stride-1 same-padded conv is the same correlation with mirrored, transposed weights
+                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
+                else:
+                    for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
+                        self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
         self.tape.append(bwd)
         return y
 
@@ -552,8 +634,16 @@ class Plan:
     def conv_layer(self, name, x, cout, k, pad, act, out, need_dx=True):
         """Decoder skip convs conv28/conv56/conv112 (capsules_ucf101.py:380-384,490,497,501)."""
         w = self.prep_conv_weight([name + ".weight"], [cout], x.C, k, need_dx)
-        othw = self.conv_bias_act(name + ".weight", x, cout, k, pad, act, out, bias_ref=self.P(name + ".bias"))
-        F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
+        wino = act in (capi.ACT_NONE, capi.ACT_RELU) and self.wino_ok(x, cout, k, (1, 1, 1), pad)
+        if wino:
+            othw = tuple(x.thw)
+            wu = self.wino_weights(name + ".weight", cout, x.C, need_dx and self.training)
+            F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
+            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.wino_op(x.ref, x.N, othw, x.thw[0], x.C, x.ld, cout, out.ld, (1, -1, 1), wu["fwd"], out.ref, bias=self.P(name + ".bias"), act=act, flags=capi.F_BIAS)
+        else:
+            othw = self.conv_bias_act(name + ".weight", x, cout, k, pad, act, out, bias_ref=self.P(name + ".bias"))
+            F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
 
         def bwd():
             dy = self.grad_of(out)
@@ -567,8 +657,11 @@ class Plan:
             if need_dx:
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd)
-                for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
-                    self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
+                if wino:
+                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, x.C, dx.ld, (1, -1, 1), wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
+                else:
+                    for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
+                        self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
         self.tape.append(bwd)
 
     def _skip_conv(self, name, x, cat):
@@ -1118,7 +1211,8 @@ class Plan:
             mine = set()
             for nm in ("conv56.weight", "conv112.weight"):
                 if nm in self.kw:
-                    mine |= {self.kw[nm].get("fwd"), self.kw[nm].get("tr")}
+                    mine |= {self.kw[nm].get("fwd"), self.kw[nm].get("tr"), self.kw[nm].get("wino_fwd"), self.kw[nm].get("wino_tr")}
+            mine.discard(None)
             lane_of = lambda op: self.skip_lane if (self.skip_lane and any(r in mine for r in op[3] if r is not None)) else self.wg_lane
             late[:] = [(capi.OP_FORK, [(1 << self.wg_lane | 1 << self.skip_lane) & ~1, 0], [], [], [], 0)] + [op[:5] + (lane_of(op),) for op in late]
 
@@ -1177,7 +1271,7 @@ class Plan:
         for op in lst:
             if op[0] == capi.OP_TRANSPOSE and op[3][0][0] == "P":
                 pending.setdefault(op[5], []).append(op)
-            elif op[0] in (capi.OP_FILL, capi.OP_FORK, capi.OP_WSPEC_MASTER_FWD):
+            elif op[0] in (capi.OP_FILL, capi.OP_FORK, capi.OP_WSPEC_MASTER_FWD, capi.OP_WINO_WEIGHTS):
                 res.append(op)           # fills precede the transposes into their buffer; the fork opens the region; the
                                          # master-layout weight planes touch nothing the transposes do
             else:

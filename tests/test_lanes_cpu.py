@@ -18,7 +18,7 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_TAIL6_GATHER: (3,), capi.OP_TAIL6_SCATTER: (1,), capi.OP_TAIL6_BIAS_SUMS: (1,), capi.OP_TAIL6_WGRAD_MAP: (1,),
           capi.OP_TAIL_GRADS: (6, 7, 8, 9), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
           capi.OP_WSPEC_MASTER_BWD: (2,), capi.OP_LOSS: (4, 5, 6, 7, 8, 9), capi.OP_SPREAD: (3, 4), capi.OP_ADAM: (0, 2, 3), capi.OP_COL2IM: (1,),
-          capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,)}
+          capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,)}
 
 
 def _plan(lanes, bs=1, hw=112):
@@ -131,12 +131,12 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
             assert _forks(p, name, 1 << p.skip_lane) == 2, name          # conv56, conv112
     if p.skip_lane and p.skip_lane != p.wg_lane:
         on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
-        assert sum(1 for op in on_skip if op[0] == capi.OP_CONV) == 4
+        assert sum(1 for op in on_skip if op[0] in (capi.OP_CONV, capi.OP_WINO_CONV)) == 4
     if p.wg_lane:
         wg = [op for op in p.lists["bwd"] if op[0] in (capi.OP_WGRAD, capi.OP_WGRAD_MULTI)]
         assert all(op[5] == p.wg_lane for op in wg)
         assert not any(op[0] == capi.OP_WGRAD_MULTI for op in wg)          # grouped launches are opt-in (PICONS_WGRAD_MULTI*)
-        assert sum(1 for op in p.lists["fwd"] if op[5] == p.wg_lane and op[0] == capi.OP_CONV) >= 7
+        assert sum(1 for op in p.lists["fwd"] if op[5] == p.wg_lane and op[0] in (capi.OP_CONV, capi.OP_WINO_CONV)) >= 7
 
 
 def test_inception_wgrads_as_grouped_launches(monkeypatch):

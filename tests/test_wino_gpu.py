@@ -88,6 +88,34 @@ def test_wino_input_gradient_through_flipped_weights(KT):
     assert (dx.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("T", [4, 5])
+def test_wino_temporal_stride_two_forward_and_input_gradient(T):
+    """Conv3d_2c (pytorch_i3d.py:236-238 as this model strides it): 3x3x3, stride (2, 1, 1), TF-SAME padding along t (front = pad // 2,
+    Unit3D.compute_pad :82-109).  Forward frame t reads input frames 2t - front + kt; the input gradient is the transposed map
+    (only every other (frame, tap) pair exists)."""
+    N, H, W, Ci, Co, s = 2, 8, 12, 16, 24, 2
+    pad = max(3 - s, 0) if T % s == 0 else max(3 - T % s, 0)
+    front, back = pad // 2, pad - pad // 2
+    To = (T + pad - 3) // s + 1
+    g = torch.Generator().manual_seed(11 + T)
+    x = torch.randn(N, T, H, W, Ci, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    dy = torch.randn(N, To, H, W, Co, generator=g, dtype=torch.float64)
+    xp = F.pad(x.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, front, back))
+    y = F.conv3d(xp, w, stride=(s, 1, 1)).permute(0, 2, 3, 4, 1)
+    assert y.shape[1] == To
+    (y * dy).sum().backward()
+    wd = w.float().cuda().contiguous()
+    U = ops.wino_weights(wd, Co, Ci, 3)
+    out = torch.empty(N, To, H, W, Co, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, To, H, W, Ci, Ci, Co, Co, 3, Ti=T, ta=s, tc=-front, tden=1), x.detach().float().cuda(), U, out)
+    assert (out.cpu().double() - y.detach()).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    Ut = ops.wino_weights(wd, Ci, Co, 3, flip=True, strides=(27, 1, Ci * 27))
+    dx = torch.empty(N, T, H, W, Ci, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Co, Co, Ci, Ci, 3, Ti=To, ta=1, tc=front - 2, tden=s), dy.float().cuda(), Ut, dx)
+    assert (dx.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("thw,Ci,Co", [((4, 112, 112), 64, 64), ((2, 56, 56), 64, 192), ((2, 56, 56), 192, 64)])
 def test_wino_real_shapes_vs_gather_gemm(thw, Ci, Co):
     N = 16

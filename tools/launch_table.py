@@ -36,11 +36,11 @@ def main():
     p = Plan(24, 224, n=8, groups=2, lanes=1)
     p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
     p.finalize()
-    ops = [(name, op) for name in ("prep", "fwd", "loss", "bwd") for op in p.lists[name] if op[0] in (capi.OP_CONV, capi.OP_WGRAD)]
+    ops = [(name, op) for name in ("prep", "fwd", "loss", "bwd") for op in p.lists[name] if op[0] in (capi.OP_CONV, capi.OP_WGRAD, capi.OP_WINO_CONV)]
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad4_kernel" in r["Kernel_Name"]]
+    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if "conv_gemm" in r["Kernel_Name"] or "wgrad_kernel" in r["Kernel_Name"] or "wgrad3_kernel" in r["Kernel_Name"] or "wgrad4_kernel" in r["Kernel_Name"] or "wino_conv_kernel" in r["Kernel_Name"]]
     def n_kernels(op):
         """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (pc_wgrad_work's launch count)."""
         return p.op_work[id(op[1])]["launches"] if op[0] == capi.OP_WGRAD else 1
@@ -56,7 +56,12 @@ def main():
         kn = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
         blocks = int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]) // int(r["Workgroup_Size_X"])
         w = p.op_work[id(op[1])]          # host-side walk of the launch's tiles (pc_conv_work / pc_wgrad_work): MACs as the kernel runs them
-        if op[0] == capi.OP_CONV:
+        if op[0] == capi.OP_WINO_CONV:
+            if "wino" not in kn:
+                raise SystemExit("order mismatch: winograd op paired with " + kn)
+            N_, T_, H_, W_, Ci_, _l, Co_ = op[1][:7]
+            what = "wino  M=%-7d Co=%-5d Ci=%-4d taps=3x(4x4 transform domain)" % (N_ * T_ * H_ * W_, Co_, Ci_)
+        elif op[0] == capi.OP_CONV:
             if "wgrad" in kn:
                 raise SystemExit("order mismatch: conv op paired with " + kn)
             d = unflat(op[1], D.CONV_FIELDS)
@@ -79,7 +84,7 @@ def main():
     if over:
         raise SystemExit("%d launches above the 157.3 TF/s peak even by issued MFMA FLOPs: accounting error" % len(over))
     tot = sum(x[0] for x in out)
-    for label, sel in (("conv / dgrad", lambda x: "wgrad" not in x[5]), ("weight gradients", lambda x: "wgrad" in x[5])):
+    for label, sel in (("conv / dgrad", lambda x: "conv_gemm" in x[5]), ("winograd conv", lambda x: "wino" in x[5]), ("weight gradients", lambda x: "wgrad" in x[5])):
         xs = [x for x in out if sel(x)]
         t = sum(x[0] for x in xs)
         print("%-16s %3d launches %6.2f ms/step: executed %.1f GF = %.1f TF/s (%.3f of peak), mfma-issued %.1f TF/s (%.3f), valid %.1f TF/s (%.3f)" %

@@ -1,0 +1,54 @@
+#!/usr/bin/env python3
+"""Diagnostic for csrc/wino.hip: one process per PICONS_WINO_VARIANT (ablations give wrong results by design), conv112 and conv56 shapes.
+    python tools/probe_wino.py            # runs every variant in a child process
+Variant 32 prints in-kernel s_memtime spans (prologue / K loop / epilogue, cycles per K chunk)."""
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+SHAPES = [("conv112 64->64 @4x112x112", (4, 112, 112), 64, 64), ("192->64 @2x56x56", (2, 56, 56), 192, 64), ("64->192 @2x56x56", (2, 56, 56), 64, 192)]
+NAMES = {0: "product", 1: "no patch loads", 2: "no U DMA", 3: "no loads, no DMA", 4: "no transform stores", 7: "MFMA + LDS reads only", 8: "no output stores",
+         15: "MFMA loop + inverse only", 32: "stamps"}
+
+
+def child(var):
+    import numpy as np
+    import torch
+    import picons_amd  # noqa
+    from picons_amd import ops
+    N, R = 16, 10
+    for name, thw, Ci, Co in SHAPES:
+        x = torch.randn(N, *thw, Ci, device="cuda").clamp_min(0)
+        w = torch.randn(Co, Ci, 3, 3, 3, device="cuda") * (1.0 / np.sqrt(27 * Ci))
+        out = torch.empty(N, *thw, Co, device="cuda")
+        U = ops.wino_weights(w, Co, Ci, 3)
+        wd = ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3)
+        dbg = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
+        fn = lambda: ops.wino_conv(wd, x, U, out, bnpart=dbg)
+        for _ in range(2):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(R):
+            fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / R
+        line = "var %2d %-26s %-28s %7.3f ms" % (var, NAMES.get(var, "?"), name, dt * 1e3)
+        if var == 32:
+            d = dbg.cpu().numpy().reshape(-1, 4)
+            d = d[d[:, 3] > 0]
+            med = lambda a: float(np.median(a))
+            line += "   blocks %d  prologue %.0f  loop %.0f (%.0f / chunk)  epilogue %.0f cycles (medians; 100 MHz memtime units x ?)" % (
+                len(d), med(d[:, 0]), med(d[:, 1]), med(d[:, 1] / d[:, 3]), med(d[:, 2]))
+        print(line, flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1:
+        child(int(sys.argv[1]))
+    else:
+        for v in (0, 1, 2, 3, 4, 7, 8, 15, 32):
+            subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=dict(os.environ, PICONS_WINO_VARIANT=str(v)))
