@@ -27,6 +27,7 @@ struct WinoK {
     int TH, TW, BTH, BTW, nbh, nbw, nct, nc8;
     int KT, act, flags;
     int Ti, ta, tc, tden;
+    int btw_magic;
 };
 
 constexpr int WT = 64;            // tiles per block (rows of the transform-domain GEMMs)
@@ -135,21 +136,26 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     }
     const int nchunks = nkt * p.nc8;
     const size_t plane_in = (size_t)p.H * p.W * p.ldi;
-    auto tap_of = [&](int c, int& kt, int& tt, int& c8) {          // chunk -> (weight tap, source frame, 8-channel slice)
-        const int q = c / p.nc8;
-        c8 = c - q * p.nc8;
-        kt = q == 0 ? ktl0 : (q == 1 ? ktl1 : ktl2);
-        tt = q == 0 ? ttl0 : (q == 1 ? ttl1 : ttl2);
+    // chunk c = (valid tap q, 8-channel slice c8).  Two chunk counters run ahead of the MFMA loop -- the U stream one chunk, the raw-patch
+    // stream two -- and are advanced incrementally (an integer division per chunk and stream cost 20 % of the kernel); both stop at the
+    // last chunk, which the tail iterations re-fetch harmlessly.
+    const float* rtap0 = p.in + ((size_t)n * p.Ti + ttl0) * plane_in;
+    const float* rtap1 = p.in + ((size_t)n * p.Ti + ttl1) * plane_in;
+    const float* rtap2 = p.in + ((size_t)n * p.Ti + ttl2) * plane_in;
+    const float* utap0 = p.U + (((size_t)ktl0 * p.nct + ct) * p.nc8) * PLANE + wave * 8 * 256;
+    const float* utap1 = p.U + (((size_t)ktl1 * p.nct + ct) * p.nc8) * PLANE + wave * 8 * 256;
+    const float* utap2 = p.U + (((size_t)ktl2 * p.nct + ct) * p.nc8) * PLANE + wave * 8 * 256;
+    auto advance = [&](int& q, int& c8) {
+        const bool wrap = c8 + 1 == p.nc8, last = wrap && q + 1 >= nkt;
+        c8 = last ? c8 : (wrap ? 0 : c8 + 1);
+        q = (wrap && !last) ? q + 1 : q;
     };
+    auto r_base = [&](int q, int c8) -> const float* { return (q == 0 ? rtap0 : (q == 1 ? rtap1 : rtap2)) + c8 * WK; };
+    auto u_base = [&](int q, int c8) -> const float* { return (q == 0 ? utap0 : (q == 1 ? utap1 : utap2)) + (size_t)c8 * PLANE + lane * 4; };
+    int uq = 0, uc8 = 0, rq = 0, rc8 = 0;
 
     const float* rnext = nullptr;                 // source plane / channel slice of the chunk whose raw patch the loop fetches
-    auto r_base = [&](int c) -> const float* {
-        int kt, tt, c8;
-        tap_of(min(c, nchunks - 1), kt, tt, c8);
-        return p.in + ((size_t)n * p.Ti + tt) * plane_in + c8 * WK;
-    };
-    auto issue_r = [&](int c, int rb) {           // raw patch of chunk c -> R[rb] (prologue)
-        const float* base = r_base(c);
+    auto issue_r = [&](const float* base, int rb) {           // raw patch -> R[rb] (prologue)
         float* rl = Rs + rb * RPLANE + wave * 256;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
@@ -159,12 +165,6 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     };
     const float* ug = nullptr;
     float* ul = nullptr;
-    auto set_u = [&](int c, int buf) {
-        int kt, tt, c8;
-        tap_of(min(c, nchunks - 1), kt, tt, c8);
-        ug = p.U + (((size_t)kt * p.nct + ct) * p.nc8 + c8) * PLANE + wave * 8 * 256 + lane * 4;
-        ul = Us + buf * PLANE + wave * 8 * 256;
-    };
     f32x4 d[12], x0[4], x1[4];
     const float* rsrc = nullptr;
     float* vb = nullptr;
@@ -221,11 +221,15 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int aoff = (kh * 64 + wm * 32 + (lane & 31)) * 4, boff = (kh * 64 + wn * 32 + (lane & 31)) * 4;
     // prologue: R(0), R(1), U(0) in flight; V(0) from R(0)
     if (nchunks > 0) {
-        issue_r(0, 0);
-        issue_r(1, 1);
-        set_u(0, 0);
+        issue_r(r_base(rq, rc8), 0);
+        advance(rq, rc8);
+        issue_r(r_base(rq, rc8), 1);
+        advance(rq, rc8);                         // -> chunk 2
+        ug = u_base(uq, uc8);
+        ul = Us + wave * 8 * 256;
 #pragma unroll
         for (int j = 0; j < 8; ++j) glds16<!(VAR & 2)>(ug + j * 256, ul + j * 256);
+        advance(uq, uc8);                         // -> chunk 1
     }
     __syncthreads();
     if (nchunks > 0) {
@@ -246,13 +250,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
         // during chunk c: U(c+1) -> U[buf^1], R(c+2) -> R[buf] (R[buf] held chunk c, transformed one iteration ago), V(c+1) from R[buf^1]
-        set_u(c + 1, buf ^ 1);
+        ug = u_base(uq, uc8);
+        ul = Us + (buf ^ 1) * PLANE + wave * 8 * 256;
+        advance(uq, uc8);
         rsrc = Rs + (buf ^ 1) * RPLANE + rbase;
         vb = Vs + (buf ^ 1) * PLANE + (tkh * 64 + ttile) * 4;
         const float* va = Vs + buf * PLANE + aoff;
         const float* ub = Us + buf * PLANE + boff;
         f32x4 a0 = *(const f32x4*)va, b0 = *(const f32x4*)ub, a1, b1;
-        rnext = r_base(c + 2);
+        rnext = r_base(rq, rc8);
+        advance(rq, rc8);
         // one group = the four MFMAs of one transform-domain position, with one piece of side work pinned behind each of them
         // (sched_barrier: the compiler otherwise gathers the side work, waits for it at once and strands the matrix pipe)
 #define WINO_STEP(I, E, A, B)                                                                                  \
@@ -289,7 +296,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        const int li = m / p.BTW, lj = m - li * p.BTW;
+        const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;      // m / BTW for m < 64 (exact: magic = ceil(65536 / BTW))
         const int oi = bh * p.BTH + li, oj = bw * p.BTW + lj;
         const bool ok = cval && m < p.BTH * p.BTW && oi < p.TH && oj < p.TW;
         float s[4][2];
@@ -360,6 +367,7 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     k.TH = d->H / 2; k.TW = d->W / 2;
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
     k.nbh = cdiv(k.TH, k.BTH); k.nbw = cdiv(k.TW, k.BTW);
+    k.btw_magic = (65536 + k.BTW - 1) / k.BTW;
     k.nct = cdiv(d->Co, WC); k.nc8 = d->Ci / WK;
     k.KT = d->KT; k.act = d->act; k.flags = d->flags;
     PC_CHECK_ARG(d->Ti >= 1 && d->ta >= 1 && d->tden >= 1, "pc_wino: Ti / ta / tden must be >= 1 (Ti=%d ta=%d tden=%d)", d->Ti, d->ta, d->tden);
@@ -442,3 +450,4 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     PC_CHECK_LAUNCH("wino_conv_kernel");
     return PC_OK;
 }
+

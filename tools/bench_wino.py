@@ -7,6 +7,7 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes as C
 import numpy as np
 import torch
 import picons_amd  # noqa
@@ -52,3 +53,4 @@ for name, thw, Ci, Co in SHAPES:
     print("%-38s direct %7.3f ms (%5.1f TF/s executed)   winograd %7.3f ms (%5.1f TF/s issued, %5.1f TF/s direct-equivalent)   x%.2f   "
           "weights %.3f ms   rel err %.1e   blocks %d" % (name, t_dir * 1e3, 2 * wk_["executed"] / t_dir / 1e12, t_win * 1e3, 2 * o3[0] / t_win / 1e12,
                                                         2 * wk_["executed"] / t_win / 1e12, t_dir / t_win, t_u * 1e3, err, int(o3[2])), flush=True)
+

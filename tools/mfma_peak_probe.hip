@@ -84,6 +84,67 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ src, f
     if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
 }
 
+// MODE 0 of the probe plus F dependent-free v_fma_f32 fillers behind every MFMA: does the fp32 matrix pipe run beside the same wave's
+// vector instructions (it executes at the fp32 VECTOR rate), and does a second wave per SIMD change what fillers cost?
+template <int F>
+__global__ __launch_bounds__(256, 2) void probe_fill(const float* __restrict__ src, float* __restrict__ out, unsigned long long* stamps, int nchunks) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x;
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a0 = src[tid], b0 = src[tid + 256];
+    float f[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) f[k] = src[tid + 512 + k * 256];
+    if (tid == 0) smem[0] = a0;
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int m = 0; m < 32; ++m) {
+            acc[m & 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[m & 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int k = 0; k < F; ++k) f[k & 15] = __builtin_fmaf(f[k & 15], 1.0001f, 0.25f);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[i][r];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += f[k];
+    out[(size_t)blockIdx.x * 256 + tid] = s;
+    if (tid == 0) { stamps[2 * blockIdx.x] = t1 - t0; stamps[2 * blockIdx.x + 1] = r1 - r0; }
+}
+
+template <int F>
+static void run_fill(int blocks_per_cu, int nchunks, const float* src, float* out, unsigned long long* stamps) {
+    const int lds = (160 * 1024 / blocks_per_cu) - 1024;
+    CK(hipFuncSetAttribute((const void*)probe_fill<F>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int grid = 256 * blocks_per_cu * 4;
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int w = 0; w < 2; ++w) hipLaunchKernelGGL(probe_fill<F>, dim3(grid), dim3(256), lds, 0, src, out, stamps, nchunks);
+    CK(hipDeviceSynchronize());
+    const int R = 10;
+    CK(hipEventRecord(e0, 0));
+    for (int r = 0; r < R; ++r) hipLaunchKernelGGL(probe_fill<F>, dim3(grid), dim3(256), lds, 0, src, out, stamps, nchunks);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    ms /= R;
+    const double flops = (double)grid * 4 * nchunks * 32.0 * (32.0 * 32 * 2 * 2);
+    printf("fillers per MFMA %2d   blocks/CU %d (waves/SIMD %d)  %8.3f ms  %7.1f TF/s  (%.3f of 157.3)\n", F, blocks_per_cu, blocks_per_cu, ms, flops / ms / 1e9, flops / ms / 1e9 / 157.3);
+    fflush(stdout);
+}
+
 template <int MODE>
 static void run(const char* name, int blocks_per_cu, int nchunks, const float* src, float* out, unsigned long long* stamps) {
     // LDS per block decides residency: 160 KiB / blocks_per_cu (minus a little), at least the 48 KiB the loop uses
@@ -122,6 +183,17 @@ int main() {
     for (auto& v : h) { x = x * 1664525u + 1013904223u; v = ((x >> 8) & 0xffff) / 65536.0f - 0.5f; }
     CK(hipMemcpy(src, h.data(), h.size() * 4, hipMemcpyHostToDevice));
     const int nchunks = 216;     // 4 x the 54 chunks of conv112's K = 27 * 64
+    if (getenv("PROBE_FILL")) {
+        for (int bpc = 1; bpc <= 2; ++bpc) {
+            run_fill<0>(bpc, nchunks, src, out, stamps);
+            run_fill<2>(bpc, nchunks, src, out, stamps);
+            run_fill<4>(bpc, nchunks, src, out, stamps);
+            run_fill<8>(bpc, nchunks, src, out, stamps);
+            run_fill<12>(bpc, nchunks, src, out, stamps);
+            run_fill<16>(bpc, nchunks, src, out, stamps);
+        }
+        return 0;
+    }
     for (int bpc = 1; bpc <= 3; ++bpc) {
         run<0>("0 registers only", bpc, nchunks, src, out, stamps);
         run<1>("1 + fragment reads (ds_read_b128)", bpc, nchunks, src, out, stamps);
