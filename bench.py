@@ -326,6 +326,20 @@ def main():
     ms_step = ms_total / a.steps
     value = world * a.bs * a.steps / (ms_total / 1e3)
 
+    # ---- the second GEMM family, the Winograd conv kernel: its launches get hipEvent pairs in two extra single-stream steps (outside the
+    # timed region above, whose event legs belong to the gather-GEMM family: one op kind per timed replay)
+    conv_kind_ms, conv_kind_count = eng.kind_ms, eng.kind_count
+    wino_ms = wino_count = wino_steps = 0
+    if kind is not None:
+        eng.kind_ms, eng.kind_count = 0.0, 0
+        for _ in range(2):
+            eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=capi.OP_WINO_CONV, collect=False)
+            wino_steps += 1
+        torch.cuda.synchronize()
+        eng.collect_timing()
+        wino_ms, wino_count = eng.kind_ms, eng.kind_count
+        eng.kind_ms, eng.kind_count = conv_kind_ms, conv_kind_count
+
     # ---- the same step with the reference's per-step input work inside the timed region (every rank, same barrier / max rule)
     staged = None
     if not a.resident_inputs and a.bs % 2 == 0 and not a.jhmdb:
@@ -388,6 +402,19 @@ def main():
                 "launches_per_step": eng.kind_count // max(1, timed_steps), "avg_launch_ms": avg_ms,
                 "kernel_ms_per_step": eng.kind_ms / max(1, timed_steps), "timed_steps": timed_steps,
                 "flops_per_launch": conv_exec * timed_steps / eng.kind_count}
+    roof_wino = None
+    if wino_count:
+        fzw = sum(fz[n]["executed"] for n in lists)
+        fzm = sum(fz[n]["mfma"] for n in lists)
+        fzd = sum(eng.plan.flops_reference_counted_wino()[n] for n in lists)
+        wms = wino_ms / wino_steps
+        roof_wino = {"bound": "mfma", "kernel": "wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)",
+                     "achieved": fzw / (wms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": fzw / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                     "frac_mfma_issued": fzm / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                     "direct_equivalent_tflops": fzd / (wms * 1e-3) / 1e12,      # the 3x3x3 formulation's FLOPs over the same time (2.25x the transform-domain work)
+                     "launches_per_step": wino_count // wino_steps, "kernel_ms_per_step": wms, "timed_steps": wino_steps,
+                     "flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"}
     roof_step = {"executed_gflop_per_step": step_exec / 1e9, "achieved": step_exec / (ms_step * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": step_exec / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                  "descriptor_gflop_per_step": sum(fl[n] for n in lists) / 1e9,
@@ -409,6 +436,7 @@ def main():
         "loss": last,
         "staged": staged,
         "roofline": roof,
+        "roofline_winograd": roof_wino,
         "roofline_step": roof_step,
         "ranks_observed": ranks_observed,
         "reducer": None if reducer is None else {"buckets": len(reducer.buckets), "backend": torch.distributed.get_backend(),

@@ -208,7 +208,7 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         const bool t = kind > 0 && op.kind == kind;
         // a conv op is exactly one kernel: its event pair rides in the dispatch itself (no extra packets on the stream);
         // any other kind is bracketed by recorded events
-        const bool ext = t && op.kind == PC_OP_CONV && !g_no_ext_events;
+        const bool ext = t && (op.kind == PC_OP_CONV || op.kind == PC_OP_WINO_CONV) && !g_no_ext_events;
         if (ext) { pc_tl_ev_start = ev[2 * j]; pc_tl_ev_stop = ev[2 * j + 1]; }
         else if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
         rc = run_one(op, s);

@@ -144,6 +144,7 @@ class Plan:
         self.kg_used = 0
         self.final_at = {}        # param name -> number of bwd ops after which its gradient in G is final
         self.alg_flops = {}       # list name -> conv FLOPs as the layer's own formulation counts them (all taps, padding included)
+        self.alg_flops_wino = {}  # the same for the layers that run in Winograd form (their launches are not OP_CONV)
         self.issued = {}          # (list name, op kind) -> FLOPs the emitted (trimmed) descriptors multiply, real channel counts
         self.work = {}            # (list name, "mfma" | "executed" | "valid") -> conv / dgrad FLOPs as the kernels run them (pc_conv_work)
         self.op_work = {}         # id(op's int list) -> pc_conv_work / pc_wgrad_work of that launch
@@ -281,8 +282,9 @@ class Plan:
         self._prep_rr = (getattr(self, "_prep_rr", -1) + 1) % self.lanes
         return self._prep_rr
 
-    def alg_dgrad(self, fwd_flops):
-        self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + fwd_flops
+    def alg_dgrad(self, fwd_flops, wino=False):
+        tab = self.alg_flops_wino if wino else self.alg_flops
+        tab[self.cur] = tab.get(self.cur, 0) + fwd_flops
 
     def flush_grad(self, w):
         """Kernel-layout weight gradient -> reference layout in the flat G buffer, emitted right after the
@@ -471,14 +473,14 @@ class Plan:
         if self.training and wino:
             nrows = self.wino_bnpart_rows(x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f)
             part = self.alloc(nrows * 2 * cout)
-            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
             self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART)
             self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
                       f=[spec.BN_EPS, spec.BN_MOMENTUM],
                       p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
             g_apply = self.groups
         elif wino:
-            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
             self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref)
             self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
                       p=[gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
@@ -521,7 +523,7 @@ class Plan:
             if need_dx and part in ("all", "B"):
                 dz = st["dz"]
                 dx, acc = self.grad_for_write(x)
-                self.alg_dgrad(F_fwd)
+                self.alg_dgrad(F_fwd, wino)
                 if wino:      # the input gradient of a stride-1 same-padded conv is the same correlation with mirrored, transposed weights
                     self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
                 else:
@@ -639,7 +641,7 @@ class Plan:
             othw = tuple(x.thw)
             wu = self.wino_weights(name + ".weight", cout, x.C, need_dx and self.training)
             F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
-            self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + F_fwd
+            self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
             self.wino_op(x.ref, x.N, othw, x.thw[0], x.C, x.ld, cout, out.ld, (1, -1, 1), wu["fwd"], out.ref, bias=self.P(name + ".bias"), act=act, flags=capi.F_BIAS)
         else:
             othw = self.conv_bias_act(name + ".weight", x, cout, k, pad, act, out, bias_ref=self.P(name + ".bias"))
@@ -656,7 +658,7 @@ class Plan:
             self.mark_final(name + ".bias")
             if need_dx:
                 dx, acc = self.grad_for_write(x)
-                self.alg_dgrad(F_fwd)
+                self.alg_dgrad(F_fwd, wino)
                 if wino:
                     self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, x.C, dx.ld, (1, -1, 1), wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
                 else:
@@ -1301,6 +1303,10 @@ class Plan:
         """Conv / dgrad FLOPs per list as the layers' own formulation counts them (all taps incl. padding; every dgrad at its
         layer's forward FLOPs).  Kept beside flops() so the two roofline fractions can be told apart."""
         return {name: self.alg_flops.get(name, 0) for name in self.lists}
+
+    def flops_reference_counted_wino(self):
+        """The same count for the layers that run in Winograd form: what their direct 3x3x3 formulation multiplies (2.25x the transform-domain work)."""
+        return {name: self.alg_flops_wino.get(name, 0) for name in self.lists}
 
 
 def _conv_flops(d):

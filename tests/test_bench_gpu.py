@@ -45,6 +45,9 @@ def test_bench_line_contract():
     assert r["traffic"] is None or r["traffic"] > 1e6
     # the numerator is what the kernels execute (host walk of every launch's tiles); the older, larger bookings stay beside it
     assert r["frac_valid"] <= r["frac"] <= r["frac_mfma_issued"] < 1.0 and r["frac"] < r["frac_descriptor_counted"] < r["frac_reference_counted"]
+    w = j["roofline_winograd"]                               # the second GEMM family, timed in its own replays
+    assert w["launches_per_step"] >= 8 and 0.2 < w["frac"] <= w["frac_mfma_issued"] < 1.0 and w["direct_equivalent_tflops"] > w["achieved"]
+    assert r["frac_reference_counted"] < 1.0
     st = j["staged"]                                        # the same step with per-step input staging inside the timed region
     assert st["unit"] == "clips/s" and st["steps"] == 3 and abs(st["value"] - 8 * 1000.0 / st["ms_per_step"]) < 1e-6 * st["value"]
     assert st["ms_per_step"] < 1.5 * j["ms_per_step"] + 5.0 and st["loss_total"] == st["loss_total"]

@@ -49,6 +49,7 @@ def load_counter(path, counters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--sq")
+    ap.add_argument("--mfma", help="counter CSV of a pass with SQ_INSTS_VALU_MFMA_MOPS_F32")
     ap.add_argument("--steps", type=int, required=True); ap.add_argument("--tag", default="r02")
     a = ap.parse_args()
     stats = {}
@@ -81,6 +82,37 @@ def main():
         for ms, k, n, us, mb, tbs in sorted(rows, reverse=True):
             f.write("| `%s` | %.3f | %.1f | %.1f | %.1f | %.2f | %.2f |\n" % (k, ms, n, us, mb, tbs, tbs * 1e12 / HBM_ACHIEVABLE))
     print("conv_gemm: %d launches, %.1f MB HBM per launch" % (conv[0], out["conv_gemm_hbm_bytes_per_launch"] / 1e6))
+    if a.mfma:
+        # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = fp32 MFMA FLOPs the hardware issued; the host-side walk of every launch's tiles
+        # (pc_conv_work / pc_wino_work / pc_wgrad_work, what bench.py's roofline numerator is made of) must agree with it per kernel family
+        import sys
+        sys.path.insert(0, ROOT)
+        import picons_amd  # noqa: F401
+        from picons_amd import step as pstep
+        from picons_amd.plan import Plan
+        mf, _n = load_counter(a.mfma, {"SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE"})
+        p = Plan(24, 224, n=8, groups=2, lanes=1)
+        p.build_forward(); p.build_loss(pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)); p.build_backward(); p.build_adam()
+        host = {"conv_gemm": sum(v["mfma"] for v in p.conv_flops_executed().values()), "wino_conv": sum(v["mfma"] for v in p.wino_flops_executed().values()),
+                "wgrad": sum(v["mfma"] for v in p.wgrad_flops_executed().values())}
+        execd = {"conv_gemm": sum(v["executed"] for v in p.conv_flops_executed().values()), "wino_conv": sum(v["executed"] for v in p.wino_flops_executed().values()),
+                 "wgrad": sum(v["executed"] for v in p.wgrad_flops_executed().values())}
+        fam = lambda k: "wino_conv" if k.startswith("wino_conv") else ("conv_gemm" if k.startswith("conv_gemm") else ("wgrad" if k.startswith("wgrad") else None))
+        cnt = collections.defaultdict(float)
+        for k, v in mf.items():
+            if fam(k):
+                cnt[fam(k)] += v["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0 / a.steps
+        with open(os.path.join(ROOT, "profiles", a.tag + "_mfma_counter_check.txt"), "w") as f:
+            f.write("# fp32 MFMA FLOPs per step and kernel family: hardware counter (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, rocprofv3 --pmc, own pass) against the\n"
+                    "# host-side walk of every launch's tiles that bench.py's roofline numerator is made of (issued = whole tiles; executed = real rows x columns)\n")
+            f.write("%-12s %16s %16s %10s %16s %10s\n" % ("family", "counter GFLOP", "host issued", "host/ctr", "host executed", "exec/ctr"))
+            for k in ("conv_gemm", "wino_conv", "wgrad"):
+                c = cnt.get(k, 0.0)
+                f.write("%-12s %16.2f %16.2f %10.4f %16.2f %10.4f\n" % (k, c / 1e9, host[k] / 1e9, host[k] / max(c, 1.0), execd[k] / 1e9, execd[k] / max(c, 1.0)))
+                if c > 0:
+                    assert abs(host[k] / c - 1.0) < 0.03, "host-issued FLOPs of %s disagree with the MFMA counter: %.4f" % (k, host[k] / c)
+                    assert execd[k] <= c * 1.0001 and execd[k] >= 0.85 * c, "executed FLOPs of %s outside [0.85, 1] x counter" % k
+        print(open(os.path.join(ROOT, "profiles", a.tag + "_mfma_counter_check.txt")).read())
     if a.sq:
         names = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
                  "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE"]
@@ -88,7 +120,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", a.tag + "_pmc_sq_gemm.csv"), "w") as f:
             f.write("kernel,launches," + ",".join(names) + ",mfma_util,wait_any_frac,wait_inst_frac,active_inst_frac\n")
             for k in sorted(sq, key=lambda k: -sq[k]["SQ_BUSY_CYCLES"]):
-                if not ("gemm" in k or "wgrad" in k or "em_" in k):
+                if not ("gemm" in k or "wgrad" in k or "em_" in k or "wino" in k):
                     continue
                 v = sq[k]
                 busy, wave = v["SQ_BUSY_CYCLES"] / 32.0, max(v["SQ_WAVE_CYCLES"], 1.0)
