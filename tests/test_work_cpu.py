@@ -77,3 +77,41 @@ def test_step_totals_are_consistent():
     p.finalize()
     ops = [op for n in p.lists for op in p.lists[n] if op[0] in (capi.OP_CONV, capi.OP_WGRAD)]
     assert ops and all(id(op[1]) in p.op_work for op in ops)
+
+
+def test_winograd_layers_in_the_plan_and_their_accounting(monkeypatch):
+    """Which layers run in Winograd form at the bench size, what pc_wino_work books for them (16 transform-domain multiply-accumulates
+    per 2x2 tile, tap and channel pair: 4/9 of the direct form's valid count away from the borders), and PICONS_WINO=0 restoring the
+    gather-GEMM ops."""
+    import ctypes as C
+    from picons_amd import ops
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+
+    def build():
+        p = Plan(24, 224, n=2, groups=2, lanes=4)
+        p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam(); p.finalize()
+        return p
+    p = build()
+    wino_layers = sorted(n for n, v in p.kw.items() if "wino_fwd" in v)
+    assert wino_layers == sorted(["conv112.weight", "conv56.weight", "conv1.Conv3d_2c_3x3.conv3d.weight", "conv1.Mixed_3b.b1b.conv3d.weight",
+                                  "conv1.Mixed_3c.b1b.conv3d.weight", "conv1.Mixed_3c.b2b.conv3d.weight"])
+    count = lambda q, kind: sum(1 for n in q.lists for op in q.lists[n] if op[0] == kind)
+    assert count(p, capi.OP_WINO_CONV) == 12 and count(p, capi.OP_WINO_WEIGHTS) == 12      # forward + input gradient each
+    fz = p.wino_flops_executed()
+    ex = sum(v["executed"] for v in fz.values()); mf = sum(v["mfma"] for v in fz.values())
+    ref = sum(p.flops_reference_counted_wino().values())
+    assert 0 < ex <= mf and 1.9 < ref / ex < 3.0            # 2.25x fewer than the direct form (more where temporal taps fall outside)
+    # conv112 at bs = 8: 3136 blocks of 64 tiles x 64 channels, 10 of 12 temporal taps valid
+    d = ops.wino_desc(16, 4, 112, 112, 64, 64, 64, 64, 3)
+    out = (C.c_double * 3)()
+    capi.check(capi.lib().pc_wino_work(C.byref(d), out))
+    assert out[2] == 3136 and out[0] == out[1] == 16 * 10 * 16.0 * 56 * 56 * 64 * 64
+    assert capi.lib().pc_wino_u_floats(64, 64, 3) == 3 * 1 * 8 * 8192 and capi.lib().pc_wino_u_floats(96, 64, 3) == 3 * 2 * 8 * 8192
+    assert capi.lib().pc_wino_bnpart_rows(C.byref(d)) == 16 * 4 * 49 * 2
+    # odd sizes and thin channel counts are refused by the host checks (no GPU call)
+    bad = ops.wino_desc(2, 2, 15, 16, 64, 64, 64, 64, 3)
+    assert capi.lib().pc_wino_work(C.byref(bad), out) != 0 and b"even" in capi.lib().pc_last_error()
+    monkeypatch.setenv("PICONS_WINO", "0")
+    q = build()
+    assert count(q, capi.OP_WINO_CONV) == 0 and count(q, capi.OP_CONV) > count(p, capi.OP_CONV)
+    assert sum(v["executed"] for v in q.conv_flops_executed().values()) > sum(v["executed"] for v in p.conv_flops_executed().values())
