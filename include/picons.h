@@ -170,6 +170,14 @@ int pc_conv_wgrad_multi(const pc_wgrad_job* jobs, int njobs, pc_stream s);
 int pc_bn_finalize(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
                    const float* gamma, const float* beta, float eps, float momentum,
                    float* running_mean, float* running_var, float* stat, pc_stream s);
+/* The same with a workspace of pc_bn_finalize_ws_floats(...) floats (0 for fewer than 512 partial rows per group): layers with
+ * thousands of partial rows (the stem: 2 x 6272) are reduced in two stages -- 32 blocks per 16 channels and group, then the finalize
+ * over their double-precision partial rows -- instead of by one block per 16 channels (85 -> 15 us on the dependency chain).  ws NULL
+ * = the one-stage form.  Fixed summation order either way. */
+int64_t pc_bn_finalize_ws_floats(int nparts_per_group, int groups, int C);
+int pc_bn_finalize_ws(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
+                      const float* gamma, const float* beta, float eps, float momentum,
+                      float* running_mean, float* running_var, float* stat, float* ws, pc_stream s);
 /* y[r][c] = relu?(z[r][c]*scale[g(r)][c]+shift[g(r)][c]) */
 int pc_bn_apply(const float* z, int ldz, const float* stat, int C, int64_t rows, int groups, float* y,
                 int ldy, int relu, pc_stream s);

@@ -81,6 +81,8 @@ _SIGS = {
     "pc_wino_bnpart_rows": (i32, [C.POINTER(WinoDesc)]),
     "pc_wino_work": (i32, [C.POINTER(WinoDesc), C.POINTER(C.c_double)]),
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
+    "pc_bn_finalize_ws": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
+    "pc_bn_finalize_ws_floats": (i64, [i32, i32, i32]),
     "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
     "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),
     "pc_bn_bwd_ws_floats": (i64, [i64, i32, i32]),

@@ -33,8 +33,8 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_conv_wgrad(&d, P(const float*, 0), P(const float*, 1), P(float*, 2), s);
         }
         case PC_OP_BN_FINALIZE:
-            return pc_bn_finalize(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], P(const float*, 1), P(const float*, 2), op.f[0], op.f[1],
-                                  P(float*, 3), P(float*, 4), P(float*, 5), s);
+            return pc_bn_finalize_ws(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], P(const float*, 1), P(const float*, 2), op.f[0], op.f[1],
+                                     P(float*, 3), P(float*, 4), P(float*, 5), P(float*, 6), s);
         case PC_OP_BN_APPLY:
             return pc_bn_apply(P(const float*, 0), op.i[0], P(const float*, 1), op.i[1], op.l[0], op.i[2], P(float*, 2), op.i[3], op.i[4], s);
         case PC_OP_BN_EVAL_STAT:

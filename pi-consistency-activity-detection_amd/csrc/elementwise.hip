@@ -12,18 +12,19 @@ constexpr int FIN_RL = 64;   // row lanes of the partial-sum finalize kernels (1
 constexpr int FIN_CL = 16;   // channels per block: C / 16 blocks, so that even the 64-channel layers spread over a few CUs
 
 // sum over partial rows [npg][2][C] for FIN_CL channels; result valid on threads with rl == 0
-__device__ __forceinline__ void partial_colsum(const float* __restrict__ part, int npg, int C, int c, int rl,
+template <typename TP>
+__device__ __forceinline__ void partial_colsum(const TP* __restrict__ part, int npg, int C, int c, int rl,
                                                double (*sh)[FIN_RL][FIN_CL], int cl, double& s, double& s2) {
     double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
     if (c < C) {
         int i = rl;
         for (; i + FIN_RL < npg; i += 2 * FIN_RL) {
-            const float* q0 = part + (size_t)i * 2 * C + c;
-            const float* q1 = part + (size_t)(i + FIN_RL) * 2 * C + c;
-            const float x0 = q0[0], y0 = q0[C], x1 = q1[0], y1 = q1[C];
+            const TP* q0 = part + (size_t)i * 2 * C + c;
+            const TP* q1 = part + (size_t)(i + FIN_RL) * 2 * C + c;
+            const TP x0 = q0[0], y0 = q0[C], x1 = q1[0], y1 = q1[C];
             a0 += (double)x0; b0 += (double)y0; a1 += (double)x1; b1 += (double)y1;
         }
-        if (i < npg) { const float* q0 = part + (size_t)i * 2 * C + c; a0 += (double)q0[0]; b0 += (double)q0[C]; }
+        if (i < npg) { const TP* q0 = part + (size_t)i * 2 * C + c; a0 += (double)q0[0]; b0 += (double)q0[C]; }
     }
     sh[0][rl][cl] = a0 + a1; sh[1][rl][cl] = b0 + b1;
     __syncthreads();
@@ -39,7 +40,25 @@ __device__ __forceinline__ void partial_colsum(const float* __restrict__ part, i
     __syncthreads();
 }
 
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int npg, int groups,
+// Two-stage form for layers with thousands of partial rows (the stem leaves 2 x 6272 per batch group: one block per 16 channels walked
+// them in 85 us, alone on the dependency chain at the very start of a step): stage 1 spreads the rows of a group over FIN_S blocks per
+// channel block and leaves FIN_S double-precision partial rows, stage 2 is the finalize kernel over those.  Fixed order: deterministic.
+constexpr int FIN_S = 32;
+__global__ __launch_bounds__(1024) void bn_partial_reduce_kernel(const float* __restrict__ part, int npg, int C, double* __restrict__ ws) {
+    __shared__ double sh[2][FIN_RL][FIN_CL];
+    const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
+    const int c = blockIdx.x * FIN_CL + cl, sl = blockIdx.y, g = blockIdx.z;
+    const int per = (npg + FIN_S - 1) / FIN_S, r0 = sl * per, r1 = min(npg, r0 + per);
+    double s, s2;
+    partial_colsum(part + ((size_t)g * npg + r0) * 2 * C, max(0, r1 - r0), C, c, rl, sh, cl, s, s2);
+    if (rl == 0 && c < C) {
+        double* o = ws + ((size_t)g * FIN_S + sl) * 2 * C;
+        o[c] = s; o[C + c] = s2;
+    }
+}
+
+template <typename TP>
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const TP* __restrict__ part, int npg, int groups,
                                                            int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float mom,
                                                            float* rmean, float* rvar, float* __restrict__ stat) {
@@ -455,14 +474,31 @@ inline int64_t red_rows_per_block(int64_t rows) {
 }  // namespace
 
 // ================================================================================ C ABI
+extern "C" int64_t pc_bn_finalize_ws_floats(int nparts_per_group, int groups, int C) {
+    return nparts_per_group >= 512 ? (int64_t)groups * FIN_S * 2 * C * 2 + 2 : 0;       // doubles, + room to align
+}
+
+extern "C" int pc_bn_finalize_ws(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
+                                 const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                 float* running_var, float* stat, float* ws, pc_stream s) {
+    PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
+    if (ws && nparts_per_group >= 512) {
+        double* w = (double*)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, FIN_CL), FIN_S, groups), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, C, w);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, (const double*)w, FIN_S, groups, C,
+                           (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
+    } else {
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+                           (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
+    }
+    PC_CHECK_LAUNCH("bn_finalize");
+    return PC_OK;
+}
+
 extern "C" int pc_bn_finalize(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group,
                               const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
                               float* running_var, float* stat, pc_stream s) {
-    PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
-                       (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
-    PC_CHECK_LAUNCH("bn_finalize");
-    return PC_OK;
+    return pc_bn_finalize_ws(part, nparts_per_group, groups, C, count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat, nullptr, s);
 }
 
 extern "C" int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean, const float* running_var,

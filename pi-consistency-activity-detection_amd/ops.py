@@ -89,10 +89,17 @@ def conv_wgrad_multi(jobs):
     capi.call("pc_conv_wgrad_multi", C.c_void_p(tab.ctypes.data), len(jobs), stream())
 
 
-def bn_finalize(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean=None, rvar=None):
+def bn_finalize(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean=None, rvar=None, two_stage=False):
+    """two_stage: with the workspace of pc_bn_finalize_ws (the plan's form; a no-op below 512 partial rows per group)."""
     stat = torch.empty(groups, 4, C_, device=part.device, dtype=torch.float32)
-    capi.call("pc_bn_finalize", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
-              ptr(stat), stream())
+    if two_stage:
+        n = capi.lib().pc_bn_finalize_ws_floats(npg, groups, C_)
+        ws = torch.empty(max(int(n), 1), device=part.device, dtype=torch.float32)
+        capi.call("pc_bn_finalize_ws", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+                  ptr(stat), ptr(ws) if n > 0 else None, stream())
+    else:
+        capi.call("pc_bn_finalize", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar),
+                  ptr(stat), stream())
     return stat
 
 

@@ -334,6 +334,11 @@ class Plan:
             self.final_at[nm] = len(self.lists["bwd"])
             self.final_lane[nm] = self.lane
 
+    def bn_fin_ws(self, npg, C):
+        """Workspace of the two-stage BatchNorm finalize (pc_bn_finalize_ws; None below 512 partial rows per group)."""
+        n = capi.lib().pc_bn_finalize_ws_floats(int(npg), int(self.groups), int(C))
+        return self.alloc(n) if n > 0 else None
+
     # ------------------------------------------------------------------ Winograd F(2x2, 3x3) form of the stride-1 3x3x3 layers
     def wino_ok(self, x, cout, k, stride, pad=None):
         """The layers that run in Winograd form (csrc/wino.hip, 2.25x fewer multiply-accumulates, measured 1.5 - 2.2x faster than
@@ -477,7 +482,7 @@ class Plan:
             self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART)
             self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
                       f=[spec.BN_EPS, spec.BN_MOMENTUM],
-                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
+                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(nrows // self.groups, cout)])
             g_apply = self.groups
         elif wino:
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
@@ -493,7 +498,7 @@ class Plan:
             self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part)
             self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
                       f=[spec.BN_EPS, spec.BN_MOMENTUM],
-                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
+                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(nrows // self.groups, cout)])
             g_apply = self.groups
         else:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_CI3 if ci3 else 0)

@@ -380,6 +380,28 @@ def test_unit3d_bn_relu_fwd_bwd(groups):
     close(uncl(ye), ref_e, what="bn eval")
 
 
+@pytest.mark.parametrize("npg,C", [(6272, 64), (1568, 192), (513, 40), (100, 64)])
+def test_bn_finalize_two_stage_matches_one_stage(npg, C):
+    """Layers with thousands of BatchNorm partial rows (the stem: 6272 per group) are finalized in two stages (32 slices per 16 channels
+    and group, then their double-precision rows); both forms sum in a fixed order in fp64, so statistics and running statistics agree to
+    the last float bit or one ulp, and repeated runs are bit-identical."""
+    g = torch.Generator().manual_seed(npg + C)
+    groups, count = 2, 12345
+    part = torch.rand(groups * npg, 2, C, generator=g).to(DEV)
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV); beta = torch.randn(C, generator=g).to(DEV)
+    outs = []
+    for two in (False, True, True):
+        rm = torch.zeros(C, device=DEV); rv = torch.ones(C, device=DEV)
+        st = ops.bn_finalize(part, npg, groups, C, count, gamma, beta, spec.BN_EPS, spec.BN_MOMENTUM, rm, rv, two_stage=two)
+        outs.append((st.cpu(), rm.cpu(), rv.cpu()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.allclose(a, b, rtol=3e-7, atol=1e-9), (a - b).abs().max()
+    for a, b in zip(outs[1], outs[2]):
+        assert torch.equal(a, b)
+    ref_mean = part.view(groups, npg, 2, C)[:, :, 0].double().sum(1).cpu() / count
+    assert torch.allclose(outs[1][0][:, 0].double(), ref_mean, rtol=1e-6)
+
+
 @pytest.mark.parametrize("tag", ["p133", "p333s2", "p333s1", "p133odd"])
 def test_maxpool_golden(golden_dir, tag):
     G = np.load(os.path.join(golden_dir, "stages.npz"))
