@@ -353,6 +353,13 @@ __global__ __launch_bounds__(256) void to_ndhwc_kernel(const T* __restrict__ src
         const int64_t n = idx / thw, pos = idx - n * thw;
         int64_t sp = pos;
         if (flipw) { const int w = (int)(pos % W); sp = pos - w + (W - 1 - w); }
+        if (Cpad == 4) {          // the RGB clip (3 -> 4 channels): one 16-byte store per position instead of four 4-byte stores at a 16-byte stride
+            f32x4 v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = c < C ? (float)src[(n * C + c) * thw + sp] : 0.f;
+            *(f32x4*)(dst + idx * 4) = v;
+            continue;
+        }
         for (int c = 0; c < Cpad; ++c)
             dst[idx * Cpad + c] = c < C ? (float)src[(n * C + c) * thw + sp] : 0.f;
     }
