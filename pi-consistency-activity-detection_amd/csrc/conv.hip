@@ -5,6 +5,7 @@
 // Replaces the ATen/cuDNN convolution call sites listed in SURVEY.md §2a (K1, K6, K9-K12).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 #include <algorithm>
 #include <vector>
 
@@ -1028,9 +1029,15 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     constexpr int SROWS = (BKP + KW - 1 + SPIECE - 1) / SPIECE * SPIECE;   // S tile rows padded to whole DMA pieces
     constexpr int DI = BKP * BM * 4 / 1024, SI = SROWS * CSB * 4 / 1024;   // DMA wave-instructions per tile
     static_assert((BKP * BM * 4) % 1024 == 0, "D tile must be whole DMA pieces");
-    __shared__ __attribute__((aligned(16))) float Ds[2][BKP][BM];
-    __shared__ __attribute__((aligned(16))) float Ss[2][SROWS][CSB];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // One LDS variable per ring slot and the slot a compile-time constant (the chunk loop is unrolled by two): the compiler's
+    // s_waitcnt pass orders every LDS read behind every in-flight LDS-DMA write it cannot prove disjoint, and it can only prove it
+    // for distinct variables.  With Ds[2][..] indexed by a run-time slot it put s_waitcnt vmcnt(0) between the fetch of chunk c + 1
+    // and the first operand read of chunk c -- the fetch was never in flight during the MFMA loop (MFMA busy 0.61).
+    __shared__ __attribute__((aligned(16))) float Ds0[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ds1[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ss0[SROWS][CSB];
+    __shared__ __attribute__((aligned(16))) float Ss1[SROWS][CSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WNW, wn = wave % WNW;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.mt * p.ncs * p.ntap_t * p.ntap_h;
@@ -1058,18 +1065,25 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == p.T) { q_t = 0; ++q_n; } } }
         return (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
     };
-    auto gload = [&](int buf) -> bool {
+    auto gload = [&](auto slot) -> bool {
+        constexpr int buf = decltype(slot)::value;
         int row_d, row_s, w0;
         if (!decode(row_d, row_s, w0)) return false;
-        float* ld = &Ds[buf][0][0];
-        float* ls = &Ss[buf][0][0];
-        for (int i = wave; i < DI; i += 4) {                               // D tile: BKP rows x BM channels
+        float* ld = buf ? &Ds1[0][0] : &Ds0[0][0];
+        float* ls = buf ? &Ss1[0][0] : &Ss0[0][0];
+#pragma unroll
+        for (int jj = 0; jj < (DI + 3) / 4; ++jj) {                        // D tile: BKP rows x BM channels
+            const int i = jj * 4 + wave;
+            if (i >= DI) break;
             const int e = i * 64 + lane, r = e / (BM / 4), c4 = e % (BM / 4);
             const bool v = (w0 + r) < p.W && (m0 + c4 * 4) < p.Cd;
             const float* src = v ? Dp + (size_t)(row_d + w0 + r) * p.ldd + m0 + c4 * 4 : g_zero16;
             glds16(src, ld + i * 256);
         }
-        for (int i = wave; i < SI; i += 4) {                               // S tile: positions w0-pad .. w0-pad+BKP+KW-2 (+ padding rows)
+#pragma unroll
+        for (int jj = 0; jj < (SI + 3) / 4; ++jj) {                        // S tile: positions w0-pad .. w0-pad+BKP+KW-2 (+ padding rows)
+            const int i = jj * 4 + wave;
+            if (i >= SI) break;
             const int e = i * 64 + lane, r = e / (CSB / 4), c4 = e % (CSB / 4);
             const int w = w0 - p.padw + r;
             const bool v = r < BKP + KW - 1 && (unsigned)w < (unsigned)p.Wsw;
@@ -1092,20 +1106,22 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) { const int col = wn * (BN / WNW) + 32 * j; kwj[j] = col / CSB; csj[j] = col % CSB + (lane & 31); }
     const int ml = wm * (BM / WMW) + (lane & 31), kh = lane >> 5;
-    bool live = gload(0);
+    bool live = gload(std::integral_constant<int, 0>{});
     __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        const bool next_live = c + 1 < c_end ? gload(buf ^ 1) : false;
+    auto chunk = [&](auto slot, int c) {
+        constexpr int buf = decltype(slot)::value;
+        const bool next_live = c + 1 < c_end ? gload(std::integral_constant<int, buf ^ 1>{}) : false;
         if (live) {
+            const float (*Dt)[BM] = buf ? Ds1 : Ds0;
+            const float (*St)[CSB] = buf ? Ss1 : Ss0;
 #pragma unroll
             for (int ks = 0; ks < BKP / 2; ++ks) {
                 const int pp = ks * 2 + kh;
                 float af[TM], bf[TN];
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[i] = Ds[buf][pp][ml + i * 32];
+                for (int i = 0; i < TM; ++i) af[i] = Dt[pp][ml + i * 32];
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[j] = Ss[buf][pp + kwj[j]][csj[j]];
+                for (int j = 0; j < TN; ++j) bf[j] = St[pp + kwj[j]][csj[j]];
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1115,6 +1131,10 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         }
         __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
         live = next_live;
+    };
+    for (int c = c_begin; c < c_end; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     const int tapbase = ((kt_ + p.wk0_t) * p.KH + kh_ + p.wk0_h) * KW;    // + kw
 #pragma unroll
@@ -1162,9 +1182,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     static_assert(SW * (BKP - 1) + 7 < ROWP + 1, "padding columns stay inside the row");
     constexpr int SPIECES = NKH * ROWP, SI = (SPIECES + 63) / 64, DI = BKP * BM * 4 / 1024;
     static_assert((BKP * BM * 4) % 1024 == 0 && (BKP / 2) % 2 == 0, "tile shape");
-    __shared__ __attribute__((aligned(16))) float Ds[2][BKP][BM];
-    __shared__ __attribute__((aligned(16))) float Ss[2][SI * 256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) float Ds0[BKP][BM];          // one variable per ring slot: see wgrad3_kernel
+    __shared__ __attribute__((aligned(16))) float Ds1[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ss0[SI * 256];
+    __shared__ __attribute__((aligned(16))) float Ss1[SI * 256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wk = wave >> 1;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
     const int mtile = lid % p.mt, sl = lid / p.mt;
@@ -1185,21 +1207,28 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     // chunk -> (n, t, h, seg) as a counter advanced by every fetch (chunks are fetched in order)
     int q_seg = c_begin % p.nseg, q_h, q_t, q_n;
     { int r = c_begin / p.nseg; q_h = r % p.H; r /= p.H; q_t = r % ntv; q_n = r / ntv; }
-    auto gload = [&](int buf) {
+    auto gload = [&](auto slot) {
+        constexpr int buf = decltype(slot)::value;
         const int seg = q_seg, h = q_h, t = tlo + q_t, n = q_n;
         if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == ntv) { q_t = 0; ++q_n; } } }
         const int w0 = seg * BKP;
         const int row_d = ((n * p.T + t) * p.H + h) * p.W;
         const int ts = t * p.istr_t + p.ioff_t + kt_, hs0 = h * p.istr_h + p.ioff_h;
-        float* ld = &Ds[buf][0][0];
-        float* ls = &Ss[buf][0];
-        for (int i = wave; i < DI; i += 4) {
+        float* ld = buf ? &Ds1[0][0] : &Ds0[0][0];
+        float* ls = buf ? &Ss1[0] : &Ss0[0];
+#pragma unroll
+        for (int jj = 0; jj < (DI + 3) / 4; ++jj) {
+            const int i = jj * 4 + wave;
+            if (i >= DI) break;
             const int e = i * 64 + lane, rr = e / (BM / 4), c4 = e % (BM / 4);
             const bool v = (m0 + c4 * 4) < p.Cd;
             const float* src = v ? p.D + (size_t)(row_d + w0 + rr) * p.ldd + m0 + c4 * 4 : g_zero16;
             glds16(src, ld + i * 256);
         }
-        for (int i = wave; i < SI; i += 4) {
+#pragma unroll
+        for (int jj = 0; jj < (SI + 3) / 4; ++jj) {
+            const int i = jj * 4 + wave;
+            if (i >= SI) break;
             const int e = i * 64 + lane, kh = e / ROWP, rr = e - kh * ROWP;
             const int hs = hs0 + kh, w = w0 * SW - p.padw + rr;
             const bool v = kh < NKH && (unsigned)hs < (unsigned)p.Hs && (unsigned)w < (unsigned)p.Wsw;
@@ -1228,16 +1257,17 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
             gcol[j] = nl < KW * 4 ? j * KW * 4 + nl : -1;          // kw = KW..7 are padding columns
         }
     }
-    gload(0);
+    gload(std::integral_constant<int, 0>{});
     __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) gload(buf ^ 1);
-        const float* sb = &Ss[buf][0];
+    auto chunk = [&](auto slot, int c) {
+        constexpr int buf = decltype(slot)::value;
+        if (c + 1 < c_end) gload(std::integral_constant<int, buf ^ 1>{});
+        const float* sb = buf ? &Ss1[0] : &Ss0[0];
+        const float (*Dt)[BM] = buf ? Ds1 : Ds0;
 #pragma unroll
         for (int q = 0; q < BKP / 4; ++q) {
             const int pp = (2 * q + wk) * 2 + kh2;
-            const float af = Ds[buf][pp][ml];
+            const float af = Dt[pp][ml];
             float bf[NACC];
 #pragma unroll
             for (int j = 0; j < NACC; ++j) bf[j] = sb[boff[j] + 4 * SW * pp];
@@ -1245,6 +1275,10 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
             for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
         }
         __syncthreads();
+    };
+    for (int c = c_begin; c < c_end; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     const size_t tap0 = (size_t)((kt_ + p.wk0_t) * p.KH + p.wk0_h) * KW * 4;       // g offset of (kt, kh = 0, kw = 0, cs = 0)
 #pragma unroll
