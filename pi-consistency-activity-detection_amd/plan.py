@@ -82,6 +82,10 @@ class Plan:
         # decoder tail as one five-tap transposed conv with a single output channel (csrc/tail6.hip) instead of the
         # 27-channel form + tap sum
         self.merged_tail = os.environ.get("PICONS_TAIL6", "1") != "0"
+        # the decoder's forward sits on lane 0 with the side lanes idle: the position classes of a stride-2 transposed conv (8 independent
+        # launches of 196 - 784 blocks) are dealt to all lanes, and conv28 (196 blocks, K = 7488) runs on the skip lane beside PrimaryCaps
+        self.spread_classes = lanes >= 2 and os.environ.get("PICONS_SPREAD_CLASSES", "1") != "0"
+        self.conv28_aside = os.environ.get("PICONS_CONV28_ASIDE", "1") != "0"
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -714,9 +718,23 @@ class Plan:
         if cscale is None and max(k) >= 7 and tuple(stride) == (1, 1, 1) and self.groups * self.n == x.N:
             flags |= capi.F_NFAST          # 9x9 'full' conv (upsample1): most taps of a border patch are padding
         F_fwd = 0
-        for dd in D.transposed_classes(x.N, x.thw, Ci, x.ld, othw, cout, out.ld, k, stride, pad, act=act, flags=flags):
+        classes = list(D.transposed_classes(x.N, x.thw, Ci, x.ld, othw, cout, out.ld, k, stride, pad, act=act, flags=flags))
+        side = list(range(1, self.lanes)) if (self.spread_classes and self.lane == 0 and self.cur == "fwd" and len(classes) >= 4) else []
+        if side:
+            # position classes write disjoint sub-lattices of `out`: heaviest first onto the least loaded lane
+            mask = sum(1 << q for q in side)
+            self.fork(mask, src=0)
+            load = {q: 0 for q in [0] + side}
+            classes.sort(key=lambda dd: -_conv_flops(dd))
+        for dd in classes:
             F_fwd += _conv_flops(dd)
+            if side:
+                self.lane = min(load, key=lambda q: (load[q], q))
+                load[self.lane] += _conv_flops(dd)
             self.conv_op(dd, x.ref, w["fwd"], out.ref, bias=self.P(name + ".bias"), cscale=cscale)
+        if side:
+            self.lane = 0
+            self.join(mask)
 
         def bwd():
             dy = self.grad_of(out)
@@ -841,6 +859,14 @@ class Plan:
             self.tape.append(bwd_drop)
         else:
             xd = x
+        cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")
+        conv28_early = bool(self.conv28_aside and self.skip_lane)
+        if conv28_early:          # conv28 reads nothing but xd: on the skip lane (idle since conv112), beside PrimaryCaps; joined in front of upsample2
+            self.fork(1 << self.skip_lane)
+            self.lane = self.skip_lane
+            self.conv_layer("conv28", xd, 64, (1, 3, 3), (0, 1, 1), capi.ACT_RELU, cat28.slice(64, 64))
+            self.lane = 0
+            self.skip_bwd["conv28"] = self.tape.pop()
         # PrimaryCaps: pose (512) and activation (32, sigmoid) convs as one GEMM (capsules_ucf101.py:43-49)
         KP = spec.PRIMARY_K
         s20 = s28 - KP + 1
@@ -951,9 +977,12 @@ class Plan:
                     self.conv_op(dd, dcaps.ref, wpc["tr"], dx.ref, alg=0)
         self.tape.append(bwd_caps)
         # decoder (capsules_ucf101.py:486-510)
-        cat28 = self.tensor(N, (1, s28, s28), 128, "cat28")
         self.convT_layer("upsample1", masked, 64, (1, KP, KP), (1, 1, 1), (0, 0, 0), (0, 0, 0), capi.ACT_RELU, cat28.slice(0, 64))
-        self.conv_layer("conv28", xd, 64, (1, 3, 3), (0, 1, 1), capi.ACT_RELU, cat28.slice(64, 64))
+        if conv28_early:
+            self.tape.append(self.skip_bwd["conv28"])         # its backward stays where it was: lane 0, behind upsample2's
+            self.join(1 << self.skip_lane)
+        else:
+            self.conv_layer("conv28", xd, 64, (1, 3, 3), (0, 1, 1), capi.ACT_RELU, cat28.slice(64, 64))
         if not self.skip_lane:
             cat56 = self.tensor(N, (2, 2 * s28, 2 * s28), 128, "cat56")
         self.convT_layer("upsample2", cat28, 64, (3, 3, 3), (2, 2, 2), (1, 1, 1), (1, 1, 1), capi.ACT_RELU, cat56.slice(0, 64))

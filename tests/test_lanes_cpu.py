@@ -125,13 +125,19 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
     third = branch | (1 << p.wg_lane if p.wg_lane else 0)
     # one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes; the forward's module
     # forks include the weight-gradient lane (idle there: the third branch)
-    assert _forks(p, "bwd", branch) == 8 and sum(_forks(p, "fwd", m) for m in {third, branch}) == 8
-    for name in ("fwd", "bwd"):
-        if p.skip_lane and p.skip_lane != p.wg_lane:
-            assert _forks(p, name, 1 << p.skip_lane) == 2, name          # conv56, conv112
+    # ... and the forward deals the position classes of upsample2 / upsample3 to ALL lanes (one FORK of every side lane each)
+    all_side = (1 << lanes) - 2
+    assert _forks(p, "bwd", branch) == 8
+    assert sum(_forks(p, "fwd", m) for m in {third, branch}) == 8 + (2 if all_side in (third, branch) else 0)
+    assert _forks(p, "fwd", all_side) >= 2
     if p.skip_lane and p.skip_lane != p.wg_lane:
-        on_skip = [op for name in ("fwd", "bwd") for op in p.lists[name] if op[5] == p.skip_lane]
-        assert sum(1 for op in on_skip if op[0] in (capi.OP_CONV, capi.OP_WINO_CONV)) == 4
+        assert _forks(p, "fwd", 1 << p.skip_lane) == 3                   # conv56, conv112, conv28
+        assert _forks(p, "bwd", 1 << p.skip_lane) == 2                   # conv56, conv112 (conv28's backward stays on lane 0)
+        on_skip = {name: [op for op in p.lists[name] if op[5] == p.skip_lane] for name in ("fwd", "bwd")}
+        assert sum(1 for op in on_skip["bwd"] if op[0] in (capi.OP_CONV, capi.OP_WINO_CONV)) == 2
+        assert sum(1 for op in on_skip["fwd"] if op[0] == capi.OP_WINO_CONV) == 2
+        nclass = sum(1 for op in on_skip["fwd"] if op[0] == capi.OP_CONV) - 1       # conv28 + this lane's share of the 16 position classes
+        assert 2 <= nclass <= 6
     if p.wg_lane:
         wg = [op for op in p.lists["bwd"] if op[0] in (capi.OP_WGRAD, capi.OP_WGRAD_MULTI)]
         assert all(op[5] == p.wg_lane for op in wg)

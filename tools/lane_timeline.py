@@ -48,6 +48,9 @@ def main():
     ap.add_argument("trace"); ap.add_argument("--thresh", type=float, default=0.6); ap.add_argument("--out")
     ap.add_argument("--window", type=int, default=-1, help="which step of the trace (index into the windows between adam_kernel dispatches; "
                     "-1 = the last; the last step of a short profiled run can carry host stalls of the profiler's own)")
+    ap.add_argument("--by-lane", type=int, default=0, help="also print, per stream, the N kernels with the largest summed duration in this step")
+    ap.add_argument("--sequence", type=int, default=-1, help="print the dispatches of this stream id in order (start offset, duration, kernel, blocks, "
+                    "kernels of other streams live at its start)")
     a = ap.parse_args()
     rows = [r for r in csv.DictReader(open(a.trace)) if r["Kind"] == "KERNEL_DISPATCH"]
     for r in rows:
@@ -99,6 +102,25 @@ def main():
     out.append("\nkernels running while fill < %.1f (ms of such time; a kernel counts for every instant it is live)" % a.thresh)
     for k, d in under.most_common(25):
         out.append("  %8.3f  (alone %6.3f)  %s" % (d / 1e6, alone[k] / 1e6, k))
+    if a.by_lane:
+        for k, _ in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            agg = collections.defaultdict(lambda: [0, 0])
+            for r in step:
+                if (r["Queue_Id"], r["Stream_Id"]) == k:
+                    v = agg[clean(r["Kernel_Name"])]; v[0] += 1; v[1] += r["e"] - r["s"]
+            out.append("\nstream %s: kernel, dispatches, summed ms" % (k,))
+            for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.by_lane]:
+                out.append("  %8.3f %4d  %s" % (d / 1e6, c, n))
+    if a.sequence >= 0:
+        out.append("\nstream %d in order: start ms, duration ms, blocks, kernel | live on other streams at its start" % a.sequence)
+        for r in sorted(step, key=lambda r: r["s"]):
+            if int(r["Stream_Id"]) != a.sequence:
+                continue
+            others = [clean(o["Kernel_Name"])[:28] for o in step if o is not r and o["s"] <= r["s"] < o["e"]]
+            blocks = 1
+            for ax in "XYZ":
+                blocks *= max(1, int(r["Grid_Size_" + ax]) // max(1, int(r["Workgroup_Size_" + ax])))
+            out.append("  %8.3f %7.3f %6d  %-44s | %s" % ((r["s"] - t0) / 1e6, (r["e"] - r["s"]) / 1e6, blocks, clean(r["Kernel_Name"])[:44], ", ".join(others)))
     text = "\n".join(out) + "\n"
     sys.stdout.write(text)
     if a.out:
