@@ -44,13 +44,19 @@ def off(ref, nfloats):
 
 
 class Plan:
-    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1, spectral_pc=None):
+    def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1, spectral_pc=None,
+                 early_adam=False):
         """n = clips per forward pass; the batch the kernels see is N = groups*n.
         accum_grads: backward adds into the flat G buffer instead of overwriting it (drop-in nn.Module path,
         where the reference's two forward passes are two separate autograd graphs).
         lanes: HIP streams the runner may use; >1 tags the four branches of every Inception module (and their
         backward) onto separate lanes between FORK/JOIN ops, so the under-filled 14x14 launches overlap."""
         self.acc = 1 if accum_grads else 0
+        # early_adam: the backward list carries an (un-armed: length 0) Adam op over every parameter but the stem's, on a side lane in
+        # front of the stem's backward -- the HBM-bound optimiser pass then runs beside the stem's MFMA-bound weight gradient, the last
+        # kernel of the step, instead of behind it.  The caller arms it (StepEngine, single process); see build_backward.
+        self.early_adam = bool(early_adam) and lanes >= 2 and training and os.environ.get("PICONS_EARLY_ADAM", "1") != "0"
+        self.op_adam_early, self.adam_split = None, 0
         if hw % 8 or hw // 8 < spec.PRIMARY_K:
             # the reference fails the same way, inside nn.Conv2d (capsules_ucf101.py:43-49: a 9x9 valid conv on the hw/8 feature map)
             raise ValueError("frame size %d: must be a multiple of 8 and at least %d (the 9x9 PrimaryCaps conv needs a feature map of "
@@ -1156,13 +1162,34 @@ class Plan:
         self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
         if (self.wg_lane or self.skip_lane) and os.environ.get("PICONS_DEFER_SIDE", "0") != "0":
             self.deferred = []
-        for fn in reversed(self.tape):
+        for idx, fn in enumerate(reversed(self.tape)):
+            if self.early_adam and idx == len(self.tape) - 1:
+                self._emit_early_adam()
             fn()
             self.flush_unprep()
         self.release_deferred()
         self.flush_unprep()
         if self.wg_lane or self.skip_lane:
             self.join((1 << self.wg_lane | 1 << self.skip_lane) & ~1)
+
+    def _emit_early_adam(self):
+        """In front of the LAST backward closure (the stem unit: the first three tensors of the flat parameter buffer): every other
+        gradient is final once what has been enqueued so far, on any lane, has run.  One Adam op over [adam_split, nparams) on the skip
+        lane (idle by now), ordered behind every lane; length 0 until the caller arms it."""
+        names = sorted(self.pshape, key=self.poff.get)
+        stem = [nm for nm in names if nm.startswith(spec.trunk_units()[0][0] + ".")]
+        assert names[:len(stem)] == stem and len(stem) == 3, "the stem's parameters lead the flat buffer"
+        assert all(nm in self.final_at for nm in names[len(stem):]), "a gradient outside the stem is finalised by the stem's backward"
+        n0 = self.poff[names[len(stem)]]
+        lane = self.skip_lane or 1
+        for src in range(self.lanes):
+            if src != lane:
+                self.fork(1 << lane, src=src)
+        self.adam_split = n0
+        self.op_adam_early = len(self.lists["bwd"])
+        self.emit(capi.OP_ADAM, i=[1], f=[1e-4, 0.9, 0.999, 1e-6, 1.0], l=[0], p=[("P", 4 * n0), ("G", 4 * n0), ("M", 4 * n0), ("V", 4 * n0)], lane=lane)
+        if lane != (self.skip_lane or self.wg_lane):
+            self.join(1 << lane)
 
     def grad_buckets(self, target_floats=12_000_000, joined=False):
         """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the

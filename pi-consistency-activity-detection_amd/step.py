@@ -51,7 +51,7 @@ class StepEngine:
             # measured best on MI355X: lane 1 for the second Inception branch, lane 2 for the decoder's skip convs,
             # lane 3 for the weight gradients
             lanes = int(os.environ.get("PICONS_LANES", "4"))
-        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes)
+        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes, early_adam=True)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         # ROCm binds a stream to one of its (by default four) hardware queues when the stream is first used, and two lanes on one
         # hardware queue serialise: use the lanes, in order, before anything else in this process creates work on another stream
@@ -201,13 +201,31 @@ class StepEngine:
             if done < len(o["bwd"]):
                 run(o["bwd"][done:])
 
+    def arm_early_adam(self, lr, on):
+        """on: the backward list's Adam op (plan.early_adam) updates every parameter but the stem's beside the stem's weight gradient,
+        with THIS step's count and lr; adam() then updates the stem alone.  Off (a reducer is active: the gradients are only final
+        after the all-reduce; or a caller that runs the lists by hand): the op is a no-op and adam() covers everything."""
+        k = self.plan.op_adam_early
+        self._early_armed = bool(on) and k is not None
+        if k is None:
+            return
+        e = self.ops["bwd"][k]
+        e["l"][0] = self.plan.nparams - self.plan.adam_split if self._early_armed else 0
+        e["i"][0] = self.step_count + 1
+        e["f"][0] = lr
+        e["f"][4] = 1.0
+
     def adam(self, lr, gscale=1.0):
         self.step_count += 1
         a = self.ops["adam"][0]
         a["i"][0] = self.step_count
         a["f"][0] = lr
         a["f"][4] = gscale
+        a["l"][0] = self.plan.adam_split if getattr(self, "_early_armed", False) else self.plan.nparams
         ops.run_ops(self.ops["adam"])
+        self._early_armed = False
+        if self.plan.op_adam_early is not None:
+            self.ops["bwd"][self.plan.op_adam_early]["l"][0] = 0       # a backward replayed by hand must not step the optimiser
         for k in self.nbt:
             self.nbt[k] += 2           # two forward passes per step (SURVEY a9)
 
@@ -277,6 +295,7 @@ class StepEngine:
         scalars' copy, which is final before the backward starts.  Stream-ordered consumers (the next step, torch ops on the current
         stream) need nothing; anything else calls synchronize() first.  collect=False leaves the timing events of a timed step pending (the caller
         reads them with collect_timing() later, e.g. after its timed region: reading 212 events costs ~0.4 ms of host time)."""
+        self.arm_early_adam(self.args.lr if lr is None else lr, on=(reducer is None or not reducer.active) and timed_kind is None)
         self.forward_backward(epoch, wt_ramp, reducer, timed_kind)
         gscale = 1.0
         if reducer is not None:

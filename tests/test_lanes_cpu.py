@@ -21,9 +21,9 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,)}
 
 
-def _plan(lanes, bs=1, hw=112):
+def _plan(lanes, bs=1, hw=112, early_adam=False):
     args = pstep.default_args(bv=True, n_frames=5)
-    p = Plan(24, hw, n=bs, groups=2, lanes=lanes)
+    p = Plan(24, hw, n=bs, groups=2, lanes=lanes, early_adam=early_adam)
     p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
     p.finalize()
     return p
@@ -333,3 +333,46 @@ def test_frame_size_is_checked_where_the_reference_would_fail():
         with pytest.raises(ValueError, match="frame size"):
             Plan(24, hw, n=1, groups=2)
     Plan(24, 72, n=1, groups=2)
+
+
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_early_adam_op_is_ordered_behind_every_other_gradient(lanes):
+    """StepEngine's plan: one Adam op inside the backward list, over every parameter but the stem's, on a side lane in front of the stem's
+    backward.  Every op that finalises a gradient in its range, on whatever lane, must happen-before it; nothing behind it may read a
+    parameter in its range; the lane is joined before the list ends."""
+    p = _plan(lanes, early_adam=True)
+    bwd = p.lists["bwd"]
+    k = p.op_adam_early
+    assert k is not None and bwd[k][0] == capi.OP_ADAM and bwd[k][4] == [0] and bwd[k][5] != 0          # un-armed, on a side lane
+    _check_list(p, bwd, lanes)
+    n0 = p.adam_split
+    assert n0 == p.poff["conv1.Conv3d_2b_1x1.conv3d.weight"]
+    # happens-before of every earlier op: replay the clocks up to k
+    clock = [[0] * lanes for _ in range(lanes)]
+    stamp_of = {}
+    for idx, op in enumerate(bwd[:k + 1]):
+        kind, lane = op[0], op[5]
+        if kind == capi.OP_FORK:
+            src = op[1][1] if len(op[1]) > 1 else 0
+            for q in range(lanes):
+                if (op[1][0] >> q) & 1 and q != src:
+                    clock[q] = [max(a, b) for a, b in zip(clock[q], clock[src])]
+        elif kind == capi.OP_JOIN:
+            for q in range(1, lanes):
+                if (op[1][0] >> q) & 1:
+                    clock[0] = [max(a, b) for a, b in zip(clock[0], clock[q])]
+        else:
+            clock[lane][lane] += 1
+            stamp_of[idx] = (lane, list(clock[lane]))
+    alane, astamp = stamp_of[k]
+    for idx, (lane, st) in stamp_of.items():
+        if idx != k:
+            assert st[lane] <= astamp[lane], "op %d on lane %d is not ordered before the early Adam" % (idx, lane)
+    # every gradient outside the stem is final before it; the ops behind it touch no parameter / gradient / moment in its range
+    for nm in p.pshape:
+        if p.poff[nm] >= n0:
+            assert p.final_at[nm] <= k, nm
+    for op in bwd[k + 1:]:
+        for r in op[3]:
+            if isinstance(r, tuple) and r[0] in ("P", "G", "M", "V"):
+                assert r[1] < 4 * n0, (op[0], r)

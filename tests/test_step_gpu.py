@@ -432,3 +432,34 @@ def test_thread_events_can_be_released_between_steps():
     eng.collect_timing()
     assert eng.kind_count > 50 and eng.kind_ms > 0.0
     capi.call("pc_release_thread_events")
+
+
+def test_early_adam_uses_final_gradients():
+    """The backward list's early Adam op (every parameter but the stem's, beside the stem's weight gradient) must see FINAL gradients:
+    after one armed step from zero moments, every parameter equals p - lr * g / (|g| + eps) of the gradient left in G, and the same
+    step with the op un-armed (PICONS_EARLY_ADAM=0 semantics: one Adam behind the backward) gives the same parameters."""
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    eng = pstep.StepEngine(args, bs=2, hw=112)
+    assert eng.plan.op_adam_early is not None and 0 < eng.plan.adam_split < eng.plan.nparams
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, step=3, hw=112)
+    res = []
+    for armed in (True, False):
+        eng.load_state(synthetic.init_state(53, 24))
+        eng.M.zero_(); eng.V.zero_(); eng.step_count = 0
+        p0 = eng.P.clone()
+        eng.stage(lab, unl, perm, drops)
+        if armed:
+            eng.run_staged(1, 0.01, lr=1e-3)
+        else:
+            eng.arm_early_adam(1e-3, on=False)
+            eng.forward_backward(1, 0.01)
+            eng.adam(1e-3)
+        eng.synchronize()
+        g = eng.G.double()
+        want = p0.double() - 1e-3 * g / (g.abs() + 1e-6)
+        err = (eng.P.double() - want).abs().max().item()
+        assert err <= 2e-7, (armed, err)
+        assert int(eng.ops["bwd"][eng.plan.op_adam_early]["l"][0]) == 0          # disarmed again behind the step
+        res.append(eng.P.clone())
+    # weight gradients are summed with fp32 atomics (arrival order): the two runs agree to that, not bit for bit
+    assert ((res[0] - res[1]).abs().max().item()) <= 2e-3 * 1e-3 + 1e-7 or ((res[0] - res[1]).norm() / res[0].norm()).item() < 1e-6
