@@ -306,6 +306,21 @@ __device__ __forceinline__ void glds16(const float* g, float* l) {
                                      (__attribute__((address_space(3))) void*)l, 16, 0, 0);
 }
 
+// The same 1 KiB LDS-DMA piece through a raw buffer resource: wave-uniform base (SGPRs, rebuilt per K chunk with scalar adds) + one
+// 32-bit byte offset per lane.  Measured beside the MFMA stream (tools/mfma_peak_probe.hip, PROBE_DMA=1): a piece with 64-bit per-lane
+// addresses costs ~60 cycles of matrix-pipe time (the address VGPR pairs and the 64-bit adds that make them), this form ~24.  A lane
+// whose offset is DMA_OOB lies outside the resource: the hardware writes ZEROS into its LDS slot (tools/dma_oob_probe.hip), so padding
+// taps need no zero line and no address select.  Tensors addressed this way must be smaller than 4 GiB (checked by the launchers).
+constexpr unsigned DMA_OOB = 0xffffffffu;
+constexpr long long DMA_MAX_BYTES = 0xff000000ll;
+typedef __amdgpu_buffer_rsrc_t dma_rsrc_t;
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffff00u, 0x00020000);
+}
+__device__ __forceinline__ void glds16b(dma_rsrc_t rs, unsigned voff, float* l) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
+}
+
 template <int BM, int BN, int WM, int WN, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -322,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     int* rout = rinfo + BM * 4;                // [BM] output position index or -1
     unsigned* tile_or = (unsigned*)(rout + BM);   // OR of every row's tap-validity mask
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     // VAR bit 2 (TAP4): Ci == 4 (the stem: 3 channels padded to one 16-byte piece per tap) - a K chunk is 8 consecutive taps of the
     // tile's tap box instead of 32 channels of one tap, so every 16-byte DMA piece has its own tap (address, validity)
@@ -357,8 +372,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 
     // per-thread fetch rows: row = lrow + 32*j, 16-byte slot (tid&7), source slot XOR-swizzled
     const int lrow = tid >> 3, slot = tid & 7;
-    const float* aptr[AR]; unsigned amask[AR];
-    const float* bptr[BR];
+    unsigned adma[AR], amask[AR];      // byte offset of the row's tap-origin position from (p.in - abias): never negative
+    unsigned bdma[BR];                 // byte offset of the output channel's weight row from wbase, DMA_OOB past Co
+    // tap origins may lie in the padding (negative coordinates): the lowest origin position any row can have, as a bias on the base
+    const long long apos0 = ((long long)min(p.ioff0[0], 0) * p.Hi + min(p.ioff0[1], 0)) * p.Wi + min(p.ioff0[2], 0);
+    const long long abias = -apos0 * p.ldi;      // floats
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int row = lrow + 32 * j;
@@ -372,13 +390,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         }
         amask[j] = m;
         const long long pos = ((long long)(ri.x * p.Ti + ri.y) * p.Hi + ri.z) * p.Wi + ri.w;   // may be "out of range": only used when valid
-        aptr[j] = p.in + pos * p.ldi + ks;
+        adma[j] = (unsigned)(((pos - apos0) * p.ldi + ks) * 4);
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
         const int row = lrow + 32 * j, co = n0 + row;
         const int ks = TAP4 ? 0 : (slot ^ ((row >> 1) & 7)) * 4;
-        bptr[j] = co < p.Co ? wbase + (size_t)co * p.wtaps * p.ldw + ks : nullptr;
+        bdma[j] = co < p.Co ? (unsigned)(((size_t)co * p.wtaps * p.ldw + ks) * 4) : DMA_OOB;
     }
 
     // Tap box of the tile: per dimension a row's valid taps form an interval, and so does their union over the tile.
@@ -416,16 +434,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
             const long long db = (long long)wtap * p.ldw;
             float* la = As + buf * BM * BK + (wave * 8) * BK;
             float* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+            // every lane has its own tap here: the tap offset is a 32-bit per-lane add (wraps back into range whenever the tap is valid)
+            const dma_rsrc_t ra = dma_rsrc(p.in - abias), rb = dma_rsrc(wbase);
+            const unsigned dab = (unsigned)(da * 4), dbb = (unsigned)(db * 4);
 #pragma unroll
-            for (int j = 0; j < AR; ++j) {
-                const float* src = ((amask[j] & sel) == sel) ? aptr[j] + da : g_zero16;
-                glds16(src, la + j * 32 * BK);
-            }
+            for (int j = 0; j < AR; ++j) glds16b(ra, ((amask[j] & sel) == sel) ? adma[j] + dab : DMA_OOB, la + j * 32 * BK);
 #pragma unroll
-            for (int j = 0; j < BR; ++j) {
-                const float* src = (bptr[j] && inb) ? bptr[j] + db : g_zero16;
-                glds16(src, lb + j * 32 * BK);
-            }
+            for (int j = 0; j < BR; ++j) glds16b(rb, (bdma[j] != DMA_OOB && inb) ? bdma[j] + dbb : DMA_OOB, lb + j * 32 * BK);
             t_c += 8;
             while (t_c > c_hi) { t_c -= nc_; if (++t_b > b_hi) { t_b = b_lo; ++t_a; } }
             return;
@@ -436,16 +451,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
         const long long db = (long long)wtap * p.ldw + u_ci;
         float* la = As + buf * BM * BK + (wave * 8) * BK;     // wave-uniform base; the DMA adds lane*16 B itself
         float* lb = Bs + buf * BN * BK + (wave * 8) * BK;
+        // the tap / channel-chunk offset is wave-uniform: it moves the resource base (scalar adds), the lane offsets never change
+        const dma_rsrc_t ra = dma_rsrc(p.in + (da - abias)), rb = dma_rsrc(wbase + db);
 #pragma unroll
-        for (int j = 0; j < AR; ++j) {
-            const float* src = ((amask[j] & sel) == sel) ? aptr[j] + da : g_zero16;
-            glds16(src, la + j * 32 * BK);
-        }
+        for (int j = 0; j < AR; ++j) glds16b(ra, ((amask[j] & sel) == sel) ? adma[j] : DMA_OOB, la + j * 32 * BK);
 #pragma unroll
-        for (int j = 0; j < BR; ++j) {
-            const float* src = bptr[j] ? bptr[j] + db : g_zero16;
-            glds16(src, lb + j * 32 * BK);
-        }
+        for (int j = 0; j < BR; ++j) glds16b(rb, bdma[j], lb + j * 32 * BK);
         u_ci += BK;
         if (u_ci >= p.Ci) {
             u_ci = 0;
@@ -572,6 +583,12 @@ template <int BM, int BN, int WM, int WN, int VAR>
 int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
     static bool attr_set = false;
     constexpr int ST = 2 + ((VAR >> 3) & 3);
+    {   // the tiles are fetched with 32-bit lane offsets from a wave-uniform base (glds16b)
+        const long long halo = ((long long)(k.ioff0[0] < 0 ? -k.ioff0[0] : 0) * k.Hi + (k.ioff0[1] < 0 ? -k.ioff0[1] : 0)) * k.Wi + (k.ioff0[2] < 0 ? -k.ioff0[2] : 0);
+        const long long in_bytes = ((long long)k.N * k.Ti * k.Hi * k.Wi + 2 * halo) * k.ldi * 4, w_bytes = (long long)k.Co * k.wtaps * k.ldw * 4;
+        PC_CHECK_ARG(in_bytes < DMA_MAX_BYTES && w_bytes < DMA_MAX_BYTES,
+                     "pc_conv_fwd: input (%lld B) or weights (%lld B) exceed the 4 GiB the LDS-DMA gather addresses: use a smaller per-GPU batch", in_bytes, w_bytes);
+    }
     const size_t lds = (size_t)(ST * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
     if (!attr_set) {
         (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

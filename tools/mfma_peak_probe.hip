@@ -46,13 +46,32 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ src, f
     const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
-        if (MODE >= 3) {
-            float* la = As + (buf ^ 1) * 128 * 32 + wave * 8 * 32;
-            float* lb = Bs + (buf ^ 1) * 64 * 32 + wave * 8 * 32;
+        // MODE 3: the conv kernel's form (64-bit per-lane addresses, M0 from a per-lane LDS pointer).  4: wave index made uniform.  5: scalar base +
+        // 32-bit per-lane offset (saddr form).  6: buffer_load ... lds (resource + 32-bit offset).  7: mode 4 with half the pieces.
+        // 8: mode 4 with the six pieces spread behind the MFMA groups instead of bunched at the head of the chunk.
+        const int wv = (MODE >= 4) ? __builtin_amdgcn_readfirstlane(wave) : wave;
+        float* la = As + (buf ^ 1) * 128 * 32 + wv * 8 * 32;
+        float* lb = Bs + (buf ^ 1) * 64 * 32 + wv * 8 * 32;
+        const float* gsrc = gp + (size_t)(c & 15) * 6144;
+        auto piece = [&](int j) {
+            float* l = j < 4 ? la + j * 32 * 32 : lb + (j - 4) * 32 * 32;
+            if (MODE == 5) {
+                const unsigned voff = (unsigned)(((size_t)lrow * 32 + slot * 4 + (size_t)j * 32 * 32) * 4);
+                const float* sb = src + (size_t)(blockIdx.x % 512) * 192 * 32 + (size_t)(c & 15) * 6144;
+                const unsigned m0v = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)l;
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" :: "v"(voff), "s"(sb), "s"(m0v) : "memory");
+            } else if (MODE == 6) {
+                const unsigned voff = (unsigned)(((size_t)lrow * 32 + slot * 4 + (size_t)j * 32 * 32) * 4);
+                const float* sb = src + (size_t)(blockIdx.x % 512) * 192 * 32 + (size_t)(c & 15) * 6144;
+                auto rs = __builtin_amdgcn_make_buffer_rsrc((void*)sb, 0, 0x7fffffff, 0x00020000);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
+            } else {
+                glds16(gsrc + (size_t)j * 32 * 32, l);
+            }
+        };
+        if (MODE >= 3 && MODE != 8) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) glds16(gp + (size_t)j * 32 * 32 + (size_t)(c & 15) * 6144, la + j * 32 * 32);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) glds16(gp + (size_t)(4 + j) * 32 * 32 + (size_t)(c & 15) * 6144, lb + j * 32 * 32);
+            for (int j = 0; j < (MODE == 7 ? 3 : 6); ++j) piece(j);
         }
         const float* a = As + (MODE >= 3 ? buf : 0) * 128 * 32;
         const float* b = Bs + (MODE >= 3 ? buf : 0) * 64 * 32;
@@ -68,9 +87,15 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ src, f
                 af[0] = ra[0]; af[1] = ra[1]; bf = rb;
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
+            for (int e = 0; e < 4; ++e) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[e], acc[i], 0, 0, 0);
+                if (MODE == 8 && ks < 3 && (e & 1)) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(ks * 2 + (e >> 1));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
         if (MODE >= 2) __syncthreads();
     }
@@ -199,6 +224,13 @@ int main() {
         run<1>("1 + fragment reads (ds_read_b128)", bpc, nchunks, src, out, stamps);
         run<2>("2 + barrier per chunk", bpc, nchunks, src, out, stamps);
         run<3>("3 + LDS-DMA fill of the next chunk", bpc, nchunks, src, out, stamps);
+        if (getenv("PROBE_DMA")) {
+            run<4>("4 DMA, uniform wave index", bpc, nchunks, src, out, stamps);
+            run<5>("5 DMA, scalar base + 32-bit lane offset", bpc, nchunks, src, out, stamps);
+            run<6>("6 DMA, buffer_load ... lds", bpc, nchunks, src, out, stamps);
+            run<7>("7 DMA, half the pieces", bpc, nchunks, src, out, stamps);
+            run<8>("8 DMA, pieces spread behind MFMA groups", bpc, nchunks, src, out, stamps);
+        }
     }
     return 0;
 }
