@@ -352,15 +352,17 @@ class Plan:
     # ------------------------------------------------------------------ Winograd F(2x2, 3x3) form of the stride-1 3x3x3 layers
     def wino_ok(self, x, cout, k, stride, pad=None):
         """The layers that run in Winograd form (csrc/wino.hip, 2.25x fewer multiply-accumulates, measured 1.5 - 2.2x faster than
-        the gather-GEMM kernel on them; 1x3x3 at 28x28 measured slower and stays): 3x3x3 convs with spatial stride 1 (any temporal
-        stride: the temporal taps stay direct) and same padding over >= 2 frames, even H, W and enough channels to fill the kernel's
-        64 x 64 (tiles x channels) block.  PICONS_WINO=0: off."""
+        the gather-GEMM kernel on them): 3x3x3 convs with spatial stride 1 (any temporal stride: the temporal taps stay direct) and same
+        padding, even H, W and enough channels to fill the kernel's 64 x 64 (tiles x channels) block.  The one-frame 28x28 layers
+        (Mixed_4b..4f, 1x3x3 once the padding taps are dropped) are 0.97x alone -- 320 whole-CU blocks on 256 CUs -- but 2.25x fewer
+        MFMAs in a step whose lanes keep the chip full: kept (PICONS_WINO_T1=0 restores the gather-GEMM form).  PICONS_WINO=0: off."""
         if os.environ.get("PICONS_WINO", "1") == "0":
             return False
         if tuple(k) != (3, 3, 3) or tuple(stride[1:]) != (1, 1) or stride[0] not in (1, 2) or (pad is not None and tuple(pad) != (1, 1, 1)):
             return False
         T, H, W = x.thw
-        return T >= 2 and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= 32 and cout >= 64 and x.ld % 4 == 0
+        tmin = 1 if os.environ.get("PICONS_WINO_T1", "1") != "0" else 2     # one frame (Mixed_4b..4f: only the centre temporal tap is real): -0.13 ms on the step
+        return T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(os.environ.get("PICONS_WINO_CMIN", "32")) and cout >= 64 and x.ld % 4 == 0
 
     def wino_weights(self, wname, O, I, need_tr):
         """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
