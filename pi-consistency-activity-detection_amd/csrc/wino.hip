@@ -14,11 +14,17 @@
 
 namespace {
 
-__device__ __attribute__((aligned(16))) float w_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
+// 1 KiB LDS-DMA piece through a raw buffer resource: wave-uniform base + one 32-bit byte offset per lane; a lane whose offset is DMA_OOB gets
+// zeros (see conv.hip, glds16b: this form costs the matrix pipe less than half of what 64-bit per-lane addresses cost).  In this kernel every
+// lane offset is a per-block constant -- the K loop spends no vector instruction on DMA addresses.
+constexpr unsigned DMA_OOB = 0xffffffffu;
+typedef __amdgpu_buffer_rsrc_t dma_rsrc_t;
+__device__ __forceinline__ dma_rsrc_t dma_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffff00u, 0x00020000);
+}
 template <bool ON = true>
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-    if (ON) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+__device__ __forceinline__ void glds16b(dma_rsrc_t rs, unsigned voff, float* l) {
+    if (ON) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
 }
 
 struct WinoK {
@@ -107,17 +113,16 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int h0 = 2 * bh * p.BTH - 1, w0 = 2 * bw * p.BTW - 1;          // image position of patch position (0, 0)
 
     // raw-patch DMA role: piece j of this wave is piece wave + 4 j of the image; lane -> (position q = piece * 32 + lane / 2, 4-channel half)
-    int roff[3];
-    unsigned rmask = 0;
+    unsigned roff[3];                  // byte offset inside the source plane, DMA_OOB for padding positions (the DMA writes zeros there)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int q = (wave + 4 * j) * 32 + (lane >> 1);
         const int pr = q / PW, pc = q - pr * PW;
         const int h = h0 + pr, w = w0 + pc;
         const bool ok = q < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-        roff[j] = ok ? (h * p.W + w) * p.ldi + (lane & 1) * 4 : 0;
-        rmask |= (ok ? 1u : 0u) << j;
+        roff[j] = ok ? (unsigned)(((h * p.W + w) * p.ldi + (lane & 1) * 4) * 4) : DMA_OOB;
     }
+    const unsigned uoff = lane * 16;   // U pieces are contiguous images
 
     // transform role: thread = (tile, k half, row pair); reads 3 rows x 4 columns of R
     const int ttile = lane, tkh = wave & 1, thalf = wave >> 1;
@@ -151,25 +156,21 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         q = (wrap && !last) ? q + 1 : q;
     };
     auto r_base = [&](int q, int c8) -> const float* { return (q == 0 ? rtap0 : (q == 1 ? rtap1 : rtap2)) + c8 * WK; };
-    auto u_base = [&](int q, int c8) -> const float* { return (q == 0 ? utap0 : (q == 1 ? utap1 : utap2)) + (size_t)c8 * PLANE + lane * 4; };
+    auto u_base = [&](int q, int c8) -> const float* { return (q == 0 ? utap0 : (q == 1 ? utap1 : utap2)) + (size_t)c8 * PLANE; };
     int uq = 0, uc8 = 0, rq = 0, rc8 = 0;
 
     const float* rnext = nullptr;                 // source plane / channel slice of the chunk whose raw patch the loop fetches
     auto issue_r = [&](const float* base, int rb) {           // raw patch -> R[rb] (prologue)
         float* rl = Rs + rb * RPLANE + wave * 256;
+        const dma_rsrc_t rs = dma_rsrc(base);
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const float* src = ((rmask >> j) & 1u) ? base + roff[j] : w_zero16;
-            glds16<!(VAR & 1)>(src, rl + j * 4 * 256);
-        }
+        for (int j = 0; j < 3; ++j) glds16b<!(VAR & 1)>(rs, roff[j], rl + j * 4 * 256);
     };
     const float* ug = nullptr;
     float* ul = nullptr;
     f32x4 d[12], x0[4], x1[4];
     const float* rsrc = nullptr;
     float* vb = nullptr;
-    const float* zl = w_zero16;                   // the zero line's address once, in registers (the compiler otherwise re-loads it from the
-    asm volatile("" : "+v"(zl));                  // GOT per use: an s_load per DMA piece, and every s_waitcnt lgkmcnt becomes (0))
     auto read2 = [&](int g, int c0) {             // two columns of patch row g of this thread's three rows (tiles beyond the block's
 #pragma unroll                                    // rectangle read some valid position: their rows are never stored)
         for (int c = c0; c < c0 + 2; ++c) d[g * 4 + c] = *(const f32x4*)(rsrc + (g * PW + c) * 8);
@@ -201,11 +202,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         if constexpr (e == 0 && g < 6) read2(g >> 1, (g & 1) * 2);                                     // patch rows of chunk c + 1 out of R
         if constexpr (e == 0 && g >= 8 && g < 12) store_out(0, g - 8);
         if constexpr (e == 0 && g >= 12) store_out(1, g - 12);
-        if constexpr (e == 2 && g < 8) glds16<!(VAR & 2)>(ug + g * 256, ul + g * 256);                 // U piece g of chunk c + 1
-        if constexpr (e == 2 && g >= 8 && g < 11) {                                                   // R piece g - 8 of chunk c + 2
-            const float* src = ((rmask >> (g - 8)) & 1u) ? rnext + roff[g - 8] : zl;
-            glds16<!(VAR & 1)>(src, Rs + buf * RPLANE + (wave + 4 * (g - 8)) * 256);
-        }
+        if constexpr (e == 2 && g < 8) glds16b<!(VAR & 2)>(dma_rsrc(ug + g * 256), uoff, ul + g * 256);  // U piece g of chunk c + 1
+        if constexpr (e == 2 && g >= 8 && g < 11)                                                     // R piece g - 8 of chunk c + 2
+            glds16b<!(VAR & 1)>(dma_rsrc(rnext), roff[g - 8], Rs + buf * RPLANE + (wave + 4 * (g - 8)) * 256);
         if constexpr (g == 6 && e >= 2) { xcol(0, (e - 2) * 2); xcol(0, (e - 2) * 2 + 1); }
         if constexpr (g == 7 && e >= 2) { xcol(1, (e - 2) * 2); xcol(1, (e - 2) * 2 + 1); }
     };
@@ -228,7 +227,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         ug = u_base(uq, uc8);
         ul = Us + wave * 8 * 256;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) glds16<!(VAR & 2)>(ug + j * 256, ul + j * 256);
+        for (int j = 0; j < 8; ++j) glds16b<!(VAR & 2)>(dma_rsrc(ug + j * 256), uoff, ul + j * 256);
         advance(uq, uc8);                         // -> chunk 1
     }
     __syncthreads();
@@ -362,7 +361,7 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     PC_CHECK_ARG(d->Ci >= 8 && d->Ci % 8 == 0 && d->ldi % 4 == 0 && d->Co >= 1 && d->ldo >= d->Co, "pc_wino: Ci %% 8, ldi %% 4 (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
     PC_CHECK_ARG(d->KT == 1 || d->KT == 3, "pc_wino: KT must be 1 or 3");
     PC_CHECK_ARG((int64_t)d->N * (d->T > d->Ti ? d->T : d->Ti) * d->H * d->W * (int64_t)(d->ldi > d->ldo ? d->ldi : d->ldo) < (1ll << 40), "pc_wino: tensor too large");
-    PC_CHECK_ARG((int64_t)d->H * d->W * d->ldi < (1ll << 31), "pc_wino: plane too large");
+    PC_CHECK_ARG((int64_t)d->H * d->W * d->ldi * 4 < 0xff000000ll, "pc_wino: plane too large (the LDS-DMA lane offsets are 32-bit byte offsets inside one frame)");
     k.N = d->N; k.T = d->T; k.H = d->H; k.W = d->W; k.Ci = d->Ci; k.ldi = d->ldi; k.Co = d->Co; k.ldo = d->ldo;
     k.TH = d->H / 2; k.TW = d->W / 2;
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
