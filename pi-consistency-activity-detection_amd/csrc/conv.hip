@@ -870,7 +870,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     __shared__ int4 ptab[3][BK];                     // per chunk: n, t0, h0, w0 of its 32 positions
     __shared__ int drow[3][BK];                      // row of D for each position (sub-lattice launches)
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     // lid: logical block id of this problem (XCD-aware order: the blocks of one K slice -- every tile reads the same rows of D, and
     // overlapping rows of S -- get consecutive ids, i.e. run on one XCD and share its L2)
@@ -919,6 +919,10 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     // tiles go global -> LDS directly (global_load_lds_dwordx4): each wave-instruction writes 1 KiB = consecutive
     // float4 columns of consecutive position rows, which is exactly the lane-linear image the DMA produces
     // (LDS float offset of thread tid in pass j = (tid + 256*j) * 4); invalid rows / taps read a zero line.
+    // LDS-DMA through buffer resources (glds16b): the bases are the two tensors (wave-uniform), a lane's offset is 32-bit -- one 32-bit
+    // multiply-add per piece instead of a 64-bit one and an address select; invalid rows / taps are DMA_OOB lanes (zero-filled)
+    const dma_rsrc_t rsD = dma_rsrc(Dp + m0), rsS = dma_rsrc(Sp);
+    const unsigned dcolb = mval ? (unsigned)dcol * 4u : DMA_OOB, csb = (unsigned)cs * 4u;
     auto gload = [&](int c, int buf) {
         float* ld = &Ds[buf][0][0] + wave * 256;      // wave-uniform base; the DMA adds lane*16 B
         float* ls = &Ss[buf][0][0] + wave * 256;
@@ -928,8 +932,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
             const int r = drow0 + DRP * j;
             const int pos = c * BK + r;
             const bool v = mval && pos < p.P;
-            const float* src = v ? Dp + (size_t)drow[c % 3][r] * p.ldd + m0 + dcol : g_zero16;
-            glds16(src, ld + j * 1024);
+            glds16b(rsD, v ? (unsigned)drow[c % 3][r] * (unsigned)(p.ldd * 4) + dcolb : DMA_OOB, ld + j * 1024);
         }
         if (ABL != 4)
 #pragma unroll
@@ -939,9 +942,8 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
             const int t = info.y + dt, h = info.z + dh, w = info.w + dw;
             const bool v = nval && info.x >= 0 && (unsigned)t < (unsigned)p.Ts && (unsigned)h < (unsigned)p.Hs &&
                            (unsigned)w < (unsigned)p.Ws;
-            const size_t ps = (size_t)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
-            const float* src = v ? Sp + ps * p.lds + cs : g_zero16;
-            glds16(src, ls + j * 1024);
+            const unsigned ps = (unsigned)(((info.x * p.Ts + t) * p.Hs + h) * p.Ws + w);
+            glds16b(rsS, v ? ps * (unsigned)(p.lds * 4) + csb : DMA_OOB, ls + j * 1024);
         }
     };
 
@@ -1088,14 +1090,16 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
         if (!decode(row_d, row_s, w0)) return false;
         float* ld = buf ? &Ds1[0][0] : &Ds0[0][0];
         float* ls = buf ? &Ss1[0][0] : &Ss0[0][0];
+        // wave-uniform bases: the segment's first position (the S base may lie padw positions in front of its row: only address arithmetic)
+        const dma_rsrc_t rsD = dma_rsrc(Dp + (size_t)(row_d + w0) * p.ldd + m0);
+        const dma_rsrc_t rsS = dma_rsrc(Sp + ((long long)row_s + w0 - p.padw) * p.lds + cs0);
 #pragma unroll
         for (int jj = 0; jj < (DI + 3) / 4; ++jj) {                        // D tile: BKP rows x BM channels
             const int i = jj * 4 + wave;
             if (i >= DI) break;
             const int e = i * 64 + lane, r = e / (BM / 4), c4 = e % (BM / 4);
             const bool v = (w0 + r) < p.W && (m0 + c4 * 4) < p.Cd;
-            const float* src = v ? Dp + (size_t)(row_d + w0 + r) * p.ldd + m0 + c4 * 4 : g_zero16;
-            glds16(src, ld + i * 256);
+            glds16b(rsD, v ? (unsigned)(r * p.ldd + c4 * 4) * 4u : DMA_OOB, ld + i * 256);
         }
 #pragma unroll
         for (int jj = 0; jj < (SI + 3) / 4; ++jj) {                        // S tile: positions w0-pad .. w0-pad+BKP+KW-2 (+ padding rows)
@@ -1104,8 +1108,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
             const int e = i * 64 + lane, r = e / (CSB / 4), c4 = e % (CSB / 4);
             const int w = w0 - p.padw + r;
             const bool v = r < BKP + KW - 1 && (unsigned)w < (unsigned)p.Wsw;
-            const float* src = v ? Sp + (size_t)(row_s + w) * p.lds + cs0 + c4 * 4 : g_zero16;
-            glds16(src, ls + i * 256);
+            glds16b(rsS, v ? (unsigned)(r * p.lds + c4 * 4) * 4u : DMA_OOB, ls + i * 256);
         }
         return true;
     };
@@ -1233,14 +1236,16 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
         const int ts = t * p.istr_t + p.ioff_t + kt_, hs0 = h * p.istr_h + p.ioff_h;
         float* ld = buf ? &Ds1[0][0] : &Ds0[0][0];
         float* ls = buf ? &Ss1[0] : &Ss0[0];
+        const dma_rsrc_t rsD = dma_rsrc(p.D + (size_t)(row_d + w0) * p.ldd + m0);
+        // S rows hs0 .. hs0 + NKH - 1 of frame (n, ts), from w0*SW - padw on: base at (hs0, w0*SW - padw) -- possibly in front of the frame
+        const dma_rsrc_t rsS = dma_rsrc(p.S + (((long long)(n * p.Ts + ts) * p.Hs + hs0) * p.Wsw + (long long)w0 * SW - p.padw) * p.lds);
 #pragma unroll
         for (int jj = 0; jj < (DI + 3) / 4; ++jj) {
             const int i = jj * 4 + wave;
             if (i >= DI) break;
             const int e = i * 64 + lane, rr = e / (BM / 4), c4 = e % (BM / 4);
             const bool v = (m0 + c4 * 4) < p.Cd;
-            const float* src = v ? p.D + (size_t)(row_d + w0 + rr) * p.ldd + m0 + c4 * 4 : g_zero16;
-            glds16(src, ld + i * 256);
+            glds16b(rsD, v ? (unsigned)(rr * p.ldd + c4 * 4) * 4u : DMA_OOB, ld + i * 256);
         }
 #pragma unroll
         for (int jj = 0; jj < (SI + 3) / 4; ++jj) {
@@ -1249,8 +1254,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
             const int e = i * 64 + lane, kh = e / ROWP, rr = e - kh * ROWP;
             const int hs = hs0 + kh, w = w0 * SW - p.padw + rr;
             const bool v = kh < NKH && (unsigned)hs < (unsigned)p.Hs && (unsigned)w < (unsigned)p.Wsw;
-            const float* src = v ? p.S + ((size_t)((n * p.Ts + ts) * p.Hs + hs) * p.Wsw + w) * p.lds : g_zero16;
-            glds16(src, ls + i * 256);
+            glds16b(rsS, v ? (unsigned)((kh * p.Wsw + rr) * p.lds) * 4u : DMA_OOB, ls + i * 256);     
         }
     };
 
@@ -1446,6 +1450,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     PC_CHECK_ARG(!k.dlat || (int64_t)d->N * d->Td * d->Hd * d->Wd < (1ll << 31), "pc_conv_wgrad: D tensor too large");
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad: position count out of range");
+    PC_CHECK_ARG((int64_t)d->N * d->Ts * d->Hs * d->Ws * d->lds * 4 < DMA_MAX_BYTES && (k.dlat ? (int64_t)d->N * d->Td * d->Hd * d->Wd : P) * d->ldd * 4 < DMA_MAX_BYTES,
+                 "pc_conv_wgrad: D or S exceeds the 4 GiB the LDS-DMA gather addresses: use a smaller per-GPU batch");
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
     k.nchunks = cdiv(P, BK);
@@ -1605,6 +1611,8 @@ int wg_fill(const pc_wgrad_desc* d, const float* D, const float* S, float* g, Wg
     k.dlat = d->Td > 0; k.Td = d->Td; k.Hd = d->Hd; k.Wd = d->Wd;
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     PC_CHECK_ARG(P > 0 && P < (1ll << 31) && (int64_t)d->N * d->Ts * d->Hs * d->Ws < (1ll << 31), "pc_conv_wgrad_multi: position count out of range");
+    PC_CHECK_ARG((int64_t)d->N * d->Ts * d->Hs * d->Ws * d->lds * 4 < DMA_MAX_BYTES && (d->Td > 0 ? (int64_t)d->N * d->Td * d->Hd * d->Wd : P) * d->ldd * 4 < DMA_MAX_BYTES,
+                 "pc_conv_wgrad_multi: D or S exceeds the 4 GiB the LDS-DMA gather addresses");
     PC_CHECK_ARG(!k.dlat || (int64_t)d->N * d->Td * d->Hd * d->Wd < (1ll << 31), "pc_conv_wgrad_multi: D tensor too large");
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
