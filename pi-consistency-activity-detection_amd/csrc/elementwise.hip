@@ -8,35 +8,34 @@ namespace {
 
 // ------------------------------------------------------------------------------ BN forward
 // part [groups][npg][2][C]; stat [groups][4][C] = mean, invstd, scale, shift.
-constexpr int FIN_RL = 64;   // row lanes of the partial-sum finalize kernels (1024-thread blocks)
+constexpr int FIN_RL = 16;   // row lanes of the partial-sum finalize kernels
 constexpr int FIN_CL = 16;   // channels per block: C / 16 blocks, so that even the 64-channel layers spread over a few CUs
+constexpr int FIN_T = FIN_RL * FIN_CL;
+// 256-thread blocks (one wave per SIMD, <= 32 registers, 4 KB of LDS): these kernels are a handful of blocks on the step's dependency chain, and
+// they run beside GEMM launches that fill every resident-block slot for hundreds of microseconds.  As 1024-thread blocks (four waves per SIMD and
+// 128 registers per lane at once on ONE CU) they waited for a CU to drain: 35 us on average in the four-lane step, up to 290, against 5 alone.
 
 // sum over partial rows [npg][2][C] for FIN_CL channels; result valid on threads with rl == 0
 template <typename TP>
 __device__ __forceinline__ void partial_colsum(const TP* __restrict__ part, int npg, int C, int c, int rl,
                                                double (*sh)[FIN_RL][FIN_CL], int cl, double& s, double& s2) {
-    double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
     if (c < C) {
         int i = rl;
-        for (; i + FIN_RL < npg; i += 2 * FIN_RL) {
-            const TP* q0 = part + (size_t)i * 2 * C + c;
-            const TP* q1 = part + (size_t)(i + FIN_RL) * 2 * C + c;
-            const TP x0 = q0[0], y0 = q0[C], x1 = q1[0], y1 = q1[C];
-            a0 += (double)x0; b0 += (double)y0; a1 += (double)x1; b1 += (double)y1;
+        for (; i + 3 * FIN_RL < npg; i += 4 * FIN_RL) {          // four independent rows in flight per thread
+            TP x[4], y[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { const TP* q = part + (size_t)(i + u * FIN_RL) * 2 * C + c; x[u] = q[0]; y[u] = q[C]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] += (double)x[u]; b[u] += (double)y[u]; }
         }
-        if (i < npg) { const TP* q0 = part + (size_t)i * 2 * C + c; a0 += (double)q0[0]; b0 += (double)q0[C]; }
+        for (; i < npg; i += FIN_RL) { const TP* q = part + (size_t)i * 2 * C + c; a[0] += (double)q[0]; b[0] += (double)q[C]; }
     }
-    sh[0][rl][cl] = a0 + a1; sh[1][rl][cl] = b0 + b1;
+    sh[0][rl][cl] = (a[0] + a[1]) + (a[2] + a[3]); sh[1][rl][cl] = (b[0] + b[1]) + (b[2] + b[3]);
     __syncthreads();
     s = 0; s2 = 0;
-    if (rl < 8) {            // two levels: 8 row lanes sum 8 rows each, lane 0 sums those
-        double t = 0, t2 = 0;
-        for (int r = rl * (FIN_RL / 8); r < (rl + 1) * (FIN_RL / 8); ++r) { t += sh[0][r][cl]; t2 += sh[1][r][cl]; }
-        sh[0][rl * (FIN_RL / 8)][cl] = t; sh[1][rl * (FIN_RL / 8)][cl] = t2;
-    }
-    __syncthreads();
     if (rl == 0)
-        for (int r = 0; r < FIN_RL; r += FIN_RL / 8) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
+        for (int r = 0; r < FIN_RL; ++r) { s += sh[0][r][cl]; s2 += sh[1][r][cl]; }
     __syncthreads();
 }
 
@@ -44,7 +43,7 @@ __device__ __forceinline__ void partial_colsum(const TP* __restrict__ part, int 
 // them in 85 us, alone on the dependency chain at the very start of a step): stage 1 spreads the rows of a group over FIN_S blocks per
 // channel block and leaves FIN_S double-precision partial rows, stage 2 is the finalize kernel over those.  Fixed order: deterministic.
 constexpr int FIN_S = 32;
-__global__ __launch_bounds__(1024) void bn_partial_reduce_kernel(const float* __restrict__ part, int npg, int C, double* __restrict__ ws) {
+__global__ __launch_bounds__(FIN_T) void bn_partial_reduce_kernel(const float* __restrict__ part, int npg, int C, double* __restrict__ ws) {
     __shared__ double sh[2][FIN_RL][FIN_CL];
     const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
     const int c = blockIdx.x * FIN_CL + cl, sl = blockIdx.y, g = blockIdx.z;
@@ -58,7 +57,7 @@ __global__ __launch_bounds__(1024) void bn_partial_reduce_kernel(const float* __
 }
 
 template <typename TP>
-__global__ __launch_bounds__(1024) void bn_finalize_kernel(const TP* __restrict__ part, int npg, int groups,
+__global__ __launch_bounds__(FIN_T) void bn_finalize_kernel(const TP* __restrict__ part, int npg, int groups,
                                                            int C, double count, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float eps, float mom,
                                                            float* rmean, float* rvar, float* __restrict__ stat) {
@@ -177,7 +176,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
 
 // partials [groups][npg][2][C] -> coef [groups][2][C] = (sum_dzh/count, sum_dzh_xhat/count);
 // dgamma/dbeta (+)= sums over all groups.
-__global__ __launch_bounds__(1024) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
+__global__ __launch_bounds__(FIN_T) void bn_bwd_finalize_kernel(const float* __restrict__ part, int npg, int groups, int C,
                                                                double count, float* coef, float* dgamma, float* dbeta,
                                                                int accum) {
     __shared__ double sh[2][FIN_RL][FIN_CL];
@@ -226,7 +225,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 }
 
 // partial [nblk][2][C] -> dbias (+)=
-__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
+__global__ __launch_bounds__(FIN_T) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
     __shared__ double sh[2][FIN_RL][FIN_CL];
     const int cl = threadIdx.x % FIN_CL, rl = threadIdx.x / FIN_CL;
     const int c = blockIdx.x * FIN_CL + cl;
@@ -491,11 +490,11 @@ extern "C" int pc_bn_finalize_ws(const float* part, int nparts_per_group, int gr
     PC_CHECK_ARG(part && gamma && beta && stat && groups >= 1 && C > 0, "pc_bn_finalize: bad args");
     if (ws && nparts_per_group >= 512) {
         double* w = (double*)(((uintptr_t)ws + 7) & ~(uintptr_t)7);
-        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, FIN_CL), FIN_S, groups), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, C, w);
-        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, (const double*)w, FIN_S, groups, C,
+        hipLaunchKernelGGL(bn_partial_reduce_kernel, dim3(cdiv(C, FIN_CL), FIN_S, groups), dim3(FIN_T), 0, (hipStream_t)s, part, nparts_per_group, C, w);
+        hipLaunchKernelGGL(bn_finalize_kernel<double>, dim3(cdiv(C, FIN_CL)), dim3(FIN_T), 0, (hipStream_t)s, (const double*)w, FIN_S, groups, C,
                            (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
     } else {
-        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+        hipLaunchKernelGGL(bn_finalize_kernel<float>, dim3(cdiv(C, FIN_CL)), dim3(FIN_T), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
                            (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat);
     }
     PC_CHECK_LAUNCH("bn_finalize");
@@ -550,7 +549,7 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg, groups), dim3(256), 0, s, p);
     }
     PC_CHECK_LAUNCH("bn_bwd reduce");
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(FIN_T), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
     const int64_t total4 = rows * (C / 4);
     PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4, 2)), dim3(256), 0, s, dy, lddy, z, ldz, stat, coef, C / 4, total4, rpg, relu, dz, lddz);
@@ -605,7 +604,7 @@ extern "C" int pc_act_bwd(const float* dy, int lddy, const float* y, int ldy, in
         p.rows_per_block = rpb; p.act = act; p.part = ws;
         p.a_gs = p.b_gs = p.stat_gs = p.part_gs = 0;
         hipLaunchKernelGGL(colreduce_kernel<1>, dim3(nblk), dim3(256), 0, s, p);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(1024), 0, s, ws, nblk, C, dbias, accum);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(FIN_T), 0, s, ws, nblk, C, dbias, accum);
     }
     if (dz && (act != PC_ACT_NONE || dz != dy)) {
         PC_CHECK_ARG(lddz % 4 == 0, "pc_act_bwd: lddz");
