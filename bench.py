@@ -219,6 +219,7 @@ class StagedInputs:
             lab, unl, perm, drops, ev = nxt
             torch.cuda.current_stream().wait_event(ev)
             eng.stage(lab, unl, perm, drops)
+            eng.arm_early_adam(lr, on=reducer is None or not reducer.active)
             eng.forward_backward(epoch, ramp, reducer)
             gscale = 1.0
             if reducer is not None:

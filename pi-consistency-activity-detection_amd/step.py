@@ -147,9 +147,20 @@ class StepEngine:
         perm = torch.as_tensor(np.asarray(perm)).long()
         n = self.bs
         per = 3 * spec.FRAMES * self.hw * self.hw
-        data = cat("data")[perm].to(self.dev, torch.float32, non_blocking=True)
-        aug = cat("aug_data")[perm].to(self.dev, torch.float32, non_blocking=True)
-        seg = cat("loc_msk")[perm].to(self.dev, torch.float32, non_blocking=True)
+        from . import inputpipe
+        perm_d = None
+
+        def shuffled(k):          # device-resident samples (inputpipe.get_item) are gathered with a device index: a host index tensor is a blocking upload
+            nonlocal perm_d
+            c = cat(k)
+            if not c.is_cuda:
+                return c[perm]
+            if perm_d is None:
+                perm_d = inputpipe._ring.upload_array(perm.numpy(), c.device)
+            return c[perm_d]
+        data = shuffled("data").to(self.dev, torch.float32, non_blocking=True)
+        aug = shuffled("aug_data").to(self.dev, torch.float32, non_blocking=True)
+        seg = shuffled("loc_msk").to(self.dev, torch.float32, non_blocking=True)
         act_h = cat("action")[perm].reshape(-1).to(torch.float32)
         if self.jhmdb:        # main_jhmdb.py:68-70
             lab = torch.cat([torch.ones(len(label_mb["action"])), torch.zeros(len(unlabel_mb["action"]))])
@@ -157,13 +168,17 @@ class StepEngine:
             lab = cat("label_vid")
         lab_h = lab[perm].to(torch.int32)
         self.labels_host, self.action_host = lab_h.cpu(), act_h.cpu()      # kept from the host inputs (no read-back)
-        act, lab = act_h.to(self.dev), lab_h.to(self.dev)
+        # host-made scalars go up through page-locked staging (inputpipe._PinnedRing): a pageable H2D copy, however small, blocks the host
+        # until everything queued on the stream has run -- i.e. until the PREVIOUS step is over, and the host stops running ahead of the GPU
+        up = lambda t: t.to(self.dev) if t.is_cuda else inputpipe._ring.upload_array(np.ascontiguousarray(t.numpy()), self.dev)
+        act, lab = up(act_h), up(lab_h)
         self.aview(p.in_data, n * per).copy_(data.reshape(-1))
         self.aview(p.in_aug, n * per).copy_(aug.reshape(-1))
         self.aview(p.in_seg, n * per // 3).copy_(seg.reshape(-1))
         self.aview(p.in_cls, 2 * n).copy_(torch.cat([act, act]))
         self.aview(p.in_labeled, 2 * n, torch.int32).copy_(torch.cat([lab, lab]))
-        d = [torch.as_tensor(np.asarray(x), dtype=torch.float32).to(self.dev) for x in drops]
+        d = [x.to(self.dev, torch.float32) if torch.is_tensor(x) and x.is_cuda else up(torch.as_tensor(np.asarray(x.cpu() if torch.is_tensor(x) else x), dtype=torch.float32))
+             for x in drops]
         self.aview(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH).copy_(torch.cat([d[0], d[2]]).reshape(-1))
         self.aview(p.in_drop128, 2 * n * 128).copy_(torch.cat([d[1], d[3]]).reshape(-1))
 
