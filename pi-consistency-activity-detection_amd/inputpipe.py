@@ -68,6 +68,12 @@ class _PinnedRing:
 _ring = _PinnedRing()
 
 
+def pinned_upload(arr, device):
+    """Host numpy array -> device tensor through the page-locked ring, asynchronously on the current stream (StepEngine.stage's per-step
+    scalars: class ids, labeled flags, shuffle index, Dropout3d draws)."""
+    return _ring.upload_array(np.ascontiguousarray(arr), device)
+
+
 def frame_boxes(annotations, n_frames):
     """load_video :204-221: per frame the boxes drawn into `bbox`, plus label, the annotated frame ids and the labeled flag.
     Consumes the draw of :213-214 like the reference."""

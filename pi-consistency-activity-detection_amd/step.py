@@ -156,7 +156,7 @@ class StepEngine:
             if not c.is_cuda:
                 return c[perm]
             if perm_d is None:
-                perm_d = inputpipe._ring.upload_array(perm.numpy(), c.device)
+                perm_d = inputpipe.pinned_upload(perm.numpy(), c.device)
             return c[perm_d]
         data = shuffled("data").to(self.dev, torch.float32, non_blocking=True)
         aug = shuffled("aug_data").to(self.dev, torch.float32, non_blocking=True)
@@ -168,9 +168,9 @@ class StepEngine:
             lab = cat("label_vid")
         lab_h = lab[perm].to(torch.int32)
         self.labels_host, self.action_host = lab_h.cpu(), act_h.cpu()      # kept from the host inputs (no read-back)
-        # host-made scalars go up through page-locked staging (inputpipe._PinnedRing): a pageable H2D copy, however small, blocks the host
+        # host-made scalars go up through page-locked staging (inputpipe.pinned_upload): a pageable H2D copy, however small, blocks the host
         # until everything queued on the stream has run -- i.e. until the PREVIOUS step is over, and the host stops running ahead of the GPU
-        up = lambda t: t.to(self.dev) if t.is_cuda else inputpipe._ring.upload_array(np.ascontiguousarray(t.numpy()), self.dev)
+        up = lambda t: t.to(self.dev) if t.is_cuda else inputpipe.pinned_upload(t.numpy(), self.dev)
         act, lab = up(act_h), up(lab_h)
         self.aview(p.in_data, n * per).copy_(data.reshape(-1))
         self.aview(p.in_aug, n * per).copy_(aug.reshape(-1))
