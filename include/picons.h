@@ -80,7 +80,10 @@ typedef struct pc_conv_desc {
                                        partials never straddle the two forward passes of one step */
 } pc_conv_desc;
 
-/* bnpart: [pc_conv_bnpart_rows(d)][2][Co] partial (sum, sumsq) over output rows, or NULL */
+/* bnpart: [pc_conv_bnpart_rows(d)][2][Co] partial (sum, sumsq) over output rows, or NULL.
+ * Size limit: the LDS-DMA gather addresses `in` and `w` with 32-bit byte offsets from a wave-uniform base, so each must be smaller than
+ * 4 GiB (0xff000000 bytes; PC_E_ARG otherwise -- the largest activation at bs = 8 is 0.8 GB).  Same for D / S of pc_conv_wgrad and for one
+ * (H, W, ldi) frame of pc_wino_conv. */
 int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const float* bias,
                 const float* cscale, float* out, float* bnpart, pc_stream s);
 int pc_conv_bnpart_rows(const pc_conv_desc* d);

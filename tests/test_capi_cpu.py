@@ -77,3 +77,21 @@ def test_host_side_of_the_abi_under_asan_ubsan():
     r = subprocess.run([os.path.join(csrc, "asan", "capi_host_driver")], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "all checks passed" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
     assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_tensors_beyond_the_lds_dma_offset_range_are_refused_without_gpu(built):
+    """The gather kernels address their operands with 32-bit byte offsets from a wave-uniform base (buffer-resource LDS-DMA): a tensor of
+    4 GiB or more is refused by the launcher (host check, before any HIP call) instead of wrapping.  bs = 8 is 0.8 GB at most."""
+    import ctypes as C
+    # conv: 64 samples x 16 frames x 224^2 x 128 channels of fp32 = 26 GB of input
+    d = ops.conv_desc(desc.trim_conv(desc.conv_fwd(64, (16, 224, 224), 128, 128, 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1), (16, 224, 224), groups=2)))
+    rc = built.pc_conv_fwd(C.byref(d), C.c_void_p(16), C.c_void_p(16), None, None, C.c_void_p(16), None, None)
+    assert rc != 0 and b"4 GiB" in built.pc_last_error()
+    # weight gradient of the same layer
+    wd = ops._fill_struct(capi.WgradDesc(), desc.trim_wgrad(desc.wgrad(64, (16, 224, 224), 128, 128, (16, 224, 224), 128, 128, (3, 3, 3), (1, 1, 1), (1, 1, 1))))
+    rc = built.pc_conv_wgrad(C.byref(wd), C.c_void_p(16), C.c_void_p(16), C.c_void_p(16), None)
+    assert rc != 0 and (b"4 GiB" in built.pc_last_error() or b"out of range" in built.pc_last_error())
+    # Winograd: one frame of 4 GiB
+    w = ops.wino_desc(1, 1, 8192, 8192, 32, 32, 64, 64, 3)
+    out = (C.c_double * 3)()
+    assert built.pc_wino_work(C.byref(w), out) != 0 and b"plane too large" in built.pc_last_error()
