@@ -49,6 +49,9 @@ typedef void* pc_stream;            /* hipStream_t */
 #define PC_F_CI3     64             /* Ci == 4 whose 4th channel is padding (the RGB clip, 3 channels in 16-byte pieces): that
                                      * channel is taken as zero whatever it holds; the LDS-DMA stem kernel skips its MFMAs */
 
+#define PC_F_X6      128            /* the launch multiplies on the bf16 matrix cores: fp32 operands as exact sums of three bf16 values, six
+                                     * products, fp32 accumulate (pc_conv_fwd_x6; the caller holds the weights as bf16 planes) */
+
 int         pc_version(void);
 const char* pc_last_error(void);
 
@@ -87,6 +90,19 @@ typedef struct pc_conv_desc {
 int pc_conv_fwd(const pc_conv_desc* d, const float* in, const float* w, const float* bias,
                 const float* cscale, float* out, float* bnpart, pc_stream s);
 int pc_conv_bnpart_rows(const pc_conv_desc* d);
+
+/* The same convolution with the fp32 multiplications carried out on the bf16 matrix cores (csrc/conv_x6.hip): every fp32 operand is split
+ * exactly into three bf16 values h + m + l and the six products of weight >= 2^-16 are accumulated in fp32 -- closer to an fp64 result than
+ * an fp32 FMA chain (tests/test_x6_gpu.py), 1.5 - 1.8x the rate of v_mfma_f32_32x32x2_f32.  `in` stays fp32 (split in registers); the weights
+ * come as three bf16 planes, each in the layout of `w` above ([Co][KT*KH*KW][ldw], group g at + g * wgstride elements), plane p at
+ * wplanes + p * plane_stride elements -- pc_split_planes makes them from the fp32 layout.  d->flags must carry PC_F_X6 and
+ * pc_conv_x6_ok(d) must hold (Ci % 32 == 0, ldw % 8 == 0, <= 10 taps per dimension); everything else as pc_conv_fwd. */
+int pc_conv_fwd_x6(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
+                   const float* cscale, float* out, float* bnpart, pc_stream s);
+int pc_conv_x6_ok(const pc_conv_desc* d);       /* host-only: 1 if the descriptor (with PC_F_X6) takes the bf16-split kernel */
+/* planes[p * plane_stride + i] = p-th bf16 term of src[i] (p = 0, 1, 2: h = bf16(x), m = bf16(x - h), l = x - h - m, round to nearest; h + m + l == src[i] exactly for 2^-110 <= |x| < 2^128);
+ * n and plane_stride multiples of 4 */
+int pc_split_planes(const float* src, uint16_t* planes, int64_t n, int64_t plane_stride, pc_stream s);
 /* Host-only work accounting of one pc_conv_fwd launch (no GPU call; measurement support for bench.py / tools/launch_table.py,
  * no reference counterpart).  Walks the launch's tiles in the kernel's own row order and counts the K loop each block really
  * runs (taps that are padding for every row of a tile are skipped by the kernel).  out[7]:
@@ -451,6 +467,8 @@ enum {
     PC_OP_WGRAD_MULTI,              /* p[0] = HOST pointer to pc_wgrad_job[i[0]] (kept alive by the owner of the list): pc_conv_wgrad_multi */
     PC_OP_WINO_CONV,                /* i[0..11] = pc_wino_desc; p = in, U, bias, out, bnpart */
     PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip; l = sO, sT, sI; p = w, U */
+    PC_OP_CONV_X6,                  /* i = pc_conv_desc (flags with PC_F_X6); l[0] = plane stride; p = in, wplanes, bias, cscale, out, bnpart */
+    PC_OP_SPLIT_PLANES,             /* l = n, plane stride; p = src, planes */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

@@ -52,7 +52,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
  OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS) = range(1, 45)
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS, OP_CONV_X6, OP_SPLIT_PLANES) = range(1, 47)
 MAX_LANES = 8
 
 # numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 42 int32, then D, S, g)
@@ -63,7 +63,7 @@ TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64)
                        ("C", np.int32), ("sld", np.int32), ("dld", np.int32), ("accum", np.int32)], align=False)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3 = 1, 2, 4, 8, 16, 32, 64
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6 = 1, 2, 4, 8, 16, 32, 64, 128
 WG_CS3 = 1
 
 _SIGS = {
@@ -71,6 +71,9 @@ _SIGS = {
     "pc_last_error": (C.c_char_p, []),
     "pc_conv_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "pc_conv_bnpart_rows": (i32, [C.POINTER(ConvDesc)]),
+    "pc_conv_fwd_x6": (i32, [C.POINTER(ConvDesc), vp, vp, i64, vp, vp, vp, vp, vp]),
+    "pc_conv_x6_ok": (i32, [C.POINTER(ConvDesc)]),
+    "pc_split_planes": (i32, [vp, vp, i64, i64, vp]),
     "pc_conv_work": (i32, [C.POINTER(ConvDesc), i32, i32, C.POINTER(C.c_double)]),
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
     "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),

@@ -3,100 +3,13 @@
 // (TF-SAME padding folded into the gather), conv dgrad, ConvTranspose forward as sub-pixel
 // parity classes and ConvTranspose dgrad; a second form computes weight gradients.
 // Replaces the ATen/cuDNN convolution call sites listed in SURVEY.md §2a (K1, K6, K9-K12).
-#include "common.h"
+#include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>
 #include <algorithm>
 #include <vector>
 
 namespace {
-
-constexpr int F_SCALAR_EPI = 1 << 29;     // internal flag (PICONS_CONV_SCALAR_EPI=1): 4-byte stores straight from the accumulators
-
-struct ConvK {
-    const float* in; const float* w; const float* bias; const float* cscale; float* out; float* bnpart;
-    int N, Ti, Hi, Wi, Ci, ldi;
-    int Tq, Hq, Wq, To, Ho, Wo, Co, ldo;
-    int ostr[3], ooff[3], istr[3], ntap[3], ioff0[3], istep[3], wk0[3], wkstep[3];
-    int KH, KW, wtaps, ldw;
-    int K, M, Mg, groups, mtiles_g, ntiles;
-    int act, flags, act_c0, wgstride, bgstride;
-};
-
-constexpr int BK = 32;       // K chunk (floats)
-constexpr int CONV_DEFAULT_VARIANT = 0;
-constexpr int LDK = 36;      // padded LDS row (floats): conflict-free ds_read_b128 (9i mod 16 distinct)
-
-// Output tile through LDS (the operand buffers are free once the K loop has ended on a barrier) so that every lane stores
-// 16 bytes of one row and a wave covers whole 128..512-byte row segments.  The accumulator layout (one column, 16 rows
-// per lane) gives 4-byte stores, 64 per thread, whose drain is NOT hidden behind the other resident block's MFMAs
-// (0.10 ms of the 0.31 ms K = 128 tail GEMM).  Needs 4-column granularity of the output; returns false otherwise.
-template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ bool store_tile_rows(const f32x16 (&acc)[TM][TN], float* T, const int* rout, const int* rinfo, const ConvK& p,
-                                                const float* bbase, int n0, int wm, int wn, int lane, int tid) {
-    const bool has_bias = p.flags & PC_F_BIAS, has_cs = p.flags & PC_F_CSCALE, accum = p.flags & PC_F_ACCUM;
-    if (!(((p.Co | p.ldo) & 3) == 0 && ((uintptr_t)p.out & 15) == 0 && !(p.flags & F_SCALAR_EPI) && (!has_bias || ((uintptr_t)bbase & 15) == 0) &&
-          (!has_cs || ((uintptr_t)p.cscale & 15) == 0)))
-        return false;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
-        }
-    __syncthreads();
-    for (int e = tid; e < BM * BN / 4; e += 256) {
-        const int row = e / (BN / 4), c4 = e % (BN / 4);
-        const int op = rout[row], col = n0 + c4 * 4;
-        if (op < 0 || col >= p.Co) continue;
-        f32x4 v = *(const f32x4*)(T + row * BN + c4 * 4);
-        if (has_bias) v += *(const f32x4*)(bbase + col);
-        if (p.act != PC_ACT_NONE) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (col + q >= p.act_c0) {
-                    if (p.act == PC_ACT_RELU) v[q] = fmaxf(v[q], 0.f);
-                    else if (p.act == PC_ACT_SIGMOID) v[q] = 1.0f / (1.0f + expf(-v[q]));
-                }
-        }
-        if (has_cs) v *= *(const f32x4*)(p.cscale + (size_t)rinfo[row * 4] * p.Co + col);
-        float* o = p.out + (size_t)op * p.ldo + col;
-        if (accum) v += *(const f32x4*)o;
-        *(f32x4*)o = v;
-    }
-    return true;
-}
-
-// Channel-major output (PC_F_TOUT): the tile goes through LDS like store_tile_rows, but is read back column by column so that
-// a wave writes 64 consecutive positions of ONE output channel (256 contiguous bytes where the tile's rows are consecutive
-// positions).  The 16-byte column groups of a row are XOR-ed with the row so both the accumulator-layout writes (32 consecutive
-// columns of one row per half-wave) and the column reads (32 consecutive rows of one column) hit distinct banks.
-template <int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ __forceinline__ void store_tile_cols(const f32x16 (&acc)[TM][TN], float* T, const int* rout, const int* rinfo, const ConvK& p,
-                                                int n0, int wm, int wn, int lane, int tid) {
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = wn * (BN / WN) + j * 32 + (lane & 31);
-                T[row * BN + (col ^ (row & 31))] = acc[i][j][r];
-            }
-        }
-    __syncthreads();
-    const size_t P3 = (size_t)p.To * p.Ho * p.Wo;
-    for (int e = tid; e < BM * BN; e += 256) {
-        const int col = e / BM, row = e % BM;
-        const int op = rout[row];
-        if (op < 0 || n0 + col >= p.Co) continue;
-        const size_t n = (size_t)rinfo[row * 4];
-        p.out[(n * p.ldo + n0 + col) * P3 + ((size_t)op - n * P3)] = T[row * BN + (col ^ (row & 31))];
-    }
-}
 
 template <int BM, int BN, int WM, int WN, bool FAST, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
@@ -300,26 +213,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvK p) {
 // the SOURCE address (LDS-DMA writes lane-linear) and again on the fragment read, which keeps ds_read_b128
 // conflict-free for both 16-lane groups.
 __device__ __attribute__((aligned(16))) float g_zero16[4] = {0.f, 0.f, 0.f, 0.f};
-
-__device__ __forceinline__ void glds16(const float* g, float* l) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)l, 16, 0, 0);
-}
-
-// The same 1 KiB LDS-DMA piece through a raw buffer resource: wave-uniform base (SGPRs, rebuilt per K chunk with scalar adds) + one
-// 32-bit byte offset per lane.  Measured beside the MFMA stream (tools/mfma_peak_probe.hip, PROBE_DMA=1): a piece with 64-bit per-lane
-// addresses costs ~60 cycles of matrix-pipe time (the address VGPR pairs and the 64-bit adds that make them), this form ~24.  A lane
-// whose offset is DMA_OOB lies outside the resource: the hardware writes ZEROS into its LDS slot (tools/dma_oob_probe.hip), so padding
-// taps need no zero line and no address select.  Tensors addressed this way must be smaller than 4 GiB (checked by the launchers).
-constexpr unsigned DMA_OOB = 0xffffffffu;
-constexpr long long DMA_MAX_BYTES = 0xff000000ll;
-typedef __amdgpu_buffer_rsrc_t dma_rsrc_t;
-__device__ __forceinline__ dma_rsrc_t dma_rsrc(const float* base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffff00u, 0x00020000);
-}
-__device__ __forceinline__ void glds16b(dma_rsrc_t rs, unsigned voff, float* l) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
-}
 
 template <int BM, int BN, int WM, int WN, int VAR = 0>
 __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
@@ -734,14 +627,16 @@ extern "C" int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, dou
     const int groups = d->groups > 0 ? d->groups : 1;
     PC_CHECK_ARG(d->N % groups == 0, "pc_conv_work: N %% groups");
     const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
-    const TileCfg c = launch_tile(d, groups);
+    TileCfg c = launch_tile(d, groups);
+    const bool x6 = pc_x6_eligible(d);                   // PC_F_X6: the bf16-split kernel's tiles (conv_x6.hip), always with the tap box
+    if (x6) { const X6Tile t = pc_x6_tile(d, groups); c.bm = t.bm; c.bn = t.bn; c.wm = t.wm; }
     if (ci_real <= 0) ci_real = d->Ci;
     if (co_real <= 0) co_real = d->Co;
     const bool small_taps = d->ntap[0] <= 10 && d->ntap[1] <= 10 && d->ntap[2] <= 10;
     static const int no_glds = getenv("PICONS_CONV_NO_GLDS") ? atoi(getenv("PICONS_CONV_NO_GLDS")) : 0;
     static const int no_tap4 = getenv("PICONS_CONV_NO_TAP4") ? atoi(getenv("PICONS_CONV_NO_TAP4")) : 0;
-    const bool tap4 = c.bm == 128 && c.bn == 64 && d->Ci == 4 && !no_glds && !no_tap4 && small_taps;
-    const bool glds = tap4 || (d->Ci % BK == 0 && !no_glds && small_taps);
+    const bool tap4 = !x6 && c.bm == 128 && c.bn == 64 && d->Ci == 4 && !no_glds && !no_tap4 && small_taps;
+    const bool glds = x6 || tap4 || (d->Ci % BK == 0 && !no_glds && small_taps);
     const int64_t mtiles = cdiv(Mg, c.bm), ntiles = cdiv(d->Co, c.bn);
     const int ng = d->N / groups;
     const int I[3] = {d->Ti, d->Hi, d->Wi};
@@ -797,6 +692,7 @@ extern "C" int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, dou
 extern "C" int pc_conv_bnpart_rows(const pc_conv_desc* d) {
     const int groups = d->groups > 0 ? d->groups : 1;
     const int64_t Mg = (int64_t)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    if (pc_x6_eligible(d)) { const X6Tile t = pc_x6_tile(d, groups); return groups * cdiv(Mg, t.bm) * t.wm; }
     const TileCfg c = choose_tile((int)Mg, groups, d->Co, d->Ci);
     return groups * cdiv(Mg, c.bm) * c.wm;
 }
@@ -804,6 +700,7 @@ extern "C" int pc_conv_bnpart_rows(const pc_conv_desc* d) {
 static int pc_conv_fwd_g(const pc_conv_desc* d, int groups, const float* in, const float* w, const float* bias,
                   const float* cscale, float* out, float* bnpart, hipStream_t s) {
     PC_CHECK_ARG(d && in && w && out, "pc_conv_fwd: null pointer");
+    PC_CHECK_ARG(!(d->flags & PC_F_X6), "pc_conv_fwd: PC_F_X6 descriptors go to pc_conv_fwd_x6 (weight planes)");
     PC_CHECK_ARG(d->Ci % 4 == 0 && d->ldi % 4 == 0 && d->ldw % 4 == 0, "pc_conv_fwd: Ci/ldi/ldw must be multiples of 4 (Ci=%d ldi=%d ldw=%d)", d->Ci, d->ldi, d->ldw);
     PC_CHECK_ARG(groups >= 1 && d->N % groups == 0, "pc_conv_fwd: N %% groups");
     PC_CHECK_ARG(!(d->flags & PC_F_BIAS) || bias, "pc_conv_fwd: bias flag without pointer");

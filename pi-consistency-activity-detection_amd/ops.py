@@ -44,6 +44,22 @@ def conv_fwd(d, x, w, out, bias=None, cscale=None, bnpart=None):
     return out
 
 
+def split_planes(w):
+    """fp32 device tensor (numel % 4 == 0) -> int16 tensor [3][numel]: the bf16 terms h, m, l of every element (pc_split_planes)."""
+    n = w.numel()
+    planes = torch.empty(3, n, device=w.device, dtype=torch.int16)
+    capi.call("pc_split_planes", ptr(w), ptr(planes), n, n, stream())
+    return planes
+
+
+def conv_fwd_x6(d, x, wplanes, out, bias=None, cscale=None, bnpart=None):
+    """pc_conv_fwd_x6: d as for conv_fwd (PC_F_X6 is added here), wplanes = split_planes(w) of the [Co][taps][ldw] weights."""
+    dd = dict(d)
+    dd["flags"] = int(dd.get("flags", 0)) | capi.F_X6
+    capi.call("pc_conv_fwd_x6", C.byref(conv_desc(dd)), ptr(x), ptr(wplanes), wplanes.shape[1], ptr(bias), ptr(cscale), ptr(out), ptr(bnpart), stream())
+    return out
+
+
 def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0, Ti=None, ta=1, tc=None, tden=1):
     """pc_wino_desc; defaults = temporal stride 1 with padding KT // 2 (see include/picons.h for (ta, tc, tden))."""
     st = capi.WinoDesc()
