@@ -14,9 +14,10 @@ when the box has fewer than N GPUs): the launcher's own test, runnable without G
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
 the fp32-MFMA gather-GEMM conv kernel, timed with hipEvents on the launch stream) and `cpu_baseline`
 (the CPU oracle = plain-PyTorch port of the reference, timed on this host's cores on a bounded sample).
-`value` is measured with the minibatch resident in HBM (contract); `staged` in the same line is the same step with every
-step's minibatch prepared from host uint8 frames by the device input pipeline (upload + crop / flip / mask kernels + the
-reference's cat / shuffle), overlapped with the previous step (main_ucf101.py:52-79 inside the timed region).
+`value` is the step as SURVEY.md 8(d) defines it, i.e. WITH the per-step input work of main_ucf101.py:52-79 inside the timed region
+(every step's minibatch prepared from host uint8 frames by the device input pipeline and staged -- cat / shuffle -- into the arena, the
+next step's samples on a side stream); `resident` / `value_resident` is the same step on a minibatch already in HBM, `dict_contract`
+the same step fed the reference's float64 host dicts, `split_off` the step with PICONS_SPLIT=0 (all convolutions on fp32 MFMA).
 """
 import argparse
 import json
@@ -208,19 +209,26 @@ class StagedInputs:
         drops = [(torch.rand(n, c, generator=self.g) < 0.5).float().numpy() * 2 for c in (832, 128, 832, 128)]
         return lab, unl, perm, drops, ev
 
-    def run(self, steps, epoch, ramp, reducer, lr):
-        """`steps` full steps, each on a fresh minibatch; returns (seconds, last losses)."""
+    def run(self, steps, epoch, ramp, reducer, lr, timed_kind=None, time_every=0):
+        """`steps` full steps, each on a fresh minibatch; returns (seconds, last losses, steps that carried kernel-timing events)."""
         eng = self.eng
         nxt = self.prep(0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        out = None
+        out, ntimed = None, 0
+        main = torch.cuda.current_stream()
         for i in range(steps):
             lab, unl, perm, drops, ev = nxt
-            torch.cuda.current_stream().wait_event(ev)
+            main.wait_event(ev)
+            for d_ in (lab, unl):            # the samples were made on the side stream and are read here: keep the allocator from handing
+                for t in d_.values():        # their blocks back to that stream while this stream still reads them (ADVICE r3)
+                    if torch.is_tensor(t) and t.is_cuda:
+                        t.record_stream(main)
             eng.stage(lab, unl, perm, drops)
-            eng.arm_early_adam(lr, on=reducer is None or not reducer.active)
-            eng.forward_backward(epoch, ramp, reducer)
+            tk = timed_kind if (timed_kind is not None and time_every and i % time_every == 0) else None
+            ntimed += tk is not None
+            eng.arm_early_adam(lr, on=(reducer is None or not reducer.active) and tk is None)
+            eng.forward_backward(epoch, ramp, reducer, timed_kind=tk)
             gscale = 1.0
             if reducer is not None:
                 reducer.wait()
@@ -229,13 +237,56 @@ class StagedInputs:
             nxt = self.prep(i + 1)            # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above
             out = eng.read_scalars()
         torch.cuda.synchronize()
-        return time.perf_counter() - t0, out
+        return time.perf_counter() - t0, out, ntimed
+
+
+class DictInputs:
+    """The reference's minibatch contract as the DataLoader hands it over (main_ucf101.py:52-79; datasets/ucf_dataloader.py:179-191:
+    pageable float64 host tensors, 180 MB per bs-8 step) inside the timed region, through StepEngine.host_stager(): page-locked double
+    buffer, uploads on a copy stream one step ahead, f64 -> f32 on the device."""
+
+    def __init__(self, eng, bs, ncls, rank, nmb=3):
+        from picons_amd import synthetic
+        self.eng, self.st = eng, eng.host_stager()
+        self.mbs = []
+        for i in range(nmb):
+            lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=rank, step=100 + i, num_classes=ncls)
+            self.mbs.append(({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in lab.items()},
+                             {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in unl.items()}, perm, drops))
+
+    def run(self, steps, epoch, ramp, reducer, lr):
+        eng, st = self.eng, self.st
+        st.prepare(0, *self.mbs[0])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out, host_wait = None, 0.0
+        for i in range(steps):
+            slot = i & 1
+            st.commit(slot)
+            eng.arm_early_adam(lr, on=reducer is None or not reducer.active)
+            eng.forward_backward(epoch, ramp, reducer)
+            gscale = 1.0
+            if reducer is not None:
+                reducer.wait()
+                gscale = reducer.gscale
+            eng.adam(lr, gscale)
+            st.release(slot)
+            st.prepare(slot ^ 1, *self.mbs[(i + 1) % len(self.mbs)])      # the host's 180 MB gather + the uploads run under the step enqueued above
+            tw = time.perf_counter()
+            out = eng.read_scalars()
+            host_wait += time.perf_counter() - tw
+        torch.cuda.synchronize()
+        eng._restore_input_ops()
+        return time.perf_counter() - t0, out, host_wait
+
+
+PEAK_BF16_MFMA_TFLOPS = 2500.0       # MI355X_MICROARCH.md: dense bf16 MFMA peak; a bf16-split fp32 product costs six of them
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)       # >= 20 timed steps after >= 5 warm-up; 200 x 30 ms
+    ap.add_argument("--steps", type=int, default=200)       # SURVEY.md §8(d): >= 20 timed steps after >= 5 warm-up; 200 x 21 ms
                                                             # keeps the GPU busy long enough for an external sampler to see it
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--bs", type=int, default=8)
@@ -243,11 +294,13 @@ def main():
     ap.add_argument("--jhmdb", action="store_true", help="BASELINE config 5's shape: 21 classes, main_jhmdb.py's step")
     ap.add_argument("--epoch", type=int, default=1, help="epoch the step runs at (>= 11 = --thresh_epoch: argmax pseudo-labels "
                     "for the unlabeled rows, capsules_ucf101.py:463)")
-    ap.add_argument("--time-every", type=int, default=40, help="attach hipEvent pairs to the conv kernels of every n-th timed step")
+    ap.add_argument("--time-every", type=int, default=40, help="attach hipEvent pairs to the dominant conv kernel's launches of every n-th timed step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--resident-inputs", action="store_true", help="skip the `staged` leg (every step's minibatch prepared from host uint8 frames)")
-    ap.add_argument("--staged-steps", type=int, default=0, help="timed steps of the `staged` leg (default: min(steps, 50))")
+    ap.add_argument("--resident-inputs", action="store_true", help="time the step with the minibatch resident in HBM ONLY (no per-step input staging: "
+                    "`value` is then the resident figure and says so)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the dict_contract / split_off legs and the busy phase")
+    ap.add_argument("--leg-steps", type=int, default=0, help="timed steps of the secondary legs (default: min(steps, 50))")
     ap.add_argument("--dry-launch", action="store_true", help="ranks only rendezvous + all-reduce ones (launcher test; no GPU work)")
     ap.add_argument("--dry-backend", default="auto", choices=["auto", "gloo", "nccl"])
     ap.add_argument("--launch-timeout", type=float, default=0.0, help="seconds after which the launcher stops its ranks (0 = never)")
@@ -280,12 +333,14 @@ def main():
     rank, world, local = pdist.init_from_env()
     dev = "cuda:%d" % local
     torch.cuda.set_device(local)
+    t_gpu0 = time.perf_counter()
 
     args = pstep.default_args(bv=not a.gv, gv=a.gv, n_frames=5, wt_cons=0.1, lr=1e-4, epochs=100, thresh_epoch=11)
     ncls = 21 if a.jhmdb else 24
     eng = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=ncls, jhmdb=a.jhmdb, device=dev)
+    split_on = bool(eng.plan.x6)
     lab, unl, perm, drops = synthetic.make_step_inputs(a.bs, rank=rank, step=0, num_classes=ncls)
-    eng.stage(lab, unl, perm, drops)                     # inputs resident in HBM before the timed region
+    eng.stage(lab, unl, perm, drops)
     # PICONS_FORCE_REDUCER=1 on one GPU: a one-rank RCCL group and the whole DP schedule (segmented backward, bucket all-reduces on
     # the comm stream behind events, 1/world in Adam) -- the N > 1 code path executed through RCCL where only one GPU exists
     forced = world == 1 and os.environ.get("PICONS_FORCE_REDUCER", "0") == "1"
@@ -294,7 +349,7 @@ def main():
         torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     reducer = eng.make_reducer(force=forced) if (world > 1 or forced) else None
     ramp = pstep.exp_rampup(100)(a.epoch)
-    kind = None if a.no_kernel_timing else capi.OP_CONV
+    main_kind = None if a.no_kernel_timing else (capi.OP_CONV_X6 if split_on else capi.OP_CONV)
     ranks_observed = 1
     if world > 1 or forced:                              # an all-reduce of ones: the rank count the collective really spans
         ones = torch.ones(1, device=dev)
@@ -303,143 +358,209 @@ def main():
     if ranks_observed != world:
         print("bench.py: the collective spans %d ranks, WORLD_SIZE is %d" % (ranks_observed, world), file=sys.stderr)
         sys.exit(4)
+    staged_ok = not a.resident_inputs and a.bs % 2 == 0 and not a.jhmdb
 
+    def timed_resident(e, steps, kind=None, every=0, red=None):
+        """`steps` steps on the minibatch resident in HBM, bracketed as the contract says; -> (ms over all ranks' max, last losses, timed steps)."""
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        last, nt = None, 0
+        for it in range(steps):
+            tk = kind if (kind is not None and every and it % every == 0) else None
+            nt += tk is not None
+            last = e.run_staged(a.epoch, ramp, reducer=red, timed_kind=tk, collect=False)
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        return pdist.barrier_max_ms((time.perf_counter() - t0) * 1e3, device=dev), last, nt
+
+    # ---- warm-up, then the HEADLINE leg: exactly `steps` steps between barriers + synchronize.  The step is SURVEY 8(d)'s: zero_grad ->
+    # a1 .. Adam -> loss read-back, and a1 starts with the per-step input work (main_ucf101.py:52-79), so the minibatch is staged inside
+    # the timed region (fresh samples every step from host uint8 frames through the device input pipeline, the next step's on a side stream)
     for _ in range(a.warmup):
         eng.run_staged(a.epoch, ramp, reducer=reducer)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
     eng.kind_ms, eng.kind_count = 0.0, 0
-    t0 = time.perf_counter()
-    last = None
     timed_steps = 0
-    for it in range(a.steps):
-        tk = kind if (kind is not None and it % max(1, a.time_every) == 0) else None
-        timed_steps += tk is not None
-        last = eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=tk, collect=False)   # events recorded here, read below
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    ms_local = (time.perf_counter() - t0) * 1e3
-    if kind is not None:
+    if staged_ok:
+        si = StagedInputs(eng, a.bs, ncls, rank)
+        si.run(min(3, a.steps), a.epoch, ramp, reducer, args.lr)                      # warm-up (pinned buffers, first uploads)
+        if world > 1:
+            torch.distributed.barrier()
+        sec, last, timed_steps = si.run(a.steps, a.epoch, ramp, reducer, args.lr, timed_kind=main_kind, time_every=max(1, a.time_every))
+        if world > 1:
+            torch.distributed.barrier()
+        ms_total = pdist.barrier_max_ms(sec * 1e3, device=dev)
+        inputs_note = ("staged inside the timed region: every step prepares a fresh minibatch from host uint8 frames (upload of the 8 selected frames per sample, "
+                       "pc_clip_from_u8, cat + shuffle into the arena; the next step's samples on a side stream) -- main_ucf101.py:52-79 is part of the step")
+    else:
+        ms_total, last, timed_steps = timed_resident(eng, a.steps, main_kind, max(1, a.time_every), reducer)
+        inputs_note = "resident in HBM before the timed region (--resident-inputs / --jhmdb: no per-step input staging in this run)"
+    if main_kind is not None:
         eng.collect_timing()
-    ms_total = pdist.barrier_max_ms(ms_local, device=dev)
     ms_step = ms_total / a.steps
     value = world * a.bs * a.steps / (ms_total / 1e3)
+    main_ms, main_count = eng.kind_ms, eng.kind_count
 
-    # ---- the second GEMM family, the Winograd conv kernel: its launches get hipEvent pairs in two extra single-stream steps (outside the
-    # timed region above, whose event legs belong to the gather-GEMM family: one op kind per timed replay)
-    conv_kind_ms, conv_kind_count = eng.kind_ms, eng.kind_count
-    wino_ms = wino_count = wino_steps = 0
-    if kind is not None:
+    n_leg = a.leg_steps or min(a.steps, 50)
+    # ---- the same step on the minibatch already resident in HBM (what rounds 1-3 quoted as `value`)
+    resident = None
+    if staged_ok:
+        eng.stage(lab, unl, perm, drops)
+        ms_r, last_r, _ = timed_resident(eng, n_leg, red=reducer)
+        resident = {"value": world * a.bs * n_leg / (ms_r / 1e3), "unit": "clips/s", "ms_per_step": ms_r / n_leg, "steps": n_leg, "loss_total": last_r["total"]}
+
+    # ---- the other GEMM families' kernels get their event pairs in two extra single-stream steps each (one op kind per timed replay)
+    def kind_leg(kind):
         eng.kind_ms, eng.kind_count = 0.0, 0
         for _ in range(2):
-            eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=capi.OP_WINO_CONV, collect=False)
-            wino_steps += 1
+            eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=kind, collect=False)
         torch.cuda.synchronize()
         eng.collect_timing()
-        wino_ms, wino_count = eng.kind_ms, eng.kind_count
-        eng.kind_ms, eng.kind_count = conv_kind_ms, conv_kind_count
+        return eng.kind_ms / 2, eng.kind_count // 2
+    wino_ms = wino_count = f32c_ms = f32c_count = 0
+    if main_kind is not None:
+        eng.stage(lab, unl, perm, drops)
+        wino_ms, wino_count = kind_leg(capi.OP_WINO_CONV)
+        if split_on:
+            f32c_ms, f32c_count = kind_leg(capi.OP_CONV)
 
-    # ---- the same step with the reference's per-step input work inside the timed region (every rank, same barrier / max rule)
-    staged = None
-    if not a.resident_inputs and a.bs % 2 == 0 and not a.jhmdb:
-        n_st = a.staged_steps or min(a.steps, 50)
-        si = StagedInputs(eng, a.bs, ncls, rank)
-        si.run(min(3, n_st), a.epoch, ramp, reducer, args.lr)                      # warm-up (pinned buffers, first uploads)
+    # ---- the reference's own minibatch contract inside the timed region: float64 host dicts -> pinned double buffer -> copy stream
+    dict_leg = None
+    if staged_ok and not a.no_extra_legs:
+        di = DictInputs(eng, a.bs, ncls, rank)
+        di.run(3, a.epoch, ramp, reducer, args.lr)
         if world > 1:
             torch.distributed.barrier()
-        sec, last_st = si.run(n_st, a.epoch, ramp, reducer, args.lr)
-        if world > 1:
-            torch.distributed.barrier()
-        ms_st = pdist.barrier_max_ms(sec * 1e3, device=dev)
-        staged = {"value": world * a.bs * n_st / (ms_st / 1e3), "unit": "clips/s", "ms_per_step": ms_st / n_st, "steps": n_st,
-                  "loss_total": last_st["total"],
-                  "what": "every step stages a fresh minibatch from host uint8 frames: upload of the 8 selected frames per sample, "
-                          "pc_clip_from_u8 (crop / flip / mask / normalise on the device), cat + shuffle into the arena; the next step's "
-                          "samples are prepared on a side stream while the current step runs (main_ucf101.py:52-79 inside the metric)"}
+        sec, last_d, host_wait = di.run(n_leg, a.epoch, ramp, reducer, args.lr)
+        ms_d = pdist.barrier_max_ms(sec * 1e3, device=dev)
+        dict_leg = {"value": world * a.bs * n_leg / (ms_d / 1e3), "unit": "clips/s", "ms_per_step": ms_d / n_leg, "steps": n_leg, "loss_total": last_d["total"],
+                    "host_wait_ms_per_step": host_wait * 1e3 / n_leg,
+                    "what": "the reference's minibatch contract (main_ucf101.py:52-79, datasets/ucf_dataloader.py:179-191): two dicts of pageable float64 host tensors "
+                            "per step (180 MB), gathered in shuffled order into a page-locked double buffer, uploaded on a copy stream one step ahead, "
+                            "f64 -> f32 on the device (pc_ncdhw_to_ndhwc reads the float64 staging); host_wait = time the host spends in read_scalars()"}
 
-    fl = eng.plan.flops()                                # FLOPs of the emitted (tap-trimmed) descriptors, real channel counts
-    fe = eng.plan.conv_flops_executed()                  # conv / dgrad FLOPs as the kernels run them (host walk of every launch's tiles)
-    fw = eng.plan.wgrad_flops_executed()
-    fc = eng.plan.flops(capi.OP_CONV)
-    fr = eng.plan.flops_reference_counted()
+    # ---- the same engine with every convolution on the fp32 MFMA kernels (PICONS_SPLIT=0), minibatch resident: what the bf16-split conv kernel buys
+    split_off = None
+    if split_on and not a.no_extra_legs and reducer is None:
+        os.environ["PICONS_SPLIT"] = "0"
+        try:
+            eng0 = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=ncls, jhmdb=a.jhmdb, device=dev)
+        finally:
+            os.environ["PICONS_SPLIT"] = "1"
+        eng0.stage(lab, unl, perm, drops)
+        for _ in range(3):
+            eng0.run_staged(a.epoch, ramp)
+        ms0, last0, _ = timed_resident(eng0, n_leg)
+        split_off = {"value": world * a.bs * n_leg / (ms0 / 1e3), "unit": "clips/s", "ms_per_step": ms0 / n_leg, "steps": n_leg, "loss_total": last0["total"],
+                     "what": "PICONS_SPLIT=0: every conv / dgrad launch on v_mfma_f32_32x32x2_f32 (the round-3 kernels), minibatch resident in HBM -- compare with `resident`"}
+        del eng0
+        torch.cuda.empty_cache()
+
+    # ---- keep the GPU visibly busy for an external sampler: at least 3 s of back-to-back steps in this process, outside every timed region
+    busy_steps = 0
+    if not a.no_extra_legs:
+        eng.stage(lab, unl, perm, drops)
+        while time.perf_counter() - t_gpu0 < 3.0 or busy_steps < 20:
+            eng.run_staged(a.epoch, ramp, reducer=reducer)
+            busy_steps += 1
+            if busy_steps >= 400:
+                break
+        torch.cuda.synchronize()
+
+    pl = eng.plan
+    fl = pl.flops()                                      # FLOPs of the emitted (tap-trimmed) descriptors, real channel counts
+    fe = pl.conv_flops_executed()                        # fp32-MFMA conv / dgrad FLOPs as the kernels run them (host walk of every launch's tiles)
+    fx = pl.x6_flops_executed()                          # the same for the launches on the bf16-split kernel
+    fw = pl.wgrad_flops_executed()
+    fz = pl.wino_flops_executed()                        # the Winograd launches: transform-domain FLOPs (2.25x fewer than the direct form's)
+    fr = pl.flops_reference_counted()
     lists = ("fwd", "bwd")
-    conv_exec = sum(fe[n]["executed"] for n in lists)
-    conv_mfma = sum(fe[n]["mfma"] for n in lists)
-    conv_valid = sum(fe[n]["valid"] for n in lists)
-    conv_desc = sum(fc[n] for n in lists)                # 2*M*N*K of the trimmed descriptors: round 2's numerator (over-books: the kernel
-                                                         # skips, per tile, every tap that is padding for the whole tile)
-    conv_ref = sum(fr[n] for n in lists)                 # all taps incl. zero padding, dgrad at its layer's forward FLOPs
-    fz = eng.plan.wino_flops_executed()                  # the Winograd launches: transform-domain FLOPs (2.25x fewer than the direct form's)
-    wino_exec = sum(fz[n]["executed"] for n in lists)
-    step_exec = conv_exec + wino_exec + sum(fw[n]["executed"] for n in lists)
-    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc
-    # FETCH_SIZE / WRITE_SIZE in their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run, so this
-    # is OFFLINE data from the named file, not a measurement of this run
+    tot = lambda f, k: sum(f[n][k] for n in lists)
+    conv_exec, x6_exec, wino_exec, wg_exec = tot(fe, "executed"), tot(fx, "executed"), tot(fz, "executed"), tot(fw, "executed")
+    step_exec = conv_exec + x6_exec + wino_exec + wg_exec
+    # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
+    # their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run, so this is OFFLINE data from the named file
     traffic, traffic_src = None, None
-    for tag in ("r03", "r02", "r01"):
+    tkey = "conv_x6_hbm_bytes_per_launch" if split_on else "conv_gemm_hbm_bytes_per_launch"
+    for tag in ("r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         if traffic is None and os.path.exists(tp) and a.bs == 8:
             try:
-                traffic = json.load(open(tp))["conv_gemm_hbm_bytes_per_launch"]
+                traffic = json.load(open(tp))[tkey]
                 traffic_src = "profiles/%s_traffic.json (offline rocprofv3 --pmc passes, not this run)" % tag
             except Exception:
                 traffic = None
-    roof = None
-    if kind is not None and eng.kind_count:
-        avg_ms = eng.kind_ms / eng.kind_count
-        per = lambda f: f * timed_steps / eng.kind_count / (avg_ms * 1e-3) / 1e12     # TFLOP/s of the average launch
-        ach = per(conv_exec)
-        roof = {"bound": "mfma", "kernel": "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: conv fwd / dgrad / convT)",
-                "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_MFMA_TFLOPS,
-                "flops_counted": "executed: per launch the host walks the kernel's tiles (pc_conv_work) and counts real rows x real columns x the K "
-                                 "each block walks -- taps that are padding for a whole tile are skipped by the kernel and NOT counted",
-                "frac_mfma_issued": per(conv_mfma) / PEAK_FP32_MFMA_TFLOPS,          # whole tiles: what an MFMA instruction counter sees
-                "frac_valid": per(conv_valid) / PEAK_FP32_MFMA_TFLOPS,               # non-padding MACs only
-                "frac_descriptor_counted": per(conv_desc) / PEAK_FP32_MFMA_TFLOPS,   # round 2's `frac`
-                "frac_reference_counted": per(conv_ref) / PEAK_FP32_MFMA_TFLOPS,     # round 1's `frac`
-                "traffic": traffic, "traffic_source": traffic_src,
-                "launches_per_step": eng.kind_count // max(1, timed_steps), "avg_launch_ms": avg_ms,
-                "kernel_ms_per_step": eng.kind_ms / max(1, timed_steps), "timed_steps": timed_steps,
-                "flops_per_launch": conv_exec * timed_steps / eng.kind_count}
+
+    def roof(kernel, exec_f, issued_f, valid_f, kms, count, steps_t, peak, extra=None):
+        if not count or not steps_t:
+            return None
+        ms_s = kms / steps_t
+        tf = lambda f: f / (ms_s * 1e-3) / 1e12
+        r = {"bound": "mfma", "kernel": kernel, "achieved": tf(exec_f), "peak": peak, "unit": "TFLOP/s", "frac": tf(exec_f) / peak,
+             "frac_mfma_issued": tf(issued_f) / peak, "frac_valid": tf(valid_f) / peak,
+             "launches_per_step": count // steps_t, "avg_launch_ms": kms / count, "kernel_ms_per_step": ms_s, "timed_steps": steps_t,
+             "flops_per_launch": exec_f * steps_t / count,
+             "flops_counted": "executed: per launch the host walks the kernel's tiles (pc_conv_work) and counts real rows x real columns x the K each block "
+                              "walks -- taps that are padding for a whole tile are skipped by the kernel and NOT counted"}
+        r.update(extra or {})
+        return r
+    roofline = roof_f32conv = None
+    if main_kind is not None and split_on:
+        roofline = roof("conv_x6_kernel (fp32 conv / dgrad / convT multiplied on the bf16 matrix cores: 3 bf16 terms per operand, 6 products on "
+                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate)", x6_exec, tot(fx, "mfma"), tot(fx, "valid"), main_ms, main_count, timed_steps,
+                        PEAK_BF16_MFMA_TFLOPS / 6.0,
+                        {"peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate = %.1f TFLOP/s of fp32-equivalent work; the chip holds "
+                                      "1.35 - 1.5 GHz of its 2.4 GHz in this kernel (in-kernel clock stamps, profiles/r04_x6_tile_probe.txt)" % (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                         "traffic": traffic, "traffic_source": traffic_src})
+        roof_f32conv = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: the launches that stay on v_mfma_f32_32x32x2_f32 -- the RGB stem, "
+                            "channel counts that are not multiples of 32, launches too small to gain)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"), f32c_ms * 2, f32c_count * 2, 2,
+                            PEAK_FP32_MFMA_TFLOPS)
+        if roofline:
+            roofline["frac_of_fp32_mfma_peak"] = roofline["achieved"] / PEAK_FP32_MFMA_TFLOPS
+    elif main_kind is not None:
+        roofline = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: conv fwd / dgrad / convT)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"),
+                        main_ms, main_count, timed_steps, PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic, "traffic_source": traffic_src})
     roof_wino = None
     if wino_count:
-        fzw = sum(fz[n]["executed"] for n in lists)
-        fzm = sum(fz[n]["mfma"] for n in lists)
-        fzd = sum(eng.plan.flops_reference_counted_wino()[n] for n in lists)
-        wms = wino_ms / wino_steps
-        roof_wino = {"bound": "mfma", "kernel": "wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)",
-                     "achieved": fzw / (wms * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": fzw / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                     "frac_mfma_issued": fzm / (wms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                     "direct_equivalent_tflops": fzd / (wms * 1e-3) / 1e12,      # the 3x3x3 formulation's FLOPs over the same time (2.25x the transform-domain work)
-                     "launches_per_step": wino_count // wino_steps, "kernel_ms_per_step": wms, "timed_steps": wino_steps,
-                     "flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"}
+        fzd = sum(pl.flops_reference_counted_wino()[n] for n in lists)
+        roof_wino = roof("wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
+                         wino_ms * 2, wino_count * 2, 2, PEAK_FP32_MFMA_TFLOPS,
+                         {"direct_equivalent_tflops": fzd / (wino_ms * 1e-3) / 1e12,      # the 3x3x3 formulation's FLOPs over the same time (2.25x the transform-domain work)
+                          "flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"})
+    ms_for_step = resident["ms_per_step"] if resident else ms_step
     roof_step = {"executed_gflop_per_step": step_exec / 1e9, "achieved": step_exec / (ms_step * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": step_exec / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
-                 "descriptor_gflop_per_step": sum(fl[n] for n in lists) / 1e9,
-                 "gflop_by_family": {"conv_gemm": conv_exec / 1e9, "winograd_conv": wino_exec / 1e9, "wgrad": sum(fw[n]["executed"] for n in lists) / 1e9},
-                 "note": "whole step (all kernels, host gaps and the loss read-back included) against the fp32 MFMA roof, executed GEMM FLOPs "
-                         "(gather-GEMM conv / dgrad, Winograd conv / dgrad in the transform domain, wgrad; pc_conv_work + pc_wino_work + pc_wgrad_work); the reference's own formulation would need 6 185 GFLOP/step, "
-                         "most of which are removed algebraically (DESIGN.md 3)"}
+                 "descriptor_gflop_per_step": sum(fl[n] for n in lists) / 1e9, "reference_formulation_conv_gflop_per_step": sum(fr[n] for n in lists) / 1e9,
+                 "gflop_by_family": {"conv_bf16_split": x6_exec / 1e9, "conv_fp32_mfma": conv_exec / 1e9, "winograd_conv": wino_exec / 1e9, "wgrad": wg_exec / 1e9},
+                 "note": "whole step (all kernels, host gaps, input staging and the loss read-back included) against the fp32 MFMA roof, executed GEMM FLOPs in fp32-equivalent "
+                         "multiply-accumulates (pc_conv_work + pc_wino_work + pc_wgrad_work); the launches on the bf16-split kernel have a higher roof (`roofline.peak`), "
+                         "so this fraction can exceed what an all-fp32-MFMA step could reach; resident-input step: %.3f ms" % ms_for_step}
+    dtype = ("f32 (conv / dgrad GEMMs: every fp32 operand as the exact sum of 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulate -- error vs fp64 "
+             "<= the fp32 MFMA kernel's, tests/test_x6_gpu.py; weight gradients, Winograd, stem and everything else: fp32 MFMA / VALU)") if split_on else "f32"
     out = {
         "metric": METRIC,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": ("configs[4] on one rank: JHMDB-21-shaped" if a.jhmdb else "configs[1]: UCF101-24-shaped") + " synthetic, I3D+caps, 8 frames (16-frame span, stride 2) x224x224, "
                                "bs=%d/GPU (bs/2 labeled + bs/2 unlabeled), %s consistency, dice+BCE loc loss, spread cls loss, Adam"
                                % (a.bs, "--gv" if a.gv else "--bv --n_frames 5 L2"),
                    "global_batch": world * a.bs, "clip": [3, 8, 224, 224], "parallelism": "dp%d" % world,
-                   "epoch": a.epoch, "thresh_epoch": 11, "executed_gflop_per_step_per_gpu": step_exec / 1e9,
-                   "inputs": "resident in HBM before the timed region (`staged` = the same step with per-step input staging inside it)"},
+                   "epoch": a.epoch, "thresh_epoch": 11, "executed_gflop_per_step_per_gpu": step_exec / 1e9, "inputs": inputs_note,
+                   "bf16_split_conv": split_on},
         "loss": last,
-        "staged": staged,
-        "roofline": roof,
+        "value_resident": None if resident is None else resident["value"],
+        "resident": resident,
+        "dict_contract": dict_leg,
+        "split_off": split_off,
+        "roofline": roofline,
+        "roofline_fp32_conv": roof_f32conv,
         "roofline_winograd": roof_wino,
         "roofline_step": roof_step,
         "ranks_observed": ranks_observed,
+        "busy_steps_outside_timed_regions": busy_steps,
         "reducer": None if reducer is None else {"buckets": len(reducer.buckets), "backend": torch.distributed.get_backend(),
                                                  "forced_single_rank": forced},
     }

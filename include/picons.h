@@ -99,10 +99,17 @@ int pc_conv_bnpart_rows(const pc_conv_desc* d);
  * pc_conv_x6_ok(d) must hold (Ci % 32 == 0, ldw % 8 == 0, <= 10 taps per dimension); everything else as pc_conv_fwd. */
 int pc_conv_fwd_x6(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
                    const float* cscale, float* out, float* bnpart, pc_stream s);
-int pc_conv_x6_ok(const pc_conv_desc* d);       /* host-only: 1 if the descriptor (with PC_F_X6) takes the bf16-split kernel */
+int pc_conv_x6_ok(const pc_conv_desc* d);       /* host-only advice for a planner: 1 if the descriptor (with PC_F_X6) can take the bf16-split kernel AND is
+                                                  * large enough to gain from it (small launches are faster on pc_conv_fwd) */
 /* planes[p * plane_stride + i] = p-th bf16 term of src[i] (p = 0, 1, 2: h = bf16(x), m = bf16(x - h), l = x - h - m, round to nearest; h + m + l == src[i] exactly for 2^-110 <= |x| < 2^128);
  * n and plane_stride multiples of 4 */
 int pc_split_planes(const float* src, uint16_t* planes, int64_t n, int64_t plane_stride, pc_stream s);
+/* the same for many buffers in one launch (the per-step weight planes); `jobs` is HOST memory */
+typedef struct pc_split_job {
+    uint64_t src, planes;           /* device pointers */
+    int64_t  n, plane_stride;
+} pc_split_job;
+int pc_split_planes_multi(const pc_split_job* jobs, int njobs, pc_stream s);
 /* Host-only work accounting of one pc_conv_fwd launch (no GPU call; measurement support for bench.py / tools/launch_table.py,
  * no reference counterpart).  Walks the launch's tiles in the kernel's own row order and counts the K loop each block really
  * runs (taps that are padding for every row of a tile are skipped by the kernel).  out[7]:
@@ -410,6 +417,10 @@ int pc_wspec_bwd(const float* dV, const float* tw, int A, int B, int KY, int KX,
  * GEMM); either may be NULL.  The adjoint reads plane gradients in the out_f layout and writes (accum: adds to) dw. */
 int pc_wspec_master_fwd(const float* w, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
                         float* out_f, float* out_t, pc_stream s);
+/* pc_wspec_master_fwd with the planes written as the three bf16 terms of every value (pc_split_planes' format, term p at + p * plane_stride
+ * elements) for pc_conv_fwd_x6: no fp32 copy of the 2 x 167 M-element PrimaryCaps weight planes exists in that mode */
+int pc_wspec_master_planes(const float* w, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                           uint16_t* out_f, uint16_t* out_t, int64_t plane_stride, pc_stream s);
 int pc_wspec_master_bwd(const float* dV, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
                         float* dw, int accum, pc_stream s);
 
@@ -469,6 +480,8 @@ enum {
     PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip; l = sO, sT, sI; p = w, U */
     PC_OP_CONV_X6,                  /* i = pc_conv_desc (flags with PC_F_X6); l[0] = plane stride; p = in, wplanes, bias, cscale, out, bnpart */
     PC_OP_SPLIT_PLANES,             /* l = n, plane stride; p = src, planes */
+    PC_OP_SPLIT_PLANES_MULTI,       /* p[0] = HOST pointer to pc_split_job[i[0]] (kept alive by the owner of the list) */
+    PC_OP_WSPEC_MASTER_PLANES,      /* i = Acnt, a0, Atot, B, KY, KX, U, Ur; l[0] = plane stride; p = w, tw, out_f planes, out_t planes */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

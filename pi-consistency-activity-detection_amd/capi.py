@@ -6,7 +6,12 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpicons.so")
+# PICONS_DIAG_LIB=1: the diagnostic build (make -C csrc diag), which also holds the ablation / stamp variants of the GEMM kernels -- some
+# of them WRONG by design.  The product library is built without them and never reads their switches; setting one without the diagnostic
+# library is refused here instead of being silently ignored (tools/ablate_conv.py, tools/ablate_wgrad.py, tools/probe_wino.py).
+DIAG = os.environ.get("PICONS_DIAG_LIB", "0") not in ("", "0")
+DIAG_SWITCHES = ("PICONS_CONV_ABLATE", "PICONS_WGRAD_ABLATE", "PICONS_WINO_VARIANT")
+LIB_PATH = os.path.join(_HERE, "libpicons_diag.so" if DIAG else "libpicons.so")
 _lib = None
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
@@ -52,7 +57,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
  OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS, OP_CONV_X6, OP_SPLIT_PLANES) = range(1, 47)
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS, OP_CONV_X6, OP_SPLIT_PLANES, OP_SPLIT_PLANES_MULTI, OP_WSPEC_MASTER_PLANES) = range(1, 49)
 MAX_LANES = 8
 
 # numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 42 int32, then D, S, g)
@@ -61,6 +66,9 @@ WJOB_DTYPE = np.dtype([("d", np.int32, 42), ("D", np.uint64), ("S", np.uint64), 
 # numpy mirror of struct pc_transpose_job
 TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64), ("dbs", np.int64), ("batch", np.int32), ("R", np.int32),
                        ("C", np.int32), ("sld", np.int32), ("dld", np.int32), ("accum", np.int32)], align=False)
+
+# numpy mirror of struct pc_split_job
+SJOB_DTYPE = np.dtype([("src", np.uint64), ("planes", np.uint64), ("n", np.int64), ("pstride", np.int64)], align=False)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6 = 1, 2, 4, 8, 16, 32, 64, 128
@@ -74,6 +82,7 @@ _SIGS = {
     "pc_conv_fwd_x6": (i32, [C.POINTER(ConvDesc), vp, vp, i64, vp, vp, vp, vp, vp]),
     "pc_conv_x6_ok": (i32, [C.POINTER(ConvDesc)]),
     "pc_split_planes": (i32, [vp, vp, i64, i64, vp]),
+    "pc_split_planes_multi": (i32, [vp, i32, vp]),
     "pc_conv_work": (i32, [C.POINTER(ConvDesc), i32, i32, C.POINTER(C.c_double)]),
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
     "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),
@@ -128,6 +137,7 @@ _SIGS = {
     "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_wspec_master_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "pc_wspec_master_planes": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, i64, vp]),
     "pc_wspec_master_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, vp, i32, vp]),
     "pc_tail6_weights": (i32, [vp, i32, i32, vp, vp, vp]),
     "pc_tail6_gather": (i32, [vp, vp, vp, i32, i32, i32, i32, vp, vp]),
@@ -149,6 +159,10 @@ def lib():
     """Load libpicons.so (once).  Raises if it has not been built: there is no fallback."""
     global _lib
     if _lib is None:
+        stray = [k for k in DIAG_SWITCHES if os.environ.get(k, "0") not in ("", "0")]
+        if stray and not DIAG:
+            raise RuntimeError("%s set, but these switches exist only in the diagnostic build of the library (results can be wrong by design): "
+                               "`make -C pi-consistency-activity-detection_amd/csrc diag` and PICONS_DIAG_LIB=1, or unset them" % ", ".join(stray))
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libpicons.so not built (%s): run `python -c 'import __graft_entry__ as g; g.build()'` "
                                "or `make -C pi-consistency-activity-detection_amd/csrc`; there is no CPU fallback" % LIB_PATH)

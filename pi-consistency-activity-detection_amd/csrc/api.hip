@@ -34,6 +34,11 @@ static int run_one(const pc_op& op, pc_stream s) {
         }
         case PC_OP_SPLIT_PLANES:
             return pc_split_planes(P(const float*, 0), P(uint16_t*, 1), op.l[0], op.l[1], s);
+        case PC_OP_WSPEC_MASTER_PLANES:
+            return pc_wspec_master_planes(P(const float*, 0), P(const float*, 1), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], op.i[6], op.i[7],
+                                          P(uint16_t*, 2), P(uint16_t*, 3), op.l[0], s);
+        case PC_OP_SPLIT_PLANES_MULTI:
+            return pc_split_planes_multi(P(const pc_split_job*, 0), op.i[0], s);
         case PC_OP_WGRAD: {
             pc_wgrad_desc d;
             memcpy(&d, op.i, sizeof(d));
@@ -215,7 +220,7 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         const bool t = kind > 0 && op.kind == kind;
         // a conv op is exactly one kernel: its event pair rides in the dispatch itself (no extra packets on the stream);
         // any other kind is bracketed by recorded events
-        const bool ext = t && (op.kind == PC_OP_CONV || op.kind == PC_OP_WINO_CONV) && !g_no_ext_events;
+        const bool ext = t && (op.kind == PC_OP_CONV || op.kind == PC_OP_CONV_X6 || op.kind == PC_OP_WINO_CONV) && !g_no_ext_events;
         if (ext) { pc_tl_ev_start = ev[2 * j]; pc_tl_ev_stop = ev[2 * j + 1]; }
         else if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
         rc = run_one(op, s);

@@ -807,8 +807,7 @@ extern "C" int pc_em_routing_fwd(const float* x, const float* W, const float* be
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_fwd: B must be 32 and C <= 24 (B=%d C=%d)", B, C);
     PC_CHECK_ARG((uintptr_t)x % 16 == 0, "pc_em_routing_fwd: x alignment");
     const size_t lds = (size_t)NB * MAXC * 16 * 4 + sizeof(FwdLite) * FWD_WAVES;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)em_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    PC_SET_LDS_ONCE(em_fwd_kernel, lds, "em_fwd_kernel");
     int grid = cdiv(npos, FWD_WAVES);
     if (grid > 256) grid = 256;            // one block (10 waves, 136 KB of LDS) per CU, positions strided over the grid
     hipLaunchKernelGGL(em_fwd_kernel, dim3(grid), dim3(64 * FWD_WAVES), lds, (hipStream_t)s, x, W, beta_u, beta_a, npos, C, out, (EmSaved*)state);
@@ -824,12 +823,8 @@ extern "C" int pc_em_routing_bwd(const float* x, const float* W, const float* be
     PC_CHECK_ARG(B == NB && C >= 1 && C <= MAXC, "pc_em_routing_bwd: B must be 32 and C <= 24");
     const int BWD_GROUPS = em_groups();
     const size_t lds = (size_t)NB * MAXC * 16 * 4 + BWD_GROUPS * ((size_t)EM_SMALL * 4 + sizeof(FwdState) + sizeof(BwdState) + BWD_WAVES * MAXC * 16 * 4);
-    static bool attr = false;
-    if (!attr) {
-        (void)hipFuncSetAttribute((const void*)em_bwd_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute((const void*)em_bwd_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr = true;
-    }
+    PC_SET_LDS_ONCE(em_bwd_kernel<1>, lds, "em_bwd_kernel<1>");
+    PC_SET_LDS_ONCE(em_bwd_kernel<2>, lds, "em_bwd_kernel<2>");
     const int nblk = em_bwd_blocks(npos, BWD_GROUPS);
     if (BWD_GROUPS == 1) hipLaunchKernelGGL(em_bwd_kernel<1>, dim3(nblk), dim3(64 * BWD_WAVES), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws, (const EmSaved*)state);
     else hipLaunchKernelGGL(em_bwd_kernel<2>, dim3(nblk), dim3(64 * BWD_WAVES * 2), lds, s, x, W, beta_u, beta_a, dout, npos, C, dx, ws, (const EmSaved*)state);

@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
+#include <mutex>
 #include "../../include/picons.h"
 
 void pc_set_error(const char* fmt, ...);
@@ -25,6 +26,18 @@ extern thread_local hipEvent_t pc_tl_ev_start, pc_tl_ev_stop;
             pc_set_error("%s: %s", what, hipGetErrorString(e_));                     \
             return PC_E_LAUNCH;                                                      \
         }                                                                            \
+    } while (0)
+
+// One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) per kernel instantiation.  The C-ABI is entered from Python's main thread and
+// from the autograd engine's worker thread: std::call_once instead of a plain static flag (a data race, however benign), and a refusal
+// surfaces through pc_last_error() instead of as a generic launch failure.  `fn` in parentheses if it carries template commas.
+#define PC_SET_LDS_ONCE(fn, bytes, what)                                                                                             \
+    do {                                                                                                                             \
+        static std::once_flag once_;                                                                                                 \
+        static hipError_t rc_ = hipSuccess;                                                                                          \
+        const size_t b_ = (size_t)(bytes);                                                                                           \
+        std::call_once(once_, [&] { rc_ = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)b_); }); \
+        if (rc_ != hipSuccess) { pc_set_error("%s: %zu bytes of dynamic LDS refused: %s", what, b_, hipGetErrorString(rc_)); return PC_E_LAUNCH; } \
     } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

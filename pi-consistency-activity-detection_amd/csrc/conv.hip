@@ -474,7 +474,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
 
 template <int BM, int BN, int WM, int WN, int VAR>
 int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
-    static bool attr_set = false;
     constexpr int ST = 2 + ((VAR >> 3) & 3);
     {   // the tiles are fetched with 32-bit lane offsets from a wave-uniform base (glds16b)
         const long long halo = ((long long)(k.ioff0[0] < 0 ? -k.ioff0[0] : 0) * k.Hi + (k.ioff0[1] < 0 ? -k.ioff0[1] : 0)) * k.Wi + (k.ioff0[2] < 0 ? -k.ioff0[2] : 0);
@@ -483,10 +482,7 @@ int launch_conv_glds_v(const ConvK& k, hipStream_t s) {
                      "pc_conv_fwd: input (%lld B) or weights (%lld B) exceed the 4 GiB the LDS-DMA gather addresses: use a smaller per-GPU batch", in_bytes, w_bytes);
     }
     const size_t lds = (size_t)(ST * (BM + BN) * BK + BM * 5 + 4) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    PC_SET_LDS_ONCE((conv_gemm_glds_kernel<BM, BN, WM, WN, VAR>), lds, "conv_gemm_glds_kernel");
     ConvK p = k;
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
@@ -524,13 +520,8 @@ int launch_conv_glds(const ConvK& k, hipStream_t s) {
 
 template <int BM, int BN, int WM, int WN, bool FAST>
 int launch_conv2(const ConvK& k, hipStream_t s) {
-    static bool attr_set = false;
     const size_t lds = (size_t)(2 * (BM + BN) * LDK + BM * 5) * sizeof(float);
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)conv_gemm_kernel<BM, BN, WM, WN, FAST>,
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        attr_set = true;
-    }
+    PC_SET_LDS_ONCE((conv_gemm_kernel<BM, BN, WM, WN, FAST>), lds, "conv_gemm_kernel");
     ConvK p = k;
     p.mtiles_g = cdiv(p.Mg, BM);
     p.ntiles = cdiv(p.Co, BN);
@@ -541,7 +532,9 @@ int launch_conv2(const ConvK& k, hipStream_t s) {
     return PC_OK;
 }
 
-// PICONS_CONV_ABLATE=1|2|3 (diagnostic, tools/ablate_conv.py): 1 = no tile fetch / LDS store in the K loop,
+#ifdef PICONS_DIAG
+// Diagnostic build only (make diag -> libpicons_diag.so; the product library neither holds these kernels nor reads the variable).
+// PICONS_CONV_ABLATE=1|2|3 (tools/ablate_conv.py): 1 = no tile fetch / LDS store in the K loop,
 // 2 = also no barrier, 3 = also a fixed fragment address.  Results are WRONG in these modes; they only price phases.
 template <int BM, int BN, int WM, int WN, int ABL>
 int launch_ablate(const ConvK& k, hipStream_t s) {
@@ -554,15 +547,18 @@ int launch_ablate(const ConvK& k, hipStream_t s) {
     PC_CHECK_LAUNCH("conv_gemm_kernel(ablate)");
     return PC_OK;
 }
+#endif
 
 template <int BM, int BN, int WM, int WN>
 int launch_conv(const ConvK& k, hipStream_t s) {
+#ifdef PICONS_DIAG
     static const int abl = getenv("PICONS_CONV_ABLATE") ? atoi(getenv("PICONS_CONV_ABLATE")) : 0;
     if (abl && k.Ci % BK == 0 && BM == 128 && BN >= 64) {
         if (abl == 1) return launch_ablate<BM, BN, WM, WN, 1>(k, s);
         if (abl == 2) return launch_ablate<BM, BN, WM, WN, 2>(k, s);
         return launch_ablate<BM, BN, WM, WN, 3>(k, s);
     }
+#endif
     static const int no_glds = getenv("PICONS_CONV_NO_GLDS") ? atoi(getenv("PICONS_CONV_NO_GLDS")) : 0;
     const bool fast = k.Ci % BK == 0;
     static const int no_tap4 = getenv("PICONS_CONV_NO_TAP4") ? atoi(getenv("PICONS_CONV_NO_TAP4")) : 0;
@@ -1213,7 +1209,11 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
 // work accounting (pc_wgrad_work), so the A/B switches mean the same everywhere and the fp32 atomic sum order the goldens were
 // made with cannot drift between copies of the predicates.
 enum WgRoute { WG_STEM, WG_ROW3, WG_ROW9, WG_GENERIC };
+#ifdef PICONS_DIAG
 inline bool wg_ablate() { static const bool a = getenv("PICONS_WGRAD_ABLATE") != nullptr; return a; }
+#else
+constexpr bool wg_ablate() { return false; }
+#endif
 inline WgRoute wg_route(const pc_wgrad_desc* d) {
     static const int s4_env = getenv("PICONS_WGRAD_STEM") ? atoi(getenv("PICONS_WGRAD_STEM")) : 1;
     static const int row_env = getenv("PICONS_WGRAD_ROW") ? atoi(getenv("PICONS_WGRAD_ROW")) : 1;
@@ -1352,7 +1352,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
     k.nchunks = cdiv(P, BK);
-    static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic: no tile fetch in the K loop (wrong results)
+#ifdef PICONS_DIAG
+    static const int abl = getenv("PICONS_WGRAD_ABLATE") ? atoi(getenv("PICONS_WGRAD_ABLATE")) : 0;   // diagnostic build: no tile fetch in the K loop (wrong results)
+#endif
     // rows of D's channels [m_lo, m_hi) with 64- or 128-row tiles
     // conv with 3 taps, stride 1, padding 1 along w and 32- / 64-channel blocks of S: row-segment kernel (the kw taps share
     // one LDS tile)
@@ -1458,6 +1460,7 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         kk.nsplit = splitk;
         kk.mt = mt; kk.ntl = ntl;
         dim3 grid((unsigned)((int64_t)mt * ntl * nb * splitk));
+#ifdef PICONS_DIAG
         if (abl == 2) {          // + fragment reads hoisted out of the k-step loop
             if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 2>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 2>), grid, dim3(256), 0, s, kk);
@@ -1471,7 +1474,9 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         } else if (abl) {
             if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
-        } else if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
+        } else
+#endif
+        if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
         else if (wide) hipLaunchKernelGGL((wgrad_kernel<128, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);

@@ -55,6 +55,25 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// Many split jobs in one launch (the per-step weight planes of every layer): the jobs travel by value in the kernel arguments
+constexpr int SP_JOBS = 48;
+struct SplitJobK { const float* src; uint16_t* dst; long long n, pstride; };
+struct SplitPack { SplitJobK j[SP_JOBS]; int first[SP_JOBS + 1]; int n; };
+__global__ __launch_bounds__(256) void split_planes_multi_kernel(const SplitPack pk) {
+    int k = 0;
+    while (k + 1 < pk.n && (int)blockIdx.x >= pk.first[k + 1]) ++k;
+    const SplitJobK& J = pk.j[k];
+    const long long i = ((long long)(blockIdx.x - pk.first[k]) * 256 + threadIdx.x) * 4;
+    if (i >= J.n) return;
+    const f32x4 v = *(const f32x4*)(J.src + i);
+    uint32_t h0, m0, l0, h1, m1, l1;
+    split2(v[0], v[1], h0, m0, l0);
+    split2(v[2], v[3], h1, m1, l1);
+    *(uint2*)(J.dst + i) = make_uint2(h0, h1);
+    *(uint2*)(J.dst + J.pstride + i) = make_uint2(m0, m1);
+    *(uint2*)(J.dst + 2 * J.pstride + i) = make_uint2(l0, l1);
+}
+
 __device__ __forceinline__ dma_rsrc_t dma_rsrc_h(const uint16_t* base) {
     return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0xffffff00u, 0x00020000);
 }
@@ -340,10 +359,7 @@ template <int BM, int BN, int WM, int WN>
 int launch_x6(const ConvX6& kx, hipStream_t s) {
     constexpr int OPBYTES = 2 * (BM * BK * 4 + 3 * BN * BK * 2);
     const size_t lds = (size_t)OPBYTES + (size_t)(BM * 5 + 4) * sizeof(int);
-    static std::once_flag once;
-    static hipError_t attr_rc = hipSuccess;
-    std::call_once(once, [&] { attr_rc = hipFuncSetAttribute((const void*)conv_x6_kernel<BM, BN, WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); });
-    if (attr_rc != hipSuccess) { pc_set_error("conv_x6_kernel<%d,%d>: %zu bytes of LDS refused: %s", BM, BN, lds, hipGetErrorString(attr_rc)); return PC_E_LAUNCH; }
+    PC_SET_LDS_ONCE((conv_x6_kernel<BM, BN, WM, WN>), lds, "conv_x6_kernel");
     ConvX6 p = kx;
     p.k.mtiles_g = cdiv(p.k.Mg, BM);
     p.k.ntiles = cdiv(p.k.Co, BN);
@@ -356,35 +372,50 @@ int launch_x6(const ConvX6& kx, hipStream_t s) {
 
 }  // namespace
 
-// A launch takes the bf16-split kernel when its descriptor asks for it (PC_F_X6: the caller holds weight planes) and has the shape the
+// Tile of a launch on the bf16-split kernel: the candidate with the least estimated time, time = rounds of resident blocks x the tile's
+// area / its measured efficiency (256 x 128 on 8 waves: one block per CU, the fastest per multiply-accumulate; 128 x 64 and 64 x 128 on 4 waves:
+// two blocks per CU; 64 x 64: three) -- the last, partial round costs as many block-times as the fullest CU holds blocks.  N-fastest row order
+// (the 9 x 9 transposed / spectral forms) keeps 64-row tiles where a wider tile would straddle image rows (as conv.hip's launch_tile).
+X6Tile pc_x6_tile(const pc_conv_desc* d, int groups) {
+    const long long Mg = (long long)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    bool rows64 = false;
+    if (d->flags & PC_F_NFAST) {
+        const long long per_row = (long long)d->Wq * (d->N / groups);
+        rows64 = per_row % 128 != 0 && per_row % 64 == 0;
+    }
+    if (d->Co <= 32 && !rows64) return X6Tile{128, 32, 4, 1};
+    struct Cand { X6Tile t; int bpc; double eff; };
+    const Cand cand[] = {{{256, 128, 8, 1}, 1, 1.0}, {{128, 64, 4, 1}, 2, 0.9}, {{64, 128, 2, 2}, 2, 0.85}, {{64, 64, 2, 2}, 3, 0.7}};
+    double best = 1e300;
+    X6Tile bt = cand[3].t;
+    for (const Cand& c : cand) {
+        if (rows64 && c.t.bm != 64) continue;
+        if (c.t.bn == 128 && d->Co <= 64) continue;
+        const long long blocks = (long long)groups * cdiv(Mg, c.t.bm) * cdiv(d->Co, c.t.bn);
+        const long long per_round = 256ll * c.bpc;
+        const long long full = blocks / per_round, rem = blocks % per_round;
+        const double t = (double)(full * c.bpc + cdiv(rem, 256)) * c.t.bm * c.t.bn / c.eff;
+        if (t < best) { best = t; bt = c.t; }
+    }
+    return bt;
+}
+
+// A launch CAN take the bf16-split kernel when its descriptor asks for it (PC_F_X6: the caller holds weight planes) and has the shape the
 // LDS-DMA tiles need: whole 32-channel chunks, at most 10 taps per dimension, 16-byte aligned plane rows.
 bool pc_x6_eligible(const pc_conv_desc* d) {
     return d && (d->flags & PC_F_X6) && d->Ci % BK == 0 && d->Ci >= BK && d->ldi % 4 == 0 && d->ldw % 8 == 0 && d->ntap[0] >= 1 && d->ntap[0] <= 10 &&
-           d->ntap[1] >= 1 && d->ntap[1] <= 10 && d->ntap[2] >= 1 && d->ntap[2] <= 10;
+           d->ntap[1] >= 1 && d->ntap[1] <= 10 && d->ntap[2] >= 1 && d->ntap[2] <= 10 && d->N % (d->groups > 0 ? d->groups : 1) == 0;
 }
 
-// Tile of an eligible launch.  256 x 128 on 8 waves (one block per CU) where the rows fill the chip at that size, 128 x 64 on 4 waves (two
-// blocks per CU) otherwise; n-fastest row order (the 9 x 9 transposed / spectral forms) keeps the 64-row tiles whose tap box is tight.
-X6Tile pc_x6_tile(const pc_conv_desc* d, int groups) {
+// Advice for the planner: eligible AND large enough to gain.  The kernel's pipeline has a longer prologue than the fp32 kernel's; launches of
+// fewer than ~150 blocks of its smallest tile measured 0.75 - 0.85x (profiles/r04_x6_launches.txt) and stay on the fp32 MFMA kernel.
+extern "C" int pc_conv_x6_ok(const pc_conv_desc* d) {
+    if (!pc_x6_eligible(d)) return 0;
+    const int groups = d->groups > 0 ? d->groups : 1;
+    const X6Tile t = pc_x6_tile(d, groups);
     const long long Mg = (long long)(d->N / groups) * d->Tq * d->Hq * d->Wq;
-    if (d->flags & PC_F_NFAST) {
-        const long long per_row = (long long)d->Wq * (d->N / groups);
-        if (per_row % 128 != 0 && per_row % 64 == 0) return d->Co > 64 ? X6Tile{64, 128, 2, 2} : X6Tile{64, 64, 2, 2};
-    }
-    if (d->Co <= 32) return X6Tile{128, 32, 4, 1};
-    const long long big = (long long)groups * cdiv(Mg, 256) * cdiv(d->Co, 128);
-    if (d->Co > 64 && big >= 256) {
-        // whole rounds of one block per CU, or many of them: the tail round costs at most a few percent
-        const double rounds = (double)big / 256.0;
-        const double fill = rounds / ceil(rounds);
-        const double pad = (double)(cdiv(Mg, 256) * 256) / (double)Mg * (double)(cdiv(d->Co, 128) * 128) / (double)d->Co;
-        const double pad64 = (double)(cdiv(Mg, 128) * 128) / (double)Mg * (double)(cdiv(d->Co, 64) * 64) / (double)d->Co;
-        if (fill >= 0.8 && pad <= pad64 * 1.10) return X6Tile{256, 128, 8, 1};
-    }
-    return X6Tile{128, 64, 4, 1};
+    return (long long)groups * cdiv(Mg, t.bm) * cdiv(d->Co, t.bn) >= 150 ? 1 : 0;
 }
-
-extern "C" int pc_conv_x6_ok(const pc_conv_desc* d) { return pc_x6_eligible(d) ? 1 : 0; }
 
 extern "C" int pc_split_planes(const float* src, uint16_t* planes, int64_t n, int64_t plane_stride, pc_stream s) {
     PC_CHECK_ARG(src && planes && n > 0 && n % 4 == 0 && plane_stride >= n && plane_stride % 4 == 0, "pc_split_planes: n and the plane stride must be multiples of 4 (n=%lld stride=%lld)",
@@ -393,6 +424,28 @@ extern "C" int pc_split_planes(const float* src, uint16_t* planes, int64_t n, in
     const long long blocks = (n / 4 + 255) / 256;
     hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)s, src, planes, (long long)n, (long long)plane_stride);
     PC_CHECK_LAUNCH("split_planes_kernel");
+    return PC_OK;
+}
+
+extern "C" int pc_split_planes_multi(const pc_split_job* jobs, int njobs, pc_stream s) {
+    PC_CHECK_ARG(jobs && njobs >= 1, "pc_split_planes_multi: bad args");
+    for (int j0 = 0; j0 < njobs; j0 += SP_JOBS) {
+        SplitPack pk;
+        pk.n = njobs - j0 < SP_JOBS ? njobs - j0 : SP_JOBS;
+        long long blocks = 0;
+        for (int q = 0; q < pk.n; ++q) {
+            const pc_split_job& a = jobs[j0 + q];
+            PC_CHECK_ARG(a.src && a.planes && a.n > 0 && a.n % 4 == 0 && a.plane_stride >= a.n && a.plane_stride % 4 == 0 && a.src % 16 == 0 && a.planes % 8 == 0,
+                         "pc_split_planes_multi: bad job %d (n=%lld stride=%lld)", j0 + q, (long long)a.n, (long long)a.plane_stride);
+            pk.j[q].src = (const float*)(uintptr_t)a.src; pk.j[q].dst = (uint16_t*)(uintptr_t)a.planes; pk.j[q].n = a.n; pk.j[q].pstride = a.plane_stride;
+            pk.first[q] = (int)blocks;
+            blocks += (a.n / 4 + 255) / 256;
+            PC_CHECK_ARG(blocks < (1ll << 31), "pc_split_planes_multi: too many elements");
+        }
+        pk.first[pk.n] = (int)blocks;
+        hipLaunchKernelGGL(split_planes_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, pk);
+        PC_CHECK_LAUNCH("split_planes_multi_kernel");
+    }
     return PC_OK;
 }
 

@@ -124,7 +124,6 @@ struct RedP {
 
 template <int MODE>
 __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
-    __shared__ float sh[256 * 8];
     p.a += blockIdx.y * p.a_gs; p.b += blockIdx.y * p.b_gs; p.stat += blockIdx.y * p.stat_gs; p.part += blockIdx.y * p.part_gs;
     const int C4 = p.C4, C = C4 * 4;
     const int rpi = 256 / C4;                       // rows per iteration
@@ -132,9 +131,14 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
     const bool active = rl < rpi;
     const int64_t r0 = (int64_t)blockIdx.x * p.rows_per_block;
     const int64_t r1 = min(p.rows, r0 + p.rows_per_block);
-    float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // A thread's sum runs over thousands of rows of mixed sign (a BatchNorm bias gradient is ~1e-3 of sum |dy|): fp32 chains of that
+    // length left the BN parameter gradients 3x further from an fp64 run than the fp32 reference's (pairwise) sums.  Short fp32 runs of
+    // four rows, flushed into double: the kernel stays HBM-bound.
+    double sd[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (active) {
         const int c = c4 * 4;
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        int run = 0;
         for (int64_t r = r0 + rl; r < r1; r += rpi) {
             const f32x4 dy = *(const f32x4*)(p.a + r * p.lda + c);
             const f32x4 zz = *(const f32x4*)(p.b + r * p.ldb + c);
@@ -158,19 +162,27 @@ __global__ __launch_bounds__(256) void colreduce_kernel(RedP p) {
                     s[e] += d;
                 }
             }
-        }
-    }
+            if (++run == 4) {
+                run = 0;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sh[threadIdx.x * 8 + e] = s[e];
+                for (int e = 0; e < 8; ++e) { sd[e] += (double)s[e]; s[e] = 0.f; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sd[e] += (double)s[e];
+    }
+    __shared__ double shd[256 * 8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) shd[threadIdx.x * 8 + e] = sd[e];
     __syncthreads();
     if (threadIdx.x < C4) {
-        float t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int q = 0; q < rpi; ++q)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) t[e] += sh[(q * C4 + threadIdx.x) * 8 + e];
+            for (int e = 0; e < 8; ++e) t[e] += shd[(q * C4 + threadIdx.x) * 8 + e];
         float* o = p.part + (size_t)blockIdx.x * 2 * C + threadIdx.x * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { o[e] = t[e]; o[C + e] = t[4 + e]; }
+        for (int e = 0; e < 4; ++e) { o[e] = (float)t[e]; o[C + e] = (float)t[4 + e]; }
     }
 }
 

@@ -144,9 +144,21 @@ __global__ __launch_bounds__(256) void wspec_bwd_kernel(const float* __restrict_
 // The same two maps straight from / to the reference's OI(H)W master layout w[A][B][KY][KX] (taps contiguous), so a big
 // weight needs no kernel-layout copies at all.  One thread per (a, b) holds all KY*KX taps in registers.
 // ALONG_A: consecutive threads walk a (for the [g][B][KY][Atot] dgrad layout), else b (for the [g][Atot][KY][B] forward layout).
-template <int KX, int KY, bool ALONG_A>
+// PLANES: the weight planes leave as the three bf16 terms of every value (h, m, l: csrc/conv_x6.hip) at out16 + p * pstride, for the
+// bf16-split conv kernel -- 6 bytes per element instead of 4, and no fp32 copy at all.
+__device__ __forceinline__ void store_terms(uint16_t* o, long long pstride, float x) {
+    const uint32_t u = __float_as_uint(x);
+    const uint32_t h = (u + 0x7fffu + ((u >> 16) & 1u)) & 0xffff0000u;          // round to nearest even (finite weights: no NaN handling needed)
+    const float r = x - __uint_as_float(h);
+    const uint32_t v = __float_as_uint(r);
+    const uint32_t m = (v + 0x7fffu + ((v >> 16) & 1u)) & 0xffff0000u;
+    const float l = r - __uint_as_float(m);
+    o[0] = (uint16_t)(h >> 16); o[pstride] = (uint16_t)(m >> 16); o[2 * pstride] = (uint16_t)(__float_as_uint(l) >> 16);
+}
+
+template <int KX, int KY, bool ALONG_A, bool PLANES = false>
 __global__ __launch_bounds__(128) void wspec_master_fwd_kernel(const float* __restrict__ w, const float* __restrict__ tw, int Acnt, int a0, int Atot,
-                                                                int B, int U, int Ur, float* __restrict__ out) {
+                                                                int B, int U, int Ur, float* __restrict__ out, long long pstride = 0) {
     const int fast = blockIdx.x * 128 + threadIdx.x, slow = blockIdx.y;
     const int a = ALONG_A ? fast : slow, b = ALONG_A ? slow : fast;
     if (a >= Acnt || b >= B) return;
@@ -168,9 +180,15 @@ __global__ __launch_bounds__(128) void wspec_master_fwd_kernel(const float* __re
             float wr = 0.f, wi = 0.f;
 #pragma unroll
             for (int kx = 0; kx < KX; ++kx) { wr += tw[(u * KX + kx) * 2] * v[ky][kx]; wi += tw[(u * KX + kx) * 2 + 1] * v[ky][kx]; }
-            float* o = out + g0 * plane + base + ky * kystep;
-            o[0] = wr;
-            if (!real) { o[plane] = wr - wi; o[2 * plane] = wr + wi; }
+            if constexpr (PLANES) {
+                uint16_t* o = (uint16_t*)out + g0 * plane + base + ky * kystep;
+                store_terms(o, pstride, wr);
+                if (!real) { store_terms(o + plane, pstride, wr - wi); store_terms(o + 2 * plane, pstride, wr + wi); }
+            } else {
+                float* o = out + g0 * plane + base + ky * kystep;
+                o[0] = wr;
+                if (!real) { o[plane] = wr - wi; o[2 * plane] = wr + wi; }
+            }
         }
     }
 }
@@ -270,6 +288,18 @@ extern "C" int pc_wspec_master_fwd(const float* w, const float* tw, int Acnt, in
     if (out_f) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, false>), dim3(cdiv(B, 128), Acnt), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, out_f);
     if (out_t) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, true>), dim3(cdiv(Acnt, 128), B), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, out_t);
     PC_CHECK_LAUNCH("wspec_master_fwd_kernel");
+    return PC_OK;
+}
+
+extern "C" int pc_wspec_master_planes(const float* w, const float* tw, int Acnt, int a0, int Atot, int B, int KY, int KX, int U, int Ur,
+                                      uint16_t* out_f, uint16_t* out_t, int64_t plane_stride, pc_stream s_) {
+    PC_CHECK_ARG(w && tw && (out_f || out_t) && Acnt > 0 && a0 >= 0 && a0 + Acnt <= Atot && B > 0 && U > 0 && Ur >= 0 && Ur <= U && plane_stride > 0,
+                 "pc_wspec_master_planes: bad args");
+    PC_CHECK_ARG(KY == 9 && KX == 9, "pc_wspec_master_planes: only the 9x9 PrimaryCaps kernel is instantiated (KY=%d KX=%d)", KY, KX);
+    hipStream_t s = (hipStream_t)s_;
+    if (out_f) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, false, true>), dim3(cdiv(B, 128), Acnt), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, (float*)out_f, (long long)plane_stride);
+    if (out_t) hipLaunchKernelGGL((wspec_master_fwd_kernel<9, 9, true, true>), dim3(cdiv(Acnt, 128), B), dim3(128), 0, s, w, tw, Acnt, a0, Atot, B, U, Ur, (float*)out_t, (long long)plane_stride);
+    PC_CHECK_LAUNCH("wspec_master_fwd_kernel(planes)");
     return PC_OK;
 }
 

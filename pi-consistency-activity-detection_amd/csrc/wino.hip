@@ -358,7 +358,8 @@ void choose_block(int TH, int TW, int& bth, int& btw) {
 int fill(const pc_wino_desc* d, WinoK& k) {
     PC_CHECK_ARG(d, "pc_wino: null descriptor");
     PC_CHECK_ARG(d->N >= 1 && d->T >= 1 && d->H >= 2 && d->W >= 2 && d->H % 2 == 0 && d->W % 2 == 0, "pc_wino: H, W must be even (H=%d W=%d)", d->H, d->W);
-    PC_CHECK_ARG(d->Ci >= 8 && d->Ci % 8 == 0 && d->ldi % 4 == 0 && d->Co >= 1 && d->ldo >= d->Co, "pc_wino: Ci %% 8, ldi %% 4 (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
+    PC_CHECK_ARG(d->Ci >= 8 && d->Ci % 8 == 0 && d->ldi % 4 == 0 && d->ldi >= d->Ci && d->Co >= 1 && d->ldo >= d->Co,
+                 "pc_wino: Ci %% 8, ldi %% 4, ldi >= Ci, ldo >= Co (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
     PC_CHECK_ARG(d->KT == 1 || d->KT == 3, "pc_wino: KT must be 1 or 3");
     PC_CHECK_ARG((int64_t)d->N * (d->T > d->Ti ? d->T : d->Ti) * d->H * d->W * (int64_t)(d->ldi > d->ldo ? d->ldi : d->ldo) < (1ll << 40), "pc_wino: tensor too large");
     PC_CHECK_ARG((int64_t)d->H * d->W * d->ldi * 4 < 0xff000000ll, "pc_wino: plane too large (the LDS-DMA lane offsets are 32-bit byte offsets inside one frame)");
@@ -424,16 +425,20 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     PC_CHECK_ARG(!(d->flags & ~(PC_F_BIAS | PC_F_ACCUM | PC_F_BNPART)), "pc_wino_conv: unsupported flag");
     PC_CHECK_ARG(d->act == PC_ACT_NONE || d->act == PC_ACT_RELU, "pc_wino_conv: activation");
     k.in = in; k.U = U; k.bias = bias; k.out = out; k.bnpart = bnpart;
+#ifdef PICONS_DIAG
+    // diagnostic build only (make diag; tools/probe_wino.py): ablations and in-kernel stamps, bits 1-8 give wrong results by design
     static const int var = getenv("PICONS_WINO_VARIANT") ? atoi(getenv("PICONS_WINO_VARIANT")) : 0;
+    PC_CHECK_ARG(var != 32 || bnpart, "pc_wino_conv: variant 32 writes its stamps through bnpart");
+#endif
     const size_t lds = (size_t)(4 * PLANE + 2 * RPLANE) * sizeof(float);
     const dim3 grid((unsigned)((int64_t)k.N * k.T * k.nbh * k.nbw * k.nct));
 #define WINO_LAUNCH(V)                                                                                                            \
     {                                                                                                                             \
-        static bool attr_set = false;                                                                                             \
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)wino_conv_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr_set = true; } \
+        PC_SET_LDS_ONCE(wino_conv_kernel<V>, lds, "wino_conv_kernel");                                                            \
         if (pc_tl_ev_start) hipExtLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, pc_tl_ev_start, pc_tl_ev_stop, 0, k); \
         else hipLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, k);                                   \
     }
+#ifdef PICONS_DIAG
     switch (var) {
         case 1: WINO_LAUNCH(1) break;
         case 2: WINO_LAUNCH(2) break;
@@ -445,6 +450,9 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
         case 32: WINO_LAUNCH(32) break;
         default: WINO_LAUNCH(0) break;
     }
+#else
+    WINO_LAUNCH(0)
+#endif
 #undef WINO_LAUNCH
     PC_CHECK_LAUNCH("wino_conv_kernel");
     return PC_OK;

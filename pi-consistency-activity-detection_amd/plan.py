@@ -84,6 +84,10 @@ class Plan:
         self.wgrad_collect = None  # inside a wgrad group: [(descriptor, pointer refs)] collected for one pc_conv_wgrad_multi op
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
         self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
+        # convolutions multiplied on the bf16 matrix cores (csrc/conv_x6.hip: fp32 operands as exact sums of three bf16 terms, six products,
+        # fp32 accumulate); PICONS_SPLIT=0 keeps every launch on the fp32 MFMA kernels
+        self.x6 = os.environ.get("PICONS_SPLIT", "1") != "0"
+        self.wbufs = []           # kernel-layout weight buffers: dict(ref, n floats, lst / lane of the producing ops, planes ref once split)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
         # decoder tail as one five-tap transposed conv with a single output channel (csrc/tail6.hip) instead of the
         # 27-channel form + tap sum
@@ -243,9 +247,11 @@ class Plan:
         return TR((g.ref[0], g.ref[1] + delta), y.N, y.thw, y.C, y.ld, g.name)
 
     # ------------------------------------------------------------------ weights
-    def prep_conv_weight(self, names, O_list, I, k, need_tr, Ipad=None):
+    def prep_conv_weight(self, names, O_list, I, k, need_tr, Ipad=None, layouts=True):
         """Reference OI(T)HW masters (one or several stacked along O) -> kernel layouts:
-        fwd [O][taps][Ipad], tr [I][taps][O] (for dgrad).  Also the kernel-layout grad buffer."""
+        fwd [O][taps][Ipad], tr [I][taps][O] (for dgrad).  Also the kernel-layout grad buffer.
+        layouts=False (the layer's forward and input gradient run in Winograd form, from U / U^T built off the master weights): only the
+        kernel-layout gradient buffer and its way back into G are made -- no fwd / tr copies, no transposes."""
         taps = k[0] * k[1] * k[2]
         Ipad = Ipad or I
         O = sum(O_list)
@@ -253,22 +259,29 @@ class Plan:
         saved_target = self.prep_target
         if self.late_prep and any(key.startswith("conv1." + u) for u in ("Conv3d_1a_7x7", "Conv3d_2b_1x1", "Conv3d_2c_3x3")):
             self.prep_target = "prep"          # needed before anything else runs
-        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, fwd=self.alloc(O * taps * Ipad), kg=self.alloc_kg(O * taps * Ipad), unprep=[])
+        w = dict(O=O, I=I, Ipad=Ipad, taps=taps, kg=self.alloc_kg(O * taps * Ipad), unprep=[])
         pl = self.next_prep_lane()
-        if Ipad != I:
-            self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst=self.prep_target, lane=pl)
-        if need_tr:
-            w["tr"] = self.alloc(I * taps * O)
+        if layouts:
+            w["fwd"] = self.alloc(O * taps * Ipad)
+            if Ipad != I:
+                self.emit(capi.OP_FILL, p=[w["fwd"]], l=[O * taps * Ipad], f=[0.0], lst=self.prep_target, lane=pl)
+            if need_tr:
+                w["tr"] = self.alloc(I * taps * O)
         o0 = 0
         for nm, Oi in zip(names, O_list):
             src = self.P(nm)
-            self.emit(capi.OP_TRANSPOSE, i=[Oi, I, taps, taps, Ipad, 0], l=[I * taps, taps * Ipad],
-                      p=[src, off(w["fwd"], o0 * taps * Ipad)], lst=self.prep_target, lane=pl)
-            if need_tr:
-                self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst=self.prep_target, lane=pl)
+            if layouts:
+                self.emit(capi.OP_TRANSPOSE, i=[Oi, I, taps, taps, Ipad, 0], l=[I * taps, taps * Ipad],
+                          p=[src, off(w["fwd"], o0 * taps * Ipad)], lst=self.prep_target, lane=pl)
+                if need_tr:
+                    self.emit(capi.OP_TRANSPOSE, i=[1, Oi, I * taps, I * taps, O, 0], l=[0, 0], p=[src, off(w["tr"], o0)], lst=self.prep_target, lane=pl)
             # grad back: kg [Oi][taps][Ipad] -> G [Oi][I][taps]  (flushed right after the wgrad, see flush_grad)
             w["unprep"].append((nm, (capi.OP_TRANSPOSE, [Oi, taps, I, Ipad, taps, self.acc], [], [off(w["kg"], o0 * taps * Ipad), self.G(nm)], [taps * Ipad, I * taps])))
             o0 += Oi
+        if layouts:
+            self.reg_weight(w["fwd"], O * taps * Ipad, self.prep_target, pl)
+            if need_tr:
+                self.reg_weight(w["tr"], I * taps * O, self.prep_target, pl)
         self.kw[key] = w
         self.prep_target = saved_target
         return w
@@ -283,6 +296,8 @@ class Plan:
         self.emit(capi.OP_TRANSPOSE, i=[1, I, O * taps, O * taps, I, 0], l=[0, 0], p=[src, w["fwd"]], lst=self.prep_target, lane=pl)
         self.emit(capi.OP_TRANSPOSE, i=[I, O, taps, taps, O, 0], l=[O * taps, taps * O], p=[src, w["tr"]], lst=self.prep_target, lane=pl)
         w["unprep"].append((name, (capi.OP_TRANSPOSE, [I, taps, O, O, taps, self.acc], [], [w["kg"], self.G(name)], [taps * O, O * taps])))
+        self.reg_weight(w["fwd"], O * taps * I, self.prep_target, pl)
+        self.reg_weight(w["tr"], I * taps * O, self.prep_target, pl)
         self.kw[name] = w
         return w
 
@@ -362,12 +377,16 @@ class Plan:
             return False
         T, H, W = x.thw
         tmin = 1 if os.environ.get("PICONS_WINO_T1", "1") != "0" else 2     # one frame (Mixed_4b..4f: only the centre temporal tap is real): -0.13 ms on the step
-        return T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(os.environ.get("PICONS_WINO_CMIN", "32")) and cout >= 64 and x.ld % 4 == 0
+        # the input gradient runs the same kernel with the roles swapped: its Ci is cout, read from a gradient tensor whose leading dimension is cout
+        return (T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(os.environ.get("PICONS_WINO_CMIN", "32")) and cout >= 64
+                and cout % 8 == 0 and x.ld % 4 == 0)
 
     def wino_weights(self, wname, O, I, need_tr):
         """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
         gradient, from its transpose with mirrored taps: strides + flip, no intermediate layout)."""
         nU = capi.lib().pc_wino_u_floats(O, I, 3)
+        if nU <= 0 or (need_tr and capi.lib().pc_wino_u_floats(I, O, 3) <= 0):
+            raise ValueError("Winograd form of %s: %d -> %d channels is not a shape the kernel takes" % (wname, I, O))
         u = dict(fwd=self.alloc(nU))
         src = self.P(wname)
         saved_target = self.prep_target
@@ -411,18 +430,61 @@ class Plan:
         and channels (transform-domain multiply-accumulates: 16 per 2x2 output tile, tap and channel pair, where the direct form does 36)."""
         return {name: {k: self.work.get((name, "wino_" + k), 0) for k in ("mfma", "executed")} for name in self.lists}
 
+    # ------------------------------------------------------------------ weight planes for the bf16-split conv kernel
+    def reg_weight(self, ref, nfloats, lst=None, lane=None):
+        """A kernel-layout weight buffer [ref, ref + nfloats) whose producing ops sit in list `lst` on lane `lane` (None: wherever the first
+        consumer runs).  conv_op splits it into bf16 planes the first time a launch that takes the bf16-split kernel reads it."""
+        self.wbufs.append(dict(ref=ref, n=int(nfloats), lst=lst, lane=lane, planes=None))
+
+    def _wbuf_of(self, w_ref):
+        for b in self.wbufs:
+            if b["ref"][0] == w_ref[0] and b["ref"][1] <= w_ref[1] < b["ref"][1] + 4 * b["n"]:
+                return b
+        return None
+
+    def maybe_x6(self, d, w_ref):
+        """The descriptor with PC_F_X6 if this launch takes the bf16-split kernel (the switch is on, the library says the shape fits, and the
+        weights are a registered kernel-layout buffer that can be split into planes), else unchanged."""
+        if not self.x6 or (d["flags"] & capi.F_X6) or self._wbuf_of(w_ref) is None:
+            return d
+        t = dict(D.trim_conv(d), flags=d["flags"] | capi.F_X6)
+        if not capi.lib().pc_conv_x6_ok(_cdesc(t)):
+            return d
+        return dict(d, flags=d["flags"] | capi.F_X6)
+
+    def planes_of(self, w_ref):
+        """-> (ref of the bf16 planes at w_ref's offset, plane stride in elements); the split op is emitted once per buffer, behind the
+        buffer's producers (same list, same lane) or, for a buffer made inside the forward / backward list, in front of its first reader."""
+        b = self._wbuf_of(w_ref)
+        if b["planes"] is None:
+            assert b["n"] % 8 == 0, "weight buffer of %d floats" % b["n"]
+            b["planes"] = self.alloc((3 * b["n"] + 1) // 2)
+            if b["lst"] in ("prep", "prep_late"):
+                self.emit(capi.OP_SPLIT_PLANES, p=[b["ref"], b["planes"]], l=[b["n"], b["n"]], lst=b["lst"], lane=b["lane"])
+            else:
+                self.emit(capi.OP_SPLIT_PLANES, p=[b["ref"], b["planes"]], l=[b["n"], b["n"]])
+        return (b["planes"][0], b["planes"][1] + (w_ref[1] - b["ref"][1]) // 2), b["n"]
+
     # ------------------------------------------------------------------ layers
     def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None):
         """alg: algorithmic FLOPs to book for this launch (default: the descriptor's own 2*M*N*K with all taps).
         Dgrad launches book the layer's FORWARD FLOPs once (alg_dgrad) and pass alg=0, so gather-form overheads
         (padding taps, the 28x28 gather of the 20x20 PrimaryCaps dgrad) never inflate the roofline numerator."""
         self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + (_conv_flops(d) if alg is None else alg)
+        d = self.maybe_x6(d, w_ref)
         t = D.trim_conv(d)
         self.issued[(self.cur, capi.OP_CONV)] = self.issued.get((self.cur, capi.OP_CONV), 0) + _conv_flops(t)
         w = conv_work(t)
+        fam = "x6_" if t["flags"] & capi.F_X6 else ""
         for key, v in (("mfma", w["issued"]), ("executed", w["executed"]), ("valid", w["valid"])):
-            self.work[(self.cur, key)] = self.work.get((self.cur, key), 0) + 2 * v
-        il = self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
+            self.work[(self.cur, fam + key)] = self.work.get((self.cur, fam + key), 0) + 2 * v
+        if w_ref[0] == "V" and not (t["flags"] & capi.F_X6):
+            raise RuntimeError("weights that exist as bf16 planes only met a launch that does not take the bf16-split kernel")
+        if t["flags"] & capi.F_X6:
+            wp, pstride = self.planes_of(w_ref)
+            il = self.emit(capi.OP_CONV_X6, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, wp, bias, cscale, out_ref, bnpart], l=[pstride])
+        else:
+            il = self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
         self.op_work[id(il)] = w          # keyed by the op's own int list (it survives the re-laning of finalize()): tools/launch_table.py
 
     def wgrad_op(self, d, p):
@@ -476,14 +538,14 @@ class Plan:
         Ci_real = self.pshape[pre + ".conv3d.weight"][1]          # 3 for the RGB stem, whose clip is padded to 4 channels
         othw = tuple(spec.same_out(x.thw[i], k[i], stride[i]) for i in range(3))
         pf = [spec.same_pad(x.thw[i], k[i], stride[i])[0] for i in range(3)]
-        w = self.prep_conv_weight([q + ".conv3d.weight" for q in pres], couts, Ci_real, k, need_dx, Ipad=Ci)
+        wino = len(pres) == 1 and Ci == Ci_real and self.wino_ok(x, cout, k, stride)
+        w = self.prep_conv_weight([q + ".conv3d.weight" for q in pres], couts, Ci_real, k, need_dx, Ipad=Ci, layouts=not wino)
         z = self.tensor(x.N, othw, cout, pre + ".z")
         y = out if out is not None else self.tensor(x.N, othw, cout, pre + ".y")
         stat = self.alloc(self.groups * 4 * cout)
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
-        wino = len(pres) == 1 and Ci == Ci_real and self.wino_ok(x, cout, k, stride)
         wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training) if wino else None
         tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
         tmap_b = (1, pf[0] - 2, stride[0])                 # input gradient (mirrored taps): frame (t + pad_front - 2 + kt) / s
@@ -505,6 +567,7 @@ class Plan:
         elif self.training:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART | (capi.F_CI3 if ci3 else 0), groups=self.groups)
             d["Ci_real"] = Ci_real
+            d = self.maybe_x6(d, w["fwd"])         # the tile (hence the partial rows) is the bf16-split kernel's where that kernel runs
             nrows = _bnpart_rows(d)
             part = self.alloc(nrows * 2 * cout)
             self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part)
@@ -652,8 +715,8 @@ class Plan:
 
     def conv_layer(self, name, x, cout, k, pad, act, out, need_dx=True):
         """Decoder skip convs conv28/conv56/conv112 (capsules_ucf101.py:380-384,490,497,501)."""
-        w = self.prep_conv_weight([name + ".weight"], [cout], x.C, k, need_dx)
         wino = act in (capi.ACT_NONE, capi.ACT_RELU) and self.wino_ok(x, cout, k, (1, 1, 1), pad)
+        w = self.prep_conv_weight([name + ".weight"], [cout], x.C, k, need_dx, layouts=not wino)
         if wino:
             othw = tuple(x.thw)
             wu = self.wino_weights(name + ".weight", cout, x.C, need_dx and self.training)
@@ -777,6 +840,8 @@ class Plan:
         w["wvt"] = self.alloc(SL.G * SL.w_g)                 # [g][Ci][ky][Co]  dgrad GEMM weight planes
         self.emit(capi.OP_WSPEC_FWD, i=[cout, Ci, KY, KX, SL.nu, SL.Ur], p=[w["fwd"], sm["tw"], w["wv"]], lst=self.prep_target)
         self.emit(capi.OP_WSPEC_FWD, i=[Ci, cout, KY, KX, SL.nu, SL.Ur], p=[w["tr"], sm["tw"], w["wvt"]], lst=self.prep_target)
+        self.reg_weight(w["wv"], SL.G * SL.w_g, self.prep_target, 0)
+        self.reg_weight(w["wvt"], SL.G * SL.w_g, self.prep_target, 0)
         xpl = self.alloc(SL.G * SL.x_g)
         tpl = self.alloc(SL.G * SL.t_g)
         self.emit(capi.OP_AXIS, i=D.flatten(SL.x_to_planes(), capi.AXIS_FIELDS), p=[x.ref, sm["F"], None, xpl])
@@ -889,12 +954,25 @@ class Plan:
             # 36.7 M-element weight), the gradient goes straight back.
             SL = spectral.Layout(N, xd.thw[1], xd.thw[2], xd.C, xd.ld, Cpc, caps_in.ld, KP, KP)
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
-            wpc = dict(wv=self.alloc(SL.G * SL.w_g),             # [g][Co][ky][Ci]  forward GEMM weight planes
-                       wvt=self.alloc(SL.G * SL.w_g))            # [g][Ci][ky][Co]  dgrad GEMM weight planes
             pl = self.next_prep_lane()
-            for nm, a0, cnt in pc_names:      # pose rows, then activation rows, of the same plane buffers: one lane
-                self.emit(capi.OP_WSPEC_MASTER_FWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[self.P(nm), sm["tw"], wpc["wv"], wpc["wvt"]],
-                          lst=self.prep_target, lane=pl)
+            nW = SL.G * SL.w_g
+            x6_pc = self.x6 and all(capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(dd), flags=dd["flags"] | capi.F_X6))) for dd in [SL.conv()] + SL.dgrad())
+            if x6_pc:
+                # the 2 x 167 M-element weight planes leave the producer as bf16 terms (6 B per element): no fp32 copy exists, the
+                # "fp32" references below are virtual addresses that only locate a group inside the planes
+                wpc = dict(wv=("V", 0), wvt=("V", 4 * nW))
+                pf, pt = self.alloc((3 * nW + 1) // 2), self.alloc((3 * nW + 1) // 2)
+                self.wbufs.append(dict(ref=wpc["wv"], n=nW, lst=None, lane=None, planes=pf))
+                self.wbufs.append(dict(ref=wpc["wvt"], n=nW, lst=None, lane=None, planes=pt))
+                for nm, a0, cnt in pc_names:
+                    self.emit(capi.OP_WSPEC_MASTER_PLANES, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur], l=[nW], p=[self.P(nm), sm["tw"], pf, pt],
+                              lst=self.prep_target, lane=pl)
+            else:
+                wpc = dict(wv=self.alloc(nW),             # [g][Co][ky][Ci]  forward GEMM weight planes
+                           wvt=self.alloc(nW))            # [g][Ci][ky][Co]  dgrad GEMM weight planes
+                for nm, a0, cnt in pc_names:      # pose rows, then activation rows, of the same plane buffers: one lane
+                    self.emit(capi.OP_WSPEC_MASTER_FWD, i=[cnt, a0, Cpc, xd.C, KP, KP, SL.nu, SL.Ur], p=[self.P(nm), sm["tw"], wpc["wv"], wpc["wvt"]],
+                              lst=self.prep_target, lane=pl)
         else:
             wpc = self.prep_conv_weight([nm for nm, _a, _c in pc_names], [cnt for _n, _a, cnt in pc_names], xd.C, (1, KP, KP), True)
             wpc["tio"] = self.alloc(KP * KP * xd.C * Cpc)       # [tap][ci][co]: GEMM weights of the col2im dgrad
@@ -1064,6 +1142,11 @@ class Plan:
         w5f = self.alloc(N * 8 * SP * 128)              # [n][z][slot][ci]   forward GEMM weights
         w5t = self.alloc(N * 8 * 128 * SP)              # [n][z][ci][slot]   dgrad GEMM weights
         self.emit(capi.OP_TAIL6_WEIGHTS, i=[N, 128], p=[wf, w5f, w5t])
+        self.reg_weight(w5f, N * 8 * SP * 128)
+        self.reg_weight(w5t, N * 8 * 128 * SP)
+        if self.x6:               # the planes are read on two lanes (interior class / border classes): made here, in front of the FORK
+            self.planes_of(w5f)
+            self.planes_of(w5t)
         cols = self.alloc(cat112.rows * SP)
         F_t6 = 2 * cat112.rows * 125 * 128
         # the class of the interior positions (z = 0) is 74 % of the work; the seven thin border classes are latency-bound
@@ -1301,6 +1384,12 @@ class Plan:
                         tab = self._job_table(self.multi_jobs[r[1]], bases)
                         keep.append(tab)
                         r = ("HOST", tab.ctypes.data)
+                    if r is not None and r[0] == "SJOBS":
+                        tab = np.zeros(len(r[1]), dtype=capi.SJOB_DTYPE)
+                        for w, (src, dst, n_, ps) in enumerate(r[1]):
+                            tab[w] = (bases[src[0]] + src[1], bases[dst[0]] + dst[1], n_, ps)
+                        keep.append(tab)
+                        r = ("HOST", tab.ctypes.data)
                     if r is not None and r[0] == "WJOBS":
                         tab = np.zeros(len(self.wjobs[r[1]]), dtype=capi.WJOB_DTYPE)
                         for w, (wd, wp) in enumerate(self.wjobs[r[1]]):
@@ -1324,7 +1413,7 @@ class Plan:
     def _merge_prep_transposes(self, lst, bases, keep):
         """The weight re-layouts that read master parameters are independent of each other: all of them on one lane
         become ONE launch (pc_transpose_multi, jobs passed by value) instead of ~80 seven-microsecond launches."""
-        res, pending = [], {}
+        res, pending, splits = [], {}, {}
 
         def flush():
             for lane in sorted(pending):
@@ -1333,10 +1422,15 @@ class Plan:
                 keep.append(tab)
                 res.append((capi.OP_TRANSPOSE_MULTI, [len(jobs)], [], [("HOST", tab.ctypes.data)], [], lane))
             pending.clear()
+            for lane in sorted(splits):          # the bf16 planes of the buffers those transposes filled: one launch per lane, behind them
+                res.append((capi.OP_SPLIT_PLANES_MULTI, [len(splits[lane])], [], [("SJOBS", splits[lane])], [], lane))
+            splits.clear()
         for op in lst:
-            if op[0] == capi.OP_TRANSPOSE and op[3][0][0] == "P":
+            if op[0] == capi.OP_SPLIT_PLANES:
+                splits.setdefault(op[5], []).append((op[3][0], op[3][1], op[4][0], op[4][1]))
+            elif op[0] == capi.OP_TRANSPOSE and op[3][0][0] == "P":
                 pending.setdefault(op[5], []).append(op)
-            elif op[0] in (capi.OP_FILL, capi.OP_FORK, capi.OP_WSPEC_MASTER_FWD, capi.OP_WINO_WEIGHTS):
+            elif op[0] in (capi.OP_FILL, capi.OP_FORK, capi.OP_WSPEC_MASTER_FWD, capi.OP_WSPEC_MASTER_PLANES, capi.OP_WINO_WEIGHTS):
                 res.append(op)           # fills precede the transposes into their buffer; the fork opens the region; the
                                          # master-layout weight planes touch nothing the transposes do
             else:
@@ -1351,6 +1445,10 @@ class Plan:
         `executed` = on real output rows x columns over the K each tile's block walks -- taps that are padding for a whole tile are
         skipped by the kernel and are NOT counted, padding taps inside a tile's tap box are --, `valid` = non-padding MACs only."""
         return {name: {k: self.work.get((name, k), 0) for k in ("mfma", "executed", "valid")} for name in self.lists}
+
+    def x6_flops_executed(self):
+        """The same three counts for the conv / dgrad launches that run on the bf16-split kernel (fp32-equivalent multiply-accumulates x 2)."""
+        return {name: {k: self.work.get((name, "x6_" + k), 0) for k in ("mfma", "executed", "valid")} for name in self.lists}
 
     def wgrad_flops_executed(self):
         """The same three counts for the weight-gradient launches (pc_wgrad_work)."""

@@ -142,6 +142,7 @@ class StepEngine:
         """Concat labeled+unlabeled, apply the shuffle (main_ucf101.py:65-79) and copy to the arena.
         drops: four (bs,C) scale arrays [d832 pass0, d128 pass0, d832 pass1, d128 pass1]."""
         p = self.plan
+        self._restore_input_ops()
         T = lambda a: torch.as_tensor(np.asarray(a) if not torch.is_tensor(a) else a)
         cat = lambda k: torch.cat([T(label_mb[k]), T(unlabel_mb[k])], dim=0)
         perm = torch.as_tensor(np.asarray(perm)).long()
@@ -181,6 +182,19 @@ class StepEngine:
              for x in drops]
         self.aview(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH).copy_(torch.cat([d[0], d[2]]).reshape(-1))
         self.aview(p.in_drop128, 2 * n * 128).copy_(torch.cat([d[1], d[3]]).reshape(-1))
+
+    # ------------------------------------------------------------------ the reference's minibatch contract, one step ahead
+    def host_stager(self):
+        """-> HostDictStager bound to this engine (created once)."""
+        if getattr(self, "_stager", None) is None:
+            self._stager = HostDictStager(self)
+        return self._stager
+
+    def _restore_input_ops(self):
+        """stage() feeds the fp32 arena staging buffers: undo a HostDictStager.commit() that pointed the clip conversion at its own."""
+        for idx, (flag, ptr) in getattr(self, "_to_ndhwc_orig", {}).items():
+            self.ops["fwd"][idx]["i"][0] = flag
+            self.ops["fwd"][idx]["p"][0] = ptr
 
     # ------------------------------------------------------------------ execution
     def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
@@ -325,3 +339,90 @@ class StepEngine:
     def train_step(self, label_mb, unlabel_mb, epoch, wt_ramp, perm, drops, lr=None, reducer=None):
         self.stage(label_mb, unlabel_mb, perm, drops)
         return self.run_staged(epoch, wt_ramp, lr, reducer)
+
+
+class HostDictStager:
+    """The reference's own minibatch contract taken one step ahead.  main_ucf101.py:52-79 gets two dicts of float64 HOST tensors from its
+    DataLoaders (datasets/ucf_dataloader.py:179-191: data / aug_data (n,3,8,H,W), loc_msk (n,1,8,H,W); 180 MB per bs-8 step), casts,
+    concatenates, shuffles and uploads them inside the step.  Here, while step i runs on the GPU:
+      prepare(i+1)  the host gathers the shuffled samples into a page-locked double buffer (one memcpy per sample: cat + randperm shuffle
+                    are the order of those copies) and enqueues ONE async H2D per tensor on a copy stream;
+      commit(i+1)   at the head of step i+1 the main stream waits for that upload and the step's first kernels read the float64 staging
+                    directly: pc_ncdhw_to_ndhwc converts f64 -> f32 while it re-lays the clip out (its op is re-pointed), the mask is cast
+                    into the arena, the per-sample scalars and Dropout3d draws follow in one small packed upload.
+    The host never waits for the GPU here; its only wait stays StepEngine.read_scalars()."""
+
+    def __init__(self, eng):
+        self.eng = eng
+        n, hw, T = eng.bs, eng.hw, spec.FRAMES
+        self.shapes = dict(data=(n, 3, T, hw, hw), aug_data=(n, 3, T, hw, hw), loc_msk=(n, 1, T, hw, hw))
+        self.pin = [{k: torch.empty(shp, dtype=torch.float64).pin_memory() for k, shp in self.shapes.items()} for _ in range(2)]
+        self.dev = [{k: torch.empty(shp, dtype=torch.float64, device=eng.dev) for k, shp in self.shapes.items()} for _ in range(2)]
+        self.nsmall = 2 * n + 2 * n * spec.TRUNK_OUT_CH + 2 * n * 128           # action, labeled flag, the four Dropout3d draws
+        self.pin_small = [torch.empty(self.nsmall, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.dev_small = [torch.empty(self.nsmall, dtype=torch.float32, device=eng.dev) for _ in range(2)]
+        self.copy_stream = torch.cuda.Stream(device=eng.dev)
+        self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.used = [False, False]
+        self.host = [None, None]
+        if not hasattr(eng, "_to_ndhwc_orig"):
+            eng._to_ndhwc_orig = {idx: (int(eng.ops["fwd"][idx]["i"][0]), int(eng.ops["fwd"][idx]["p"][0])) for idx in eng.plan.op_to_ndhwc}
+
+    def prepare(self, slot, label_mb, unlabel_mb, perm, drops):
+        """Host side of one minibatch: gather into the pinned slot in shuffled order, enqueue the uploads.  Returns at once."""
+        eng, n = self.eng, self.eng.bs
+        nl = len(label_mb["action"])
+        T_ = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))
+        perm = np.asarray(perm)
+        if self.used[slot]:
+            self.consumed[slot].synchronize()      # the step that read this slot's device copy was enqueued two steps ago: long done
+        for k in self.shapes:
+            lab, unl = T_(label_mb[k]), T_(unlabel_mb[k])
+            dst = self.pin[slot][k]
+            for j, src in enumerate(perm):         # torch.cat + the randperm shuffle of main_ucf101.py:65-79 as the ORDER of these copies
+                dst[j].copy_(lab[src] if src < nl else unl[src - nl])
+        act = torch.cat([T_(label_mb["action"]).reshape(-1), T_(unlabel_mb["action"]).reshape(-1)]).float()[perm]
+        if eng.jhmdb:                              # main_jhmdb.py:68-70
+            lab_flag = torch.cat([torch.ones(nl), torch.zeros(n - nl)])[perm]
+        else:
+            lab_flag = torch.cat([T_(label_mb["label_vid"]), T_(unlabel_mb["label_vid"])]).float()[perm]
+        ps = self.pin_small[slot]
+        ps[:n] = act
+        ps[n:2 * n] = lab_flag
+        o = 2 * n
+        for d, c in zip((drops[0], drops[2], drops[1], drops[3]), (spec.TRUNK_OUT_CH, spec.TRUNK_OUT_CH, 128, 128)):
+            ps[o:o + n * c] = T_(d).reshape(-1).float()
+            o += n * c
+        self.host[slot] = (lab_flag.to(torch.int32), act.clone())
+        with torch.cuda.stream(self.copy_stream):
+            for k in self.shapes:
+                self.dev[slot][k].copy_(self.pin[slot][k], non_blocking=True)
+            self.dev_small[slot].copy_(ps, non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        self.used[slot] = True
+
+    def commit(self, slot):
+        """Head of the step (main stream): wait for the slot's upload, point the clip conversion at its float64 staging, cast the mask
+        and scatter the small inputs into the arena."""
+        eng, p, n = self.eng, self.eng.plan, self.eng.bs
+        main = torch.cuda.current_stream(eng.dev)
+        main.wait_event(self.ready[slot])
+        fwd = eng.ops["fwd"]
+        for g, idx in enumerate(p.op_to_ndhwc):
+            fwd[idx]["i"][0] = 1                                              # src_is_f64
+            fwd[idx]["p"][0] = self.dev[slot]["data" if g == 0 else "aug_data"].data_ptr()
+        per = spec.FRAMES * eng.hw * eng.hw
+        eng.aview(p.in_seg, n * per).copy_(self.dev[slot]["loc_msk"].reshape(-1))         # f64 -> f32 on the device
+        ds = self.dev_small[slot]
+        eng.aview(p.in_cls, 2 * n).copy_(torch.cat([ds[:n], ds[:n]]))
+        eng.aview(p.in_labeled, 2 * n, torch.int32).copy_(torch.cat([ds[n:2 * n], ds[n:2 * n]]).to(torch.int32))
+        o, c8 = 2 * n, n * spec.TRUNK_OUT_CH
+        eng.aview(p.in_drop832, 2 * c8).copy_(ds[o:o + 2 * c8])
+        eng.aview(p.in_drop128, 2 * n * 128).copy_(ds[o + 2 * c8:o + 2 * c8 + 2 * n * 128])
+        eng.labels_host, eng.action_host = self.host[slot]
+
+    def release(self, slot):
+        """Behind the step that consumed the slot (its last reader is the loss list / the backward's dropout ops reading the arena -- the
+        float64 staging itself is only read by the first two kernels)."""
+        self.consumed[slot].record(torch.cuda.current_stream(self.eng.dev))

@@ -30,6 +30,22 @@ def test_header_symbols_exported(built):
     assert built.pc_version() >= 100
 
 
+def test_product_library_holds_no_wrong_result_diagnostics(built):
+    """the ablation / stamp variants of the GEMM kernels (some WRONG by design) and their switches are compiled only into
+    libpicons_diag.so (make diag); the shipped library does not even contain the variable names, and setting one without the diagnostic
+    library is refused by the loader instead of being ignored."""
+    import subprocess
+    import sys
+    blob = open(capi.LIB_PATH, "rb").read()
+    for word in (b"ABLATE", b"PICONS_WINO_VARIANT"):
+        assert word not in blob, "%s found in the product library" % word.decode()
+    code = "import picons_amd; from picons_amd import capi; capi.lib()"
+    env = dict(os.environ, PICONS_WGRAD_ABLATE="1", PYTHONPATH=ROOT)
+    env.pop("PICONS_DIAG_LIB", None)
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "diagnostic build" in p.stderr
+
+
 def test_struct_layouts_match_header(built):
     import ctypes as C
     assert C.sizeof(capi.ConvDesc) == 48 * 4

@@ -18,7 +18,8 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_TAIL6_GATHER: (3,), capi.OP_TAIL6_SCATTER: (1,), capi.OP_TAIL6_BIAS_SUMS: (1,), capi.OP_TAIL6_WGRAD_MAP: (1,),
           capi.OP_TAIL_GRADS: (6, 7, 8, 9), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
           capi.OP_WSPEC_MASTER_BWD: (2,), capi.OP_LOSS: (4, 5, 6, 7, 8, 9), capi.OP_SPREAD: (3, 4), capi.OP_ADAM: (0, 2, 3), capi.OP_COL2IM: (1,),
-          capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,)}
+          capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,),
+          capi.OP_CONV_X6: (4, 5), capi.OP_SPLIT_PLANES: (1,), capi.OP_WSPEC_MASTER_PLANES: (2, 3)}
 
 
 def _plan(lanes, bs=1, hw=112, early_adam=False):
@@ -60,10 +61,26 @@ def _accesses(p, op):
             out += [(refs[0], False), (refs[1], False), (refs[2], True)]
         return out
     assert kind in WRITES, "op kind %d has no write map" % kind
+
+    def weight_base(r):
+        """A reference into a registered kernel-layout weight buffer (a group's / a position class's slice) or into its bf16 planes ->
+        the buffer's start reference, which is the key its producer (transpose, split) writes under."""
+        for b in p.wbufs:
+            if b["ref"][0] == r[0] and b["ref"][1] <= r[1] < b["ref"][1] + 4 * b["n"]:
+                return b["ref"]
+            pl = b["planes"]
+            if pl is not None and pl[0] == r[0] and pl[1] <= r[1] < pl[1] + 6 * b["n"]:
+                return pl
+        return r
     for q, r in enumerate(ptrs):
         if r is None:
             continue
-        key = (r, tuple(ints[6:9]), tuple(ints[17:20])) if (kind == capi.OP_CONV and q == 4) else r
+        if kind in (capi.OP_CONV, capi.OP_CONV_X6) and q == 4:
+            key = (r, tuple(ints[6:9]), tuple(ints[17:20]))
+        elif kind in (capi.OP_CONV, capi.OP_CONV_X6) and q == 1:
+            key = weight_base(r)
+        else:
+            key = r
         out.append((key, q in WRITES[kind]))
     return out
 

@@ -3,6 +3,7 @@
 Run one process per mode:  PICONS_CONV_ABLATE=<0|1|2|3> python tools/ablate_conv.py
 (0 = product kernel; 1-3 are wrong-result ablations, see csrc/conv.hip launch_conv)."""
 import os
+os.environ.setdefault("PICONS_DIAG_LIB", "1")      # the ablation / stamp variants live in libpicons_diag.so only (make -C .../csrc diag)
 import sys
 import time
 

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic: wgrad_kernel on representative shapes; PICONS_WGRAD_ABLATE=1 removes the tile fetch from the K loop."""
 import os
+os.environ.setdefault("PICONS_DIAG_LIB", "1")      # the ablation / stamp variants live in libpicons_diag.so only (make -C .../csrc diag)
 import sys
 import time
 

@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 # quick look: kernel stats at 1 and 4 lanes, launch table, lane timeline  ->  gpurun_out/pq/
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

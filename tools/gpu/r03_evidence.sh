@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 # Round-3 evidence on the final code: kernel stats (4 lanes / 1 lane), launch table, lane timeline, PMC passes (each in its own run with
 # --kernel-trace only), bench variants.  Summaries are copied into profiles/ by the caller.
 export TMPDIR=/tmp

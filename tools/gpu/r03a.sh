@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 # Round 3, GPU call A: diagnostics (matrix-pipe ceiling in situ, conv shapes with counters) + the full GPU suite + the default bench.
 # Run from the repo root on the GPU box:  bash tools/gpu/r03a.sh
 export TMPDIR=/tmp

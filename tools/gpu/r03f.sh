@@ -1,4 +1,6 @@
 #!/bin/bash
+set -u
+: "${GRAFT_REPO_ROOT:?set GRAFT_REPO_ROOT (the repo root on the GPU box)}"
 # kernel stats (4 lanes) + single-lane trace for the launch table
 export TMPDIR=/tmp
 O=$GRAFT_REPO_ROOT/gpurun_out/r03f

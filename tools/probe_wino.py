@@ -3,6 +3,7 @@
     python tools/probe_wino.py            # runs every variant in a child process
 Variant 32 prints in-kernel s_memtime spans (prologue / K loop / epilogue, cycles per K chunk)."""
 import os
+os.environ.setdefault("PICONS_DIAG_LIB", "1")      # the ablation / stamp variants live in libpicons_diag.so only (make -C .../csrc diag)
 import subprocess
 import sys
 import time
