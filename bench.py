@@ -227,7 +227,10 @@ class StagedInputs:
             eng.stage(lab, unl, perm, drops)
             tk = timed_kind if (timed_kind is not None and time_every and i % time_every == 0) else None
             ntimed += tk is not None
-            eng.arm_early_adam(lr, on=(reducer is None or not reducer.active) and tk is None)
+            if reducer is not None and reducer.active and tk is None:
+                eng.arm_early_adam_dp(lr, reducer)
+            else:
+                eng.arm_early_adam(lr, on=(reducer is None or not reducer.active) and tk is None)
             eng.forward_backward(epoch, ramp, reducer, timed_kind=tk)
             gscale = 1.0
             if reducer is not None:
@@ -263,7 +266,10 @@ class DictInputs:
         for i in range(steps):
             slot = i & 1
             st.commit(slot)
-            eng.arm_early_adam(lr, on=reducer is None or not reducer.active)
+            if reducer is not None and reducer.active:
+                eng.arm_early_adam_dp(lr, reducer)
+            else:
+                eng.arm_early_adam(lr, on=True)
             eng.forward_backward(epoch, ramp, reducer)
             gscale = 1.0
             if reducer is not None:
@@ -443,20 +449,20 @@ def main():
 
     # ---- the same engine with every convolution on the fp32 MFMA kernels (PICONS_SPLIT=0), minibatch resident: what the bf16-split conv kernel buys
     split_off = None
-    if split_on and not a.no_extra_legs and reducer is None:
-        os.environ["PICONS_SPLIT"] = "0"
+    if split_on and not a.no_extra_legs and reducer is None and rank == 0:
+        # a child process of its own: a second engine in THIS process would find the four hardware queues taken by the first one's lanes and
+        # run 3 - 5 % slower for that reason alone; this process is idle meanwhile
+        import subprocess
+        cmd = [sys.executable, os.path.abspath(__file__), "--steps", str(n_leg), "--warmup", "3", "--bs", str(a.bs), "--epoch", str(a.epoch),
+               "--resident-inputs", "--no-extra-legs", "--no-kernel-timing", "--no-cpu-baseline"] + (["--gv"] if a.gv else []) + (["--jhmdb"] if a.jhmdb else [])
         try:
-            eng0 = pstep.StepEngine(args, bs=a.bs, hw=224, num_classes=ncls, jhmdb=a.jhmdb, device=dev)
-        finally:
-            os.environ["PICONS_SPLIT"] = "1"
-        eng0.stage(lab, unl, perm, drops)
-        for _ in range(3):
-            eng0.run_staged(a.epoch, ramp)
-        ms0, last0, _ = timed_resident(eng0, n_leg)
-        split_off = {"value": world * a.bs * n_leg / (ms0 / 1e3), "unit": "clips/s", "ms_per_step": ms0 / n_leg, "steps": n_leg, "loss_total": last0["total"],
-                     "what": "PICONS_SPLIT=0: every conv / dgrad launch on v_mfma_f32_32x32x2_f32 (the round-3 kernels), minibatch resident in HBM -- compare with `resident`"}
-        del eng0
-        torch.cuda.empty_cache()
+            cp = subprocess.run(cmd, env=dict(os.environ, PICONS_SPLIT="0"), capture_output=True, text=True, timeout=600, cwd=ROOT)
+            j0 = json.loads([ln for ln in cp.stdout.splitlines() if ln.strip()][-1])
+            split_off = {"value": j0["value"], "unit": "clips/s", "ms_per_step": j0["ms_per_step"], "steps": j0["steps"], "loss_total": j0["loss"]["total"],
+                         "what": "PICONS_SPLIT=0 in a process of its own: every conv / dgrad launch on v_mfma_f32_32x32x2_f32 (the round-3 kernels), minibatch "
+                                 "resident in HBM -- compare with `resident`"}
+        except Exception as e:          # the leg is evidence, not the metric: say what happened and go on
+            split_off = {"error": "%s: %s" % (type(e).__name__, e)}
 
     # ---- keep the GPU visibly busy for an external sampler: at least 3 s of back-to-back steps in this process, outside every timed region
     busy_steps = 0

@@ -170,6 +170,8 @@ typedef struct pc_wgrad_desc {
     int32_t reserved;
 } pc_wgrad_desc;
 #define PC_WG_CS3    1
+#define PC_WG_X6     2              /* the row-segment kernel (3 taps along w, padding 1) multiplies on the bf16 matrix cores: both operands split
+                                     * into three bf16 terms in registers, six products, fp32 accumulate (as pc_conv_fwd_x6); other routes ignore it */
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
 /* Host-only work accounting of one pc_conv_wgrad launch (no GPU call; see pc_conv_work).  out[5]: multiply-accumulates ISSUED to
  * the matrix cores, EXECUTED on real rows x columns, VALID (non-padding source positions), and the kernel family the problem is

@@ -72,7 +72,7 @@ SJOB_DTYPE = np.dtype([("src", np.uint64), ("planes", np.uint64), ("n", np.int64
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6 = 1, 2, 4, 8, 16, 32, 64, 128
-WG_CS3 = 1
+WG_CS3, WG_X6 = 1, 2
 
 _SIGS = {
     "pc_version": (i32, []),

@@ -1066,6 +1066,162 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
 }
 
 
+
+// ---- the same row-segment weight gradient with the multiplications on the bf16 matrix cores (csrc/conv_x6.hip has the scheme: three bf16
+// terms per fp32 operand, six products, hi / lo accumulators).  Both operands are activations here, so both are split in registers: a lane's
+// operand of v_mfma_f32_32x32x16_bf16 is eight consecutive POSITIONS of one channel -- eight ds_read_b32 down a column of the [position]
+// [channel] tile the LDS-DMA left (conflict-free: a half-wave reads 32 consecutive channels of one row) -- and the KW = 3 taps share them:
+// the ten source values at positions 8 g .. 8 g + 9 are read and split ONCE, tap 0 takes the packed pairs 0..3, tap 2 the pairs 1..4, tap 1
+// re-pairs them with four v_alignbit per plane.  Per k16 step and wave: 18 reads + 111 vector instructions beside 18 MFMAs.
+// One 32-channel tile of D and one 32-channel half of S per wave (all three taps): BM = 32 WMW, CSB = 32 (4 / WMW).  BKP (a multiple of
+// 16) positions per chunk; a segment that runs past the row end reads zeros (LDS-DMA out-of-range lanes).
+template <int BM, int BKP, int CSB, int WMW>
+__global__ __launch_bounds__(256, 2) void wgrad3_x6_kernel(const Wg3K p) {
+    constexpr int KW = 3, WNW = 4 / WMW, NS = BKP / 16;
+    static_assert(BM == 32 * WMW && CSB == 32 * WNW && BKP % 16 == 0, "one 32-channel tile of D and of S per wave");
+    constexpr int SPIECE = 256 / CSB;
+    constexpr int SROWS = (BKP + KW - 1 + SPIECE - 1) / SPIECE * SPIECE;
+    constexpr int DI = BKP * BM * 4 / 1024, SI = SROWS * CSB * 4 / 1024;
+    static_assert((BKP * BM * 4) % 1024 == 0, "D tile must be whole DMA pieces");
+    __shared__ __attribute__((aligned(16))) float Ds0[BKP][BM];          // one variable per ring slot: see wgrad3_kernel
+    __shared__ __attribute__((aligned(16))) float Ds1[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ss0[SROWS][CSB];
+    __shared__ __attribute__((aligned(16))) float Ss1[SROWS][CSB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WNW, wn = wave % WNW;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.mt * p.ncs * p.ntap_t * p.ntap_h;
+    int tile = lid % tiles;
+    const int slice = (lid / tiles) % p.nsplit, prob = lid / (tiles * p.nsplit);
+    const float* Dp = p.D + (size_t)prob * p.dbs;
+    const float* Sp = p.S + (size_t)prob * p.sbs;
+    float* gp = p.g + (size_t)prob * p.gbs;
+    const int mtile = tile % p.mt; tile /= p.mt;
+    const int csb = tile % p.ncs; tile /= p.ncs;
+    const int kh_ = tile % p.ntap_h, kt_ = tile / p.ntap_h;
+    const int m0 = mtile * BM, cs0 = csb * CSB;
+    const int c_begin = slice * p.chunks_per_split, c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+    if (c_begin >= c_end) return;
+
+    int q_seg = c_begin % p.nseg, q_h, q_t, q_n;
+    { int r = c_begin / p.nseg; q_h = r % p.H; r /= p.H; q_t = r % p.T; q_n = r / p.T; }
+    auto decode = [&](int& row_d, int& row_s, int& w0) -> bool {
+        w0 = q_seg * BKP;
+        row_d = ((q_n * p.T + q_t) * p.H + q_h) * p.W;
+        const int ts = q_t * p.istr_t + p.ioff_t + kt_, hs = q_h * p.istr_h + p.ioff_h + kh_;
+        row_s = ((q_n * p.Ts + ts) * p.Hs + hs) * p.Wsw;
+        if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == p.T) { q_t = 0; ++q_n; } } }
+        return (unsigned)ts < (unsigned)p.Ts && (unsigned)hs < (unsigned)p.Hs;
+    };
+    auto gload = [&](auto slot) -> bool {
+        constexpr int buf = decltype(slot)::value;
+        int row_d, row_s, w0;
+        if (!decode(row_d, row_s, w0)) return false;
+        float* ld = buf ? &Ds1[0][0] : &Ds0[0][0];
+        float* ls = buf ? &Ss1[0][0] : &Ss0[0][0];
+        const dma_rsrc_t rsD = dma_rsrc(Dp + (size_t)(row_d + w0) * p.ldd + m0);
+        const dma_rsrc_t rsS = dma_rsrc(Sp + ((long long)row_s + w0 - p.padw) * p.lds + cs0);
+#pragma unroll
+        for (int jj = 0; jj < (DI + 3) / 4; ++jj) {
+            const int i = jj * 4 + wave;
+            if (i >= DI) break;
+            const int e = i * 64 + lane, r = e / (BM / 4), c4 = e % (BM / 4);
+            const bool v = (w0 + r) < p.W && (m0 + c4 * 4) < p.Cd;                   // past the row end: zeros
+            glds16b(rsD, v ? (unsigned)(r * p.ldd + c4 * 4) * 4u : DMA_OOB, ld + i * 256);
+        }
+#pragma unroll
+        for (int jj = 0; jj < (SI + 3) / 4; ++jj) {
+            const int i = jj * 4 + wave;
+            if (i >= SI) break;
+            const int e = i * 64 + lane, r = e / (CSB / 4), c4 = e % (CSB / 4);
+            const int w = w0 - p.padw + r;
+            const bool v = r < BKP + KW - 1 && (unsigned)w < (unsigned)p.Wsw;
+            glds16b(rsS, v ? (unsigned)(r * p.lds + c4 * 4) * 4u : DMA_OOB, ls + i * 256);
+        }
+        return true;
+    };
+
+    f32x16 acc_hi[KW], acc_lo[KW];
+#pragma unroll
+    for (int j = 0; j < KW; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_hi[j][r] = 0.f; acc_lo[j][r] = 0.f; }
+    const int ml = wm * 32 + (lane & 31), csl = wn * 32 + (lane & 31), kg = lane >> 5;
+    typedef uint32_t u32;
+    // planes of one k16 step: A (D^T) [plane][4 regs]; B pairs p = 0..4 of the ten source values [plane][5]
+    auto load_split = [&](const float (*Dt)[BM], const float (*St)[CSB], int s, u32 (&pa)[3][4], u32 (&pb)[3][5]) {
+        const int r0 = 16 * s + 8 * kg;
+        float a[8], b[10];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = Dt[r0 + j][ml];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) b[j] = St[r0 + j][csl];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) x6_split2(a[2 * q], a[2 * q + 1], pa[0][q], pa[1][q], pa[2][q]);
+#pragma unroll
+        for (int q = 0; q < 5; ++q) x6_split2(b[2 * q], b[2 * q + 1], pb[0][q], pb[1][q], pb[2][q]);
+    };
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+    auto mma_step = [&](const u32 (&pa)[3][4], const u32 (&pb)[3][5]) {
+        u4 A[3], B[KW][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            A[pl] = u4{pa[pl][0], pa[pl][1], pa[pl][2], pa[pl][3]};
+            B[0][pl] = u4{pb[pl][0], pb[pl][1], pb[pl][2], pb[pl][3]};
+            B[2][pl] = u4{pb[pl][1], pb[pl][2], pb[pl][3], pb[pl][4]};
+            // tap 1: positions 1..8 = (hi of pair q, lo of pair q + 1)
+            B[1][pl] = u4{__builtin_amdgcn_alignbit(pb[pl][1], pb[pl][0], 16), __builtin_amdgcn_alignbit(pb[pl][2], pb[pl][1], 16),
+                          __builtin_amdgcn_alignbit(pb[pl][3], pb[pl][2], 16), __builtin_amdgcn_alignbit(pb[pl][4], pb[pl][3], 16)};
+        }
+#define WG_MF(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, X), __builtin_bit_cast(bf8, Y), Cc, 0, 0, 0)
+#pragma unroll
+        for (int j = 0; j < KW; ++j) {
+            WG_MF(A[0], B[j][2], acc_lo[j]); WG_MF(A[2], B[j][0], acc_lo[j]); WG_MF(A[1], B[j][1], acc_lo[j]);
+            WG_MF(A[0], B[j][1], acc_lo[j]); WG_MF(A[1], B[j][0], acc_lo[j]);
+            WG_MF(A[0], B[j][0], acc_hi[j]);
+        }
+#undef WG_MF
+    };
+    bool live = gload(std::integral_constant<int, 0>{});
+    __syncthreads();
+    auto chunk = [&](auto slot, int c) {
+        constexpr int buf = decltype(slot)::value;
+        const bool next_live = c + 1 < c_end ? gload(std::integral_constant<int, buf ^ 1>{}) : false;
+        if (live) {
+            const float (*Dt)[BM] = buf ? Ds1 : Ds0;
+            const float (*St)[CSB] = buf ? Ss1 : Ss0;
+            u32 pa[2][3][4], pb[2][3][5];
+            load_split(Dt, St, 0, pa[0], pb[0]);
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                if (s + 1 < NS) load_split(Dt, St, s + 1, pa[(s + 1) & 1], pb[(s + 1) & 1]);      // the next step's reads and split beside this step's MFMAs
+                mma_step(pa[s & 1], pb[s & 1]);
+            }
+        }
+        __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+        live = next_live;
+    };
+    for (int c = c_begin; c < c_end; c += 2) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c + 1);
+    }
+    const int tapbase = ((kt_ + p.wk0_t) * p.KH + kh_ + p.wk0_h) * KW;    // + kw
+#pragma unroll
+    for (int j = 0; j < KW; ++j) {
+        const f32x16 acc = acc_hi[j] + acc_lo[j];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (m >= p.Cd) continue;
+            float* dst = gp + ((size_t)m * p.taps_full + tapbase + j) * p.Cs + cs0 + csl;
+            if (p.store) *dst = acc[r];
+            else atomicAdd(dst, acc[r]);
+        }
+    }
+}
+
+
 // ---- weight gradient of a 4-channel source with stride SW along w (the stem: 7x7x7, stride 2, 3 channels padded to 4) --------
 // One tap of 4 channels is one 16-byte piece, so the generic kernel gathers its S tile piece by piece (64 taps x 16 positions
 // = 1024 pieces per chunk, each input piece fetched ~3x per chunk).  Here the K chunk is a segment of BKP positions of ONE
@@ -1238,7 +1394,7 @@ inline bool wg_wide(const pc_wgrad_desc* d, bool small_m) {
     return !wg_ablate() && Ntot >= 512 && (((wide_env & 1) && !small_m) || ((wide_env & 2) && small_m)) && P >= 65536;
 }
 // row-segment kernel geometry (shared by the launch and the accounting)
-struct Row3Geo { bool csb64, small_m; int bkp, bm, csb; };
+struct Row3Geo { bool csb64, small_m, x6; int bkp, bm, csb; };
 inline Row3Geo wg_row_geo(const pc_wgrad_desc* d, bool row9) {
     Row3Geo r;
     r.csb64 = d->Cs % 64 == 0;
@@ -1247,6 +1403,12 @@ inline Row3Geo wg_row_geo(const pc_wgrad_desc* d, bool row9) {
     r.bkp = row9 ? 20 : ((r.csb64 && r.small_m && d->Ws % 56 == 0) ? 56 : 28);
     r.bm = r.small_m ? 64 : 128;
     r.csb = r.csb64 ? 64 : 32;
+    r.x6 = !row9 && (d->flags & PC_WG_X6) != 0;
+    if (r.x6) {          // bf16-split kernel: one 32-channel tile of D and of S per wave, whole k16 steps per chunk (the segment's tail reads zeros)
+        r.bkp = d->Ws % 56 == 0 ? 64 : 32;
+        r.bm = r.csb64 ? 64 : 128;
+        r.small_m = r.csb64;
+    }
     return r;
 }
 // the generic kernel's launches for a problem: up to two row ranges [lo, hi) with 64- or 128-row tiles
@@ -1304,12 +1466,12 @@ extern "C" int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, d
         }
     } else if (route == WG_ROW3 || route == WG_ROW9) {
         const Row3Geo r = wg_row_geo(d, route == WG_ROW9);
-        const int nseg = d->Wq / r.bkp, mt = cdiv(d->Cd, r.bm), ncs = d->Cs / r.csb;
+        const int nseg = cdiv(d->Wq, r.bkp), mt = cdiv(d->Cd, r.bm), ncs = d->Cs / r.csb;
         for (int a = 0; a < d->ntap[0]; ++a)
             for (int b = 0; b < d->ntap[1]; ++b) {
                 const double chunks = (double)d->N * nb * V[0][a] * V[1][b] * nseg;
                 issued += chunks * r.bkp * (mt * (double)r.bm) * ((double)d->KW * r.csb * ncs);
-                executed += chunks * r.bkp * cd_real * ((double)d->KW * cs_real);
+                executed += chunks * (r.x6 ? (double)d->Wq / nseg : (double)r.bkp) * cd_real * ((double)d->KW * cs_real);       // real positions only
             }
     } else {
         const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
@@ -1409,11 +1571,11 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         const Row3Geo geo = wg_row_geo(d, row9);
         const bool csb64 = geo.csb64, small_m = geo.small_m;
         const int bkp = geo.bkp;
-        q.nseg = d->Wq / bkp;
+        q.nseg = cdiv(d->Wq, bkp);
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
-        q.mt = cdiv(d->Cd, small_m ? 64 : 128); q.ncs = d->Cs / (csb64 ? 64 : 32);
+        q.mt = cdiv(d->Cd, geo.bm); q.ncs = d->Cs / (csb64 ? 64 : 32);
         const int64_t tiles = (int64_t)q.mt * q.ncs * q.ntap_t * q.ntap_h;
-        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(rounds * (bkp == 56 ? 512 : 768) / (tiles * nprob)));
+        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(rounds * ((bkp == 56 || geo.x6) ? 512 : 768) / (tiles * nprob)));
         const int maxsplit = q.nchunks / 8 > 0 ? q.nchunks / 8 : 1;
         if (splitk > maxsplit) splitk = maxsplit;
         if (splitk < 1) splitk = 1;
@@ -1421,6 +1583,14 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.nsplit = cdiv(q.nchunks, q.chunks_per_split);
         q.store = d->splitk == -1;
         const dim3 grid((unsigned)(tiles * q.nsplit * nprob));
+        if (geo.x6) {
+            if (csb64 && bkp == 64) hipLaunchKernelGGL((wgrad3_x6_kernel<64, 64, 64, 2>), grid, dim3(256), 0, s, q);
+            else if (csb64) hipLaunchKernelGGL((wgrad3_x6_kernel<64, 32, 64, 2>), grid, dim3(256), 0, s, q);
+            else if (bkp == 64) hipLaunchKernelGGL((wgrad3_x6_kernel<128, 64, 32, 4>), grid, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((wgrad3_x6_kernel<128, 32, 32, 4>), grid, dim3(256), 0, s, q);
+            PC_CHECK_LAUNCH("wgrad3_x6_kernel");
+            return PC_OK;
+        }
         if (row9) hipLaunchKernelGGL((wgrad3_kernel<64, 20, 64, 2, 9>), grid, dim3(256), 0, s, q);
         else if (!csb64) hipLaunchKernelGGL((wgrad3_kernel<128, 28, 32, 4>), grid, dim3(256), 0, s, q);
         else if (small_m && bkp == 56) hipLaunchKernelGGL((wgrad3_kernel<64, 56, 64, 2>), grid, dim3(256), 0, s, q);

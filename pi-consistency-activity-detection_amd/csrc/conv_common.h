@@ -130,6 +130,25 @@ __device__ __forceinline__ void glds16b(dma_rsrc_t rs, unsigned voff, float* l) 
 }
 
 
+// two fp32 -> three packed bf16 pairs (x0 in the low half), round-to-nearest-even at every level: h = bf16(x), r = x - h (exact),
+// m = bf16(r), l = r - m (exact: at most 8 significant bits, so bf16(l) == l).  h + m + l == x bit for bit for |x| >= 2^-110 (below, the
+// lower terms are subnormal differences, which the vector ALU flushes) and |x| < 2^127 * 1.99 (above, h rounds to infinity).  Rounding to
+// nearest -- not truncation, which costs the same five instructions per pair and level -- makes the residuals signed: the three dropped
+// products m*l', l*m', l*l' (weight 2^-25 and below) then carry no common sign and do not bias the sum (measured on ReLU outputs:
+// truncation 1.2x the fp32 FMA chain's error against fp64, rounding 0.9x).
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));      // opaque to the compiler, which otherwise converts the low element a second time
+    return r;
+}
+__device__ __forceinline__ void x6_split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = cvt_pk_bf16(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = cvt_pk_bf16(r0, r1);
+    const float s0 = r0 - __uint_as_float(m << 16), s1 = r1 - __uint_as_float(m & 0xffff0000u);
+    l = cvt_pk_bf16(s0, s1);
+}
+
 }  // namespace
 
 // fp32 emulated on the bf16 matrix cores (conv_x6.hip): which launches take that kernel and with which tile -- ONE classification for

@@ -32,6 +32,31 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def check_replicas_agree(flat_params, group=None, what="parameters", rtol=0.0):
+    """Insurance for the first step of a data-parallel run: every rank must start from IDENTICAL parameters (the reference has no
+    multi-GPU loop; here a rank's state comes from its own seed / checkpoint load, dropin/main_ucf101.py).  All-reduces a 3-number
+    checksum of the flat buffer -- sum, sum of squares, and a position-weighted sum that sees permutations -- with MIN and MAX and
+    raises on every rank if they differ.  Float64 accumulation of the same fp32 values in the same order is bit-identical across ranks,
+    so the default tolerance is zero."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return True
+    x = flat_params.detach().double()
+    n = x.numel()
+    w = torch.arange(1, n + 1, device=x.device, dtype=torch.float64) / n
+    chk = torch.stack([x.sum(), (x * x).sum(), (x * w).sum()])
+    dev = chk.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    lo, hi = chk.to(dev).clone(), chk.to(dev).clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    spread = (hi - lo).abs()
+    bad = bool((spread > rtol * hi.abs().clamp_min(1e-300)).any())
+    if bad:
+        raise RuntimeError("data-parallel ranks do not hold the same %s: checksum (sum, sum of squares, weighted sum) spans %s .. %s across the "
+                           "%d ranks (this rank: %s) -- seed every rank alike or broadcast rank 0's state before training"
+                           % (what, lo.tolist(), hi.tolist(), dist.get_world_size(group), chk.tolist()))
+    return True
+
+
 class GradReducer:
     """Sums ranges of one flat gradient tensor across ranks, bucket by bucket.
 
@@ -56,6 +81,7 @@ class GradReducer:
         self.host = torch.empty(flat_grad.numel(), dtype=flat_grad.dtype).pin_memory() if self.host_staged else None
         self.handles = []
         self.launched = []
+        self._work = {}                  # bucket index -> the collective's Work handle (RCCL path; wait_buckets_on)
 
     def launch(self, i, streams=()):
         """Start bucket i's all-reduce behind everything enqueued so far on torch's current stream and on `streams`
@@ -76,9 +102,34 @@ class GradReducer:
                 if self.host_staged:
                     self.host[a:b].copy_(view, non_blocking=True)
                 else:
-                    self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    self._work[i] = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                    self.handles.append(self._work[i])
         else:
             self.handles.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def reduced_from(self):
+        """Lowest flat-buffer offset such that every bucket launched so far covers [offset, nparams) contiguously: gradients from there on
+        are (or will be, once the launched collectives finish) the cross-rank sums.  None when nothing is launched or RCCL is not the backend."""
+        if not self.active or not self.launched or self.host_staged or not self.cuda:
+            return None
+        spans = sorted((self.buckets[i][1], self.buckets[i][2]) for i in self.launched)
+        end = self.g.numel()
+        lo = end
+        for a, b in reversed(spans):
+            if b != lo:
+                break
+            lo = a
+        return lo if lo < end else None
+
+    def wait_buckets_on(self, stream):
+        """Make `stream` wait (device side, no host block) for the all-reduce of every bucket launched so far -- what an optimiser op
+        enqueued on that stream needs before it reads the summed gradients.  (A collective runs on the backend's own stream: Work.wait()
+        on a CUDA stream enqueues the dependency on the CURRENT stream and returns.)"""
+        with torch.cuda.stream(stream):
+            for i in self.launched:
+                w = self._work.get(i)
+                if w is not None:
+                    w.wait()
 
     def wait(self):
         """Join every launched bucket before the optimiser reads the gradient."""
@@ -95,6 +146,7 @@ class GradReducer:
             h.wait()
         self.handles = []
         self.launched = []
+        self._work = {}
         if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
 

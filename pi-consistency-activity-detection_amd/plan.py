@@ -447,6 +447,16 @@ class Plan:
         weights are a registered kernel-layout buffer that can be split into planes), else unchanged."""
         if not self.x6 or (d["flags"] & capi.F_X6) or self._wbuf_of(w_ref) is None:
             return d
+        if os.environ.get("PICONS_SPLIT_ONLY_SPECTRAL", "0") != "0" and w_ref[0] != "V":     # A/B diagnostics (tools/probe_tensor_grad.py)
+            return d
+        if w_ref[0] == "V":           # weights that exist as planes only: no choice
+            return dict(d, flags=d["flags"] | capi.F_X6) if capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(d), flags=d["flags"] | capi.F_X6))) else d
+        if self.cur not in os.environ.get("PICONS_SPLIT_LISTS", "fwd,bwd").split(","):
+            return d
+        if not int(os.environ.get("PICONS_SPLIT_CI_MIN", "0")) <= d["Ci"] <= int(os.environ.get("PICONS_SPLIT_CI_MAX", "1000000")):
+            return d
+        if not int(os.environ.get("PICONS_SPLIT_ROWS_MIN", "0")) <= d["N"] * d["Tq"] * d["Hq"] * d["Wq"] <= int(os.environ.get("PICONS_SPLIT_ROWS_MAX", "2000000000")):
+            return d
         t = dict(D.trim_conv(d), flags=d["flags"] | capi.F_X6)
         if not capi.lib().pc_conv_x6_ok(_cdesc(t)):
             return d
@@ -490,6 +500,8 @@ class Plan:
     def wgrad_op(self, d, p):
         """Emit a weight-gradient launch and book the FLOPs its (already trimmed) descriptor multiplies.  Inside a wgrad_group the
         launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op."""
+        if self.x6 and os.environ.get("PICONS_SPLIT_WGRAD", "1") != "0":
+            d = dict(d, flags=int(d.get("flags", 0)) | capi.WG_X6)       # honoured by the row-segment route only
         self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
         w = wgrad_work(d)
         for key, v in (("wg_mfma", w["issued"]), ("wg_executed", w["executed"]), ("wg_valid", w["valid"])):
@@ -956,7 +968,7 @@ class Plan:
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
             pl = self.next_prep_lane()
             nW = SL.G * SL.w_g
-            x6_pc = self.x6 and all(capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(dd), flags=dd["flags"] | capi.F_X6))) for dd in [SL.conv()] + SL.dgrad())
+            x6_pc = self.x6 and os.environ.get("PICONS_SPLIT_SPECTRAL", "1") != "0" and all(capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(dd), flags=dd["flags"] | capi.F_X6))) for dd in [SL.conv()] + SL.dgrad())
             if x6_pc:
                 # the 2 x 167 M-element weight planes leave the producer as bf16 terms (6 B per element): no fp32 copy exists, the
                 # "fp32" references below are virtual addresses that only locate a group inside the planes

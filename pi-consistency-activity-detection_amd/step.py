@@ -221,14 +221,39 @@ class StepEngine:
         if reducer is None or not reducer.active:
             run(o["bwd"])
         else:
+            k = p.op_adam_early if getattr(self, "_early_dp", False) else None
             done = 0
+
+            def run_to(end):
+                """bwd[done:end), stopping at the early Adam op: it may only read gradients whose all-reduce has been launched, and its lane
+                must first wait for those collectives (device-side events of the comm stream)."""
+                nonlocal done
+                if k is not None and done <= k < end:
+                    if k > done:
+                        run(o["bwd"][done:k])
+                    lo = reducer.reduced_from()
+                    e = o["bwd"][k]
+                    if lo is not None and lo < p.nparams:
+                        lo = max(lo, p.adam_split)
+                        for q, base in enumerate(("P", "G", "M", "V")):
+                            e["p"][q] = self.bases[base] + 4 * lo
+                        e["l"][0] = p.nparams - lo
+                        e["f"][4] = reducer.gscale
+                        self._early_lo = lo
+                        lane = int(e["lane"])
+                        reducer.wait_buckets_on(self.side[lane - 1] if lane > 0 else torch.cuda.current_stream(self.dev))
+                    else:
+                        e["l"][0] = 0
+                        self._early_lo = None
+                    done = k
+                if end > done:
+                    run(o["bwd"][done:end])
+                    done = end
             for i, (ready, _a, _b) in enumerate(reducer.buckets):
                 if ready > done:
-                    run(o["bwd"][done:ready])
-                    done = ready
+                    run_to(ready)
                 reducer.launch(i, self.side)
-            if done < len(o["bwd"]):
-                run(o["bwd"][done:])
+            run_to(len(o["bwd"]))
 
     def arm_early_adam(self, lr, on):
         """on: the backward list's Adam op (plan.early_adam) updates every parameter but the stem's beside the stem's weight gradient,
@@ -236,13 +261,28 @@ class StepEngine:
         after the all-reduce; or a caller that runs the lists by hand): the op is a no-op and adam() covers everything."""
         k = self.plan.op_adam_early
         self._early_armed = bool(on) and k is not None
+        self._early_dp, self._early_lo = False, None
         if k is None:
             return
         e = self.ops["bwd"][k]
-        e["l"][0] = self.plan.nparams - self.plan.adam_split if self._early_armed else 0
+        n0 = self.plan.adam_split
+        for q, base in enumerate(("P", "G", "M", "V")):
+            e["p"][q] = self.bases[base] + 4 * n0
+        e["l"][0] = self.plan.nparams - n0 if self._early_armed else 0
         e["i"][0] = self.step_count + 1
         e["f"][0] = lr
         e["f"][4] = 1.0
+
+    def arm_early_adam_dp(self, lr, reducer):
+        """Data parallelism (RCCL in place): the early Adam op covers the parameters whose gradient buckets have been LAUNCHED by the time the
+        backward reaches it (decoder, capsule head and most of the trunk: the buckets leave mid-backward), behind those collectives on its
+        own lane, with 1/world folded in; adam() then covers the rest -- the trunk's last bucket, reduced at the end of the backward.
+        forward_backward() fills in the range when it gets there."""
+        self.arm_early_adam(lr, on=False)
+        k = self.plan.op_adam_early
+        ok = (k is not None and reducer is not None and reducer.active and reducer.cuda and not reducer.host_staged
+              and os.environ.get("PICONS_EARLY_ADAM_DP", "1") != "0")
+        self._early_dp = bool(ok)
 
     def adam(self, lr, gscale=1.0):
         self.step_count += 1
@@ -250,9 +290,15 @@ class StepEngine:
         a["i"][0] = self.step_count
         a["f"][0] = lr
         a["f"][4] = gscale
-        a["l"][0] = self.plan.adam_split if getattr(self, "_early_armed", False) else self.plan.nparams
+        if getattr(self, "_early_armed", False):
+            a["l"][0] = self.plan.adam_split
+        elif getattr(self, "_early_dp", False) and getattr(self, "_early_lo", None) is not None:
+            a["l"][0] = self._early_lo            # the early op took [_early_lo, nparams) behind the launched buckets
+        else:
+            a["l"][0] = self.plan.nparams
         ops.run_ops(self.ops["adam"])
         self._early_armed = False
+        self._early_dp, self._early_lo = False, None
         if self.plan.op_adam_early is not None:
             self.ops["bwd"][self.plan.op_adam_early]["l"][0] = 0       # a backward replayed by hand must not step the optimiser
         for k in self.nbt:
@@ -298,9 +344,12 @@ class StepEngine:
         pred = self.aview(p.pred, 2 * self.bs * self.C).view(2 * self.bs, self.C)
         return out[:self.bs], out[self.bs:], pred[:self.bs]
 
-    def make_reducer(self, group=None, target_floats=3_000_000, force=False):
+    def make_reducer(self, group=None, target_floats=3_000_000, force=False, check=True):
+        """check: refuse to train if the ranks do not hold identical parameters (dist.check_replicas_agree: one 3-number all-reduce)."""
         from . import dist as pdist
         joined = os.environ.get("PICONS_BUCKETS_JOINED", "0") != "0"      # A/B switch: buckets only where lane 0 has joined their lane
+        if check:
+            pdist.check_replicas_agree(self.P, group)
         return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats, joined=joined), group, force=force)
 
     def collect_timing(self):
@@ -324,7 +373,10 @@ class StepEngine:
         scalars' copy, which is final before the backward starts.  Stream-ordered consumers (the next step, torch ops on the current
         stream) need nothing; anything else calls synchronize() first.  collect=False leaves the timing events of a timed step pending (the caller
         reads them with collect_timing() later, e.g. after its timed region: reading 212 events costs ~0.4 ms of host time)."""
-        self.arm_early_adam(self.args.lr if lr is None else lr, on=(reducer is None or not reducer.active) and timed_kind is None)
+        if reducer is not None and reducer.active and timed_kind is None:
+            self.arm_early_adam_dp(self.args.lr if lr is None else lr, reducer)
+        else:
+            self.arm_early_adam(self.args.lr if lr is None else lr, on=(reducer is None or not reducer.active) and timed_kind is None)
         self.forward_backward(epoch, wt_ramp, reducer, timed_kind)
         gscale = 1.0
         if reducer is not None:
@@ -366,6 +418,10 @@ class HostDictStager:
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
         self.host = [None, None]
+        # the 180 MB gather is 24 sample-sized memcpys: one thread moves ~5 GB/s (33 ms per step, more than the step itself); tensor.copy_
+        # releases the GIL, so a small pool brings it to a few ms
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("PICONS_STAGE_THREADS", "8")))
         if not hasattr(eng, "_to_ndhwc_orig"):
             eng._to_ndhwc_orig = {idx: (int(eng.ops["fwd"][idx]["i"][0]), int(eng.ops["fwd"][idx]["p"][0])) for idx in eng.plan.op_to_ndhwc}
 
@@ -377,11 +433,14 @@ class HostDictStager:
         perm = np.asarray(perm)
         if self.used[slot]:
             self.consumed[slot].synchronize()      # the step that read this slot's device copy was enqueued two steps ago: long done
+        jobs = []
         for k in self.shapes:
             lab, unl = T_(label_mb[k]), T_(unlabel_mb[k])
             dst = self.pin[slot][k]
             for j, src in enumerate(perm):         # torch.cat + the randperm shuffle of main_ucf101.py:65-79 as the ORDER of these copies
-                dst[j].copy_(lab[src] if src < nl else unl[src - nl])
+                jobs.append(self.pool.submit(dst[j].copy_, lab[src] if src < nl else unl[src - nl]))
+        for f in jobs:
+            f.result()
         act = torch.cat([T_(label_mb["action"]).reshape(-1), T_(unlabel_mb["action"]).reshape(-1)]).float()[perm]
         if eng.jhmdb:                              # main_jhmdb.py:68-70
             lab_flag = torch.cat([torch.ones(nl), torch.zeros(n - nl)])[perm]

@@ -146,3 +146,33 @@ def test_x6_refuses_what_it_cannot_run():
         ops.conv_fwd_x6(d, x, ops.split_planes(w), torch.empty(1, 1, 8, 8, 32, device=DEV))
     with pytest.raises(RuntimeError, match="PC_F_X6"):
         ops.conv_fwd(dict(d, flags=capi.F_X6), x, w, torch.empty(1, 1, 8, 8, 32, device=DEV))
+
+
+# (Ci, Co, thw, N, stride_t): the row-segment weight gradient's four bf16-split configurations (64- and 32-channel source blocks, 64- and
+# 32-position chunks) incl. a row that is not a whole number of chunks (W = 112: 64 + 48) and the temporal stride 2 of Conv3d_2c
+WG_CASES = [(64, 64, (2, 8, 112), 2, 1), (64, 192, (4, 6, 56), 2, 2), (96, 128, (2, 5, 28), 2, 1), (128, 256, (1, 28, 28), 4, 1), (192, 64, (2, 6, 56), 2, 1)]
+
+
+@pytest.mark.parametrize("Ci,Co,thw,N,st", WG_CASES)
+def test_x6_row_segment_wgrad_vs_fp64_and_native(Ci, Co, thw, N, st):
+    """PC_WG_X6: the 3x3x3 weight gradient with both operands split in registers (csrc/conv.hip wgrad3_x6_kernel), against an fp64 torch
+    gradient and against the native fp32-MFMA kernel on the same launch: its error must be no larger (operands as the step has them: a
+    gradient of mixed sign and a ReLU output)."""
+    g = torch.Generator().manual_seed(21)
+    k, s = (3, 3, 3), (st, 1, 1)
+    x = torch.relu(torch.randn(N, Ci, *thw, generator=g) * torch.exp(torch.randn(N, Ci, 1, 1, 1, generator=g)))
+    w = (torch.randn(Co, Ci, *k, generator=g) / np.sqrt(Ci * 27)).double().requires_grad_(True)
+    pads = [spec.same_pad(thw[i], k[i], s[i]) for i in range(3)]
+    xp = F.pad(x.double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    y = F.conv3d(xp, w, None, s)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = w.grad.reshape(Co, Ci, 27).permute(0, 2, 1)
+    othw = tuple(y.shape[2:]); pf = [p[0] for p in pads]
+    xg, dyg = cl(x), cl(dy)
+    wd = desc.wgrad(N, othw, Co, Co, thw, Ci, Ci, k, s, pf)
+    nat = ops.conv_wgrad(wd, dyg, xg, torch.zeros(Co, 27, Ci, device=DEV))
+    got = ops.conv_wgrad(dict(wd, flags=capi.WG_X6), dyg, xg, torch.zeros(Co, 27, Ci, device=DEV))
+    e_nat, e_x6 = _rel(nat.cpu(), ref), _rel(got.cpu(), ref)
+    assert e_x6 <= 1.05 * e_nat + 1e-9, "wgrad: bf16-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_x6, e_nat)
+    assert e_x6 < 5e-6

@@ -1,0 +1,69 @@
+"""Worker of tests/test_step_gpu.py::test_training_trajectory_vs_reference: three REAL steps of the fused engine (fresh minibatch each, Adam
+between them) against tests/golden/traj_bv5.npz -- the reference's own loop (main_ucf101.py:171-184, Adam of :416).
+    python tests/traj_worker.py <default|reducer> <out.json>
+default: the product default (four lanes, the early Adam op inside the backward list armed); reducer: the DP schedule through a one-rank
+RCCL group (segmented backward, bucket all-reduces, the early Adam behind the launched buckets, 1/world in the optimiser)."""
+import ast
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import picons_amd  # noqa: F401
+from picons_amd import step as pstep, synthetic
+
+mode, out_path = sys.argv[1], sys.argv[2]
+S = np.load(os.path.join(ROOT, "tests", "golden", "traj_bv5.npz"))
+bs, nsteps, lr = int(S["bs"]), int(S["nsteps"]), float(S["lr"])
+akw = dict(ast.literal_eval(str(S["args"])))
+args = pstep.default_args(**{k: v for k, v in akw.items() if k in vars(pstep.default_args())})
+args.lr = lr
+eng = pstep.StepEngine(args, bs=bs, hw=224, num_classes=24, device="cuda:0")
+red = None
+if mode == "reducer":
+    torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
+    red = eng.make_reducer(force=True)
+res = dict(mode=mode, lanes=eng.plan.lanes, early_adam_op=eng.plan.op_adam_early is not None, steps=[])
+F = lambda k: float(S[k])
+for s_ in range(nsteps):
+    lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=int(S["stepids"][s_]), num_classes=24)
+    got = eng.train_step(lab, unl, int(S["epoch"]), float(S["ramp"]), perm, drops, lr=lr, reducer=red)
+    _out, _flip, pred = eng.outputs()
+    eng.synchronize()
+    p32, p64 = torch.from_numpy(S["s%d::predicted_action" % s_]), torch.from_numpy(S["f64::s%d::predicted_action" % s_])
+    res["steps"].append(dict(
+        # distance of this engine and of the reference's own fp32 run from the reference's fp64 run, and the two fp32 runs from each other
+        loss_vs_f64={k: abs(got[k] - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
+        ref32_vs_f64={k: abs(F("s%d::%s" % (s_, k)) - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
+        loss_vs_ref32={k: abs(got[k] - F("s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
+        logits_vs_f64=float((pred.cpu().double() - p64).abs().max()), logits_ref32_vs_f64=float((p32.double() - p64).abs().max()),
+        logits_vs_ref32=float((pred.cpu() - p32).abs().max()), total=got["total"]))
+sd = eng.state_dict()
+res["bufs"], res["params"], res["nbt"] = {}, {}, {}
+state0 = synthetic.init_state(seed=47, num_classes=24, conditioned=True)
+for k in S.files:
+    if k.startswith("buf::"):
+        if k.endswith("num_batches_tracked"):
+            res["nbt"][k[5:]] = [int(sd[k[5:]]), int(S[k])]
+        else:
+            r64 = torch.from_numpy(S["f64::" + k])
+            res["bufs"][k[5:]] = dict(vs_f64=float((sd[k[5:]].cpu().double() - r64).abs().max()), ref32_vs_f64=float((torch.from_numpy(S[k]).double() - r64).abs().max()),
+                                      scale=float(r64.abs().max()))
+    if k.startswith("param::"):
+        got = sd[k[7:]].cpu().double().numpy(); r32 = S[k].astype(np.float64); r64 = S["f64::" + k]; init = np.asarray(state0[k[7:]], np.float64)
+        res["params"][k[7:]] = dict(mean_vs_f64=float(np.abs(got - r64).mean()), ref32_mean_vs_f64=float(np.abs(r32 - r64).mean()), moved=float(np.abs(r64 - init).mean()),
+                                    max_vs_f64=float(np.abs(got - r64).max()), frac_over_lr=float((np.abs(got - r64) > lr).mean()),
+                                    ref32_frac_over_lr=float((np.abs(r32 - r64) > lr).mean()))
+names = [str(x) for x in S["param_names"]]
+norms = {n: float(sd[n].double().norm()) for n in names}
+# every parameter tensor's norm after the last step: distance from the fp64 run beyond 3x the reference's own fp32 distance, relative to max(norm, 1)
+# (biases start at zero: after three steps their norm IS the handful of +-lr moves, sign noise included)
+res["param_norm_excess"] = max((abs(norms[n] - float(r64)) - 3 * abs(float(r32) - float(r64))) / max(float(r64), 1.0)
+                               for n, r32, r64 in zip(names, S["param_norms"], S["f64::param_norms"]))
+res["step_count"] = eng.step_count
+json.dump(res, open(out_path, "w"), indent=1)
+if red is not None:
+    torch.distributed.destroy_process_group()

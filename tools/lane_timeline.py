@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Where is the chip under-filled during a multi-lane step?  Reads a rocprofv3 --kernel-trace csv of `bench.py` (four lanes),
-takes the last full step (between the last two adam_kernel dispatches) and prints
+takes one full step -- from the first kernel behind the previous step's last adam_kernel (the weight-layout prep in front of the clip's
+to_ndhwc_kernel pair) to the step's own last adam_kernel; with the early Adam a step has TWO adam_kernel dispatches, so the windows are
+found from the to_ndhwc pairs, not from the optimiser -- and prints
 
   * per stream: kernels, busy time, share of the step;
   * the step's wall time split by how many CU slots the kernels running at that instant could fill at most
@@ -25,7 +27,7 @@ def clean(name):
 
 # rocprofv3's dispatch record does not carry dynamic LDS and reports allocation granules, so the GEMM and EM kernels' resident
 # blocks per CU come from their launch code (conv.hip: __launch_bounds__(256, 2), 3 for the small-tile wgrad variants; caps.hip)
-OVERRIDE = (("wgrad4_kernel", 3), ("wgrad_kernel<64,", 3), ("wgrad_kernel<128, 256", 3), ("conv_gemm", 2), ("wgrad", 2), ("em_fwd", 1), ("em_bwd", 1))
+OVERRIDE = (("conv_x6_kernel<256", 1), ("conv_x6_kernel<64, 64", 3), ("conv_x6_kernel", 2), ("wgrad4_kernel", 3), ("wgrad_kernel<64,", 3), ("wgrad_kernel<128, 256", 3), ("conv_gemm", 2), ("wgrad", 2), ("em_fwd", 1), ("em_bwd", 1))
 
 
 def resident(r):
@@ -46,8 +48,10 @@ def resident(r):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("trace"); ap.add_argument("--thresh", type=float, default=0.6); ap.add_argument("--out")
-    ap.add_argument("--window", type=int, default=-1, help="which step of the trace (index into the windows between adam_kernel dispatches; "
-                    "-1 = the last; the last step of a short profiled run can carry host stalls of the profiler's own)")
+    ap.add_argument("--window", type=int, default=-1, help="which step of the trace (-1 = the last complete one; the last step of a short profiled "
+                    "run can carry host stalls of the profiler's own)")
+    ap.add_argument("--expect-ms", type=float, default=0.0, help="the bench's ms_per_step: fail if the window found is shorter than half of it "
+                    "(a window that is not a step proves nothing)")
     ap.add_argument("--by-lane", type=int, default=0, help="also print, per stream, the N kernels with the largest summed duration in this step")
     ap.add_argument("--sequence", type=int, default=-1, help="print the dispatches of this stream id in order (start offset, duration, kernel, blocks, "
                     "kernels of other streams live at its start)")
@@ -55,10 +59,24 @@ def main():
     rows = [r for r in csv.DictReader(open(a.trace)) if r["Kind"] == "KERNEL_DISPATCH"]
     for r in rows:
         r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    rows.sort(key=lambda r: r["s"])
     adams = sorted(r["e"] for r in rows if "adam_kernel" in r["Kernel_Name"])
-    assert len(adams) >= 2, "need two steps in the trace"
-    wins = list(zip(adams, adams[1:]))
+    nd = [r["s"] for r in rows if "to_ndhwc_kernel" in r["Kernel_Name"]]
+    heads = [t for i, t in enumerate(nd) if i == 0 or t - nd[i - 1] > 2_000_000]      # first to_ndhwc of every step (the pair is microseconds apart)
+    assert len(heads) >= 2 and adams, "need two steps in the trace"
+    wins = []
+    for i in range(len(heads)):
+        prev_adam = max([e for e in adams if e <= heads[i]], default=None)
+        nxt_head = heads[i + 1] if i + 1 < len(heads) else None
+        last_adam = max([e for e in adams if e > heads[i] and (nxt_head is None or e <= nxt_head)], default=None)
+        if prev_adam is None or last_adam is None:
+            continue
+        start = min(r["s"] for r in rows if r["s"] >= prev_adam and r["s"] <= heads[i])
+        wins.append((start, last_adam))
+    assert wins, "no complete step in the trace"
     t0, t1 = wins[a.window]
+    if a.expect_ms and (t1 - t0) / 1e6 < 0.5 * a.expect_ms:
+        sys.exit("lane_timeline: the window found is %.3f ms, the step takes %.3f ms: not a step" % ((t1 - t0) / 1e6, a.expect_ms))
     step = [r for r in rows if r["s"] >= t0 and r["e"] <= t1]
     out = []
     out.append("step window %.3f ms, %d kernel dispatches" % ((t1 - t0) / 1e6, len(step)))

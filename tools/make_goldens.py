@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running THE REFERENCE ITSELF on CPU (authoring container only).
 
-    python tools/make_goldens.py [--only stages|masks|steps]
+    python tools/make_goldens.py [--only stages|masks|steps|traj]
 
 Fixtures are data only (inputs/expected outputs); nothing of the reference's source travels.
 Each file records torch version and thread count (results differ across thread counts,
@@ -281,6 +281,85 @@ def gen_steps(only_tags=None):
         save(case[0] + ".npz", d)
 
 
+# ----------------------------------------------------------------------------- a training trajectory
+TRAJ_STEPIDS = (20, 21, 22)
+TRAJ_PARAMS = ["conv_caps.beta_u", "conv_caps.beta_a", "smooth.weight", "smooth.bias", "upsample4.bias", "conv28.bias", "primary_caps.a.bias",
+               "conv1.Conv3d_1a_7x7.bn.weight", "conv1.Conv3d_1a_7x7.bn.bias", "conv1.Mixed_4f.b3b.bn.weight", "conv1.Mixed_3b.b1b.bn.bias",
+               "conv1.Mixed_4f.b0.conv3d.weight", "conv_caps.weights"]
+TRAJ_BUFS = ["conv1.Conv3d_1a_7x7", "conv1.Conv3d_2c_3x3", "conv1.Mixed_3b.b1b", "conv1.Mixed_4c.b0", "conv1.Mixed_4f.b3b"]
+
+
+def gen_trajectory(bs=2, nsteps=3):
+    """The reference's own training loop for `nsteps` steps (main_ucf101.py:171-184: zero_grad -> train_model_interface -> backward ->
+    optimizer.step(), optimizer = Adam(lr 1e-4, weight_decay 0, eps 1e-6) of main_ucf101.py:416), a FRESH minibatch per step, scripted
+    permutation / dropout draws -- once in fp32 and once in fp64 (the anchor: Adam's first updates are +-lr per element whatever the
+    gradient's size, so two fp32 implementations whose gradient NOISE differs drift apart from step 2 on; the fp64 run says how far the
+    reference's own fp32 arithmetic is from the exact trajectory).  Stored per run: the loss scalars and class predictions of every step,
+    the BatchNorm running statistics and num_batches_tracked after 2 * nsteps forward passes, a few small parameters and the norm of every
+    parameter after the last step."""
+    import importlib
+    import torch.nn as nn
+    from oracle.step import default_args
+    from oracle.losses import exp_rampup
+    t0 = time.time()
+    lr = 1e-4
+    epoch, ramp = 1, exp_rampup(100)(1)
+    args = default_args(bv=True, n_frames=5, wt_cons=0.1)
+    d = dict(bs=np.array(bs), nsteps=np.array(nsteps), stepids=np.array(TRAJ_STEPIDS[:nsteps]), lr=np.array(lr), epoch=np.array(epoch), ramp=np.array(ramp),
+             args=np.array(repr(sorted(vars(args).items()))))
+
+    def run(double, pre):
+        ref_import.install_shims(double=double)
+        from models.capsules_ucf101 import CapsNet
+        from utils.losses import SpreadLoss, DiceLoss
+        state = synthetic.init_state(seed=47, num_classes=24, conditioned=True)
+        model = CapsNet(pt_path=ref_import.synthetic_charades(state))
+        model.load_state_dict({k: torch.from_numpy(np.array(v)) for k, v in state.items()})
+        if double:
+            model.double()
+            model.conv_caps.ln_2pi = model.conv_caps.ln_2pi.double()
+        model.train(True); model.training = True
+        main = importlib.import_module("main_ucf101")
+        main.model = model
+        main.criterion_cls = SpreadLoss(num_class=24, m_min=0.2, m_max=0.9)
+        main.criterion_seg_1 = nn.BCEWithLogitsLoss(size_average=True)
+        main.criterion_seg_2 = DiceLoss()
+        opt = torch.optim.Adam(model.parameters(), lr=lr, weight_decay=0, eps=1e-6)          # main_ucf101.py:416
+        orig_randperm = torch.randperm
+        for s in range(nsteps):
+            lab, unl, perm, drops = synthetic.make_step_inputs(bs, rank=0, step=TRAJ_STEPIDS[s], num_classes=24)
+            model.dropout3d = ref_import.ScriptedDropout(drops)
+            tomb = lambda mb: {k: torch.from_numpy(v) for k, v in mb.items()}
+            opt.zero_grad()
+            torch.randperm = lambda n, *a, **k: torch.from_numpy(perm.copy())
+            try:
+                out = main.train_model_interface(args, tomb(lab), tomb(unl), epoch, ramp)
+            finally:
+                torch.randperm = orig_randperm
+            output, pred_action, _seg, _act, total, loc, cls, cons = out
+            total.backward()
+            opt.step()
+            for k, v in (("total", total), ("loc", loc), ("cls", cls), ("cons", cons), ("predicted_action", pred_action),
+                         ("output_frame_sum", output.sum(dim=(-1, -2)))):
+                d["%ss%d::%s" % (pre, s, k)] = v
+            print("%strajectory step %d: total %.6f loc %.6f cls %.6f cons %.6f  (%.0f s)" % (pre, s, float(total), float(loc), float(cls), float(cons), time.time() - t0))
+        sd = model.state_dict()
+        for p_ in TRAJ_BUFS:
+            for nm in ("running_mean", "running_var", "num_batches_tracked"):
+                d["%sbuf::%s.bn.%s" % (pre, p_, nm)] = sd["%s.bn.%s" % (p_, nm)]
+        params = dict(model.named_parameters())
+        for n in TRAJ_PARAMS:
+            d["%sparam::%s" % (pre, n)] = params[n].detach()
+        d[pre + "param_names"] = np.array(list(params.keys()))
+        d[pre + "param_norms"] = np.array([float(p.detach().double().norm()) for p in params.values()])
+        d[pre + "param_delta_norms"] = np.array([float((p.detach().double() - torch.from_numpy(np.array(state[n])).double()).norm()) for n, p in params.items()])
+    run(False, "")
+    run(True, "f64::")
+    ref_import.install_shims(double=False)
+    d["seconds"] = np.array(time.time() - t0)
+    save("traj_bv5.npz", d)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
@@ -295,3 +374,5 @@ if __name__ == "__main__":
         gen_masks()
     if a.only in (None, "steps"):
         gen_steps(a.steps.split(",") if a.steps else None)
+    if a.only in (None, "traj"):
+        gen_trajectory()
