@@ -753,7 +753,9 @@ struct WgK {
     int mt, ntl;                     // tiles along Cd and along the columns; the grid is 1-D: mt * ntl * problems * slices blocks
 };
 
-template <int BM, int BN, int ABL, int KB>
+// X6: the multiplications on the bf16 matrix cores (conv_x6.hip's scheme; both operands are activations, so both are split in registers: a
+// lane's MFMA operand is eight consecutive positions of one column of the [position][column] tiles, read with eight ds_read_b32)
+template <int BM, int BN, int ABL, int KB, bool X6 = false, bool HILO = true, bool ALLOW_PIPE = true>
 __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     constexpr int BK = KB;                           // positions per chunk (shadows the file-level BK)
     constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
@@ -841,12 +843,13 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     };
 
     f32x16 acc[TM][TN];
+    f32x16 acc_lo[(X6 && HILO) ? TM : 1][(X6 && HILO) ? TN : 1];          // X6: `acc` takes the h*h products, acc_lo the five small ones (conv_x6.hip)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if constexpr (X6 && HILO) acc_lo[i][j][r] = 0.f; }
 
     ptab_fill(c_begin);
     ptab_fill(c_begin + 1);
@@ -858,6 +861,60 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
         const int buf = (ABL >= 1 && ABL <= 3) ? 0 : ((c - c_begin) & 1);
         if (!ABL || ABL >= 4) ptab_fill(c + 2);
         if ((!ABL || ABL == 4 || ABL == 5) && c + 1 < c_end) gload(c + 1, buf ^ 1);   // 4: D tile only, 5: S tile only, 6: position table only
+        if constexpr (X6) {
+            static_assert(BK % 16 == 0 && ABL == 0, "whole k16 steps");
+            typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+            typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+            auto load_split = [&](int s16, u4 (&A)[TM][3], u4 (&B)[TN][3]) {
+                const int r0 = 16 * s16 + 8 * kh;
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = Ds[buf][r0 + q][ml + i * 32];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { uint32_t h_, m_, l_; x6_split2(v[2 * q], v[2 * q + 1], h_, m_, l_); A[i][0][q] = h_; A[i][1][q] = m_; A[i][2][q] = l_; }
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    float v[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) v[q] = Ss[buf][r0 + q][nl + j * 32];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { uint32_t h_, m_, l_; x6_split2(v[2 * q], v[2 * q + 1], h_, m_, l_); B[j][0][q] = h_; B[j][1][q] = m_; B[j][2][q] = l_; }
+                }
+            };
+#define WG_MF(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, X), __builtin_bit_cast(bf8, Y), Cc, 0, 0, 0)
+            auto mma = [&](const u4 (&A)[TM][3], const u4 (&B)[TN][3]) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x16& lo = HILO ? acc_lo[HILO ? i : 0][HILO ? j : 0] : acc[i][j];
+                        WG_MF(A[i][0], B[j][2], lo); WG_MF(A[i][2], B[j][0], lo); WG_MF(A[i][1], B[j][1], lo);
+                        WG_MF(A[i][0], B[j][1], lo); WG_MF(A[i][1], B[j][0], lo);
+                        WG_MF(A[i][0], B[j][0], acc[i][j]);
+                    }
+            };
+            constexpr bool PIPE = ALLOW_PIPE && (TM + TN) * 24 + TM * TN * (HILO ? 32 : 16) <= 200;       // both plane sets + the accumulators fit beside two waves per SIMD
+            if constexpr (PIPE) {
+                u4 A[2][TM][3], B[2][TN][3];
+                load_split(0, A[0], B[0]);
+#pragma unroll
+                for (int s16 = 0; s16 < BK / 16; ++s16) {
+                    if (s16 + 1 < BK / 16) load_split(s16 + 1, A[(s16 + 1) & 1], B[(s16 + 1) & 1]);      // the next step's reads and split beside this step's MFMAs
+                    mma(A[s16 & 1], B[s16 & 1]);
+                }
+            } else {
+#pragma unroll
+                for (int s16 = 0; s16 < BK / 16; ++s16) {
+                    u4 A[TM][3], B[TN][3];
+                    load_split(s16, A, B);
+                    mma(A, B);
+                }
+            }
+#undef WG_MF
+        } else
 #pragma unroll
         for (int ks = 0; ks < BK / 2; ++ks) {
             float af[TM], bf[TN];
@@ -872,6 +929,12 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
         if (ABL < 3) __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+    }
+    if constexpr (X6 && HILO) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += acc_lo[i][j];
     }
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -898,6 +961,10 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
 template <int BM, int BN, int ABL = 0, int KB = 32>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     wgrad_body<BM, BN, ABL, KB>(p, xcd_remap(blockIdx.x, gridDim.x));
+}
+template <int BM, int BN, bool HILO = true, bool ALLOW_PIPE = true>
+__global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgK p) {
+    wgrad_body<BM, BN, 0, 32, true, HILO, ALLOW_PIPE>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Several weight-gradient problems in ONE grid (pc_conv_wgrad_multi): the wgrads of one Inception module, or the eight position
@@ -1388,6 +1455,7 @@ inline WgRoute wg_route(const pc_wgrad_desc* d) {
 }
 // 256-column tiles with 16-position chunks for the long-K launches of the generic kernel (PICONS_WGRAD_WIDE bit 0: 128-row, bit 1: 64-row tiles)
 inline bool wg_wide(const pc_wgrad_desc* d, bool small_m) {
+    if (d->flags & PC_WG_X6) return false;          // the bf16-split kernel keeps 128-column tiles (two accumulators per tile)
     static const int wide_env = getenv("PICONS_WGRAD_WIDE") ? atoi(getenv("PICONS_WGRAD_WIDE")) : 3;
     const int64_t P = (int64_t)d->N * d->Tq * d->Hq * d->Wq;
     const int Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
@@ -1646,7 +1714,16 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
         } else
 #endif
-        if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
+        if (d->flags & PC_WG_X6) {
+            // reserved bit 2 (tests / tools only): one accumulator per tile instead of the hi / lo pair -- to measure what the pair buys
+            const bool one = (d->flags & 4) != 0;
+            static const bool nopipe = getenv("PICONS_WGRAD_X6_NOPIPE") && atoi(getenv("PICONS_WGRAD_X6_NOPIPE"));
+            if (small_m && one) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, false>), grid, dim3(256), 0, s, kk);
+            else if (small_m && nopipe) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, true, false>), grid, dim3(256), 0, s, kk);
+            else if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, dim3(256), 0, s, kk);
+            else if (one) hipLaunchKernelGGL((wgrad_x6_kernel<128, 128, false>), grid, dim3(256), 0, s, kk);
+            else hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, dim3(256), 0, s, kk);
+        } else if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
         else if (wide) hipLaunchKernelGGL((wgrad_kernel<128, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);

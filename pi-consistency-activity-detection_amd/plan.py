@@ -476,12 +476,13 @@ class Plan:
         return (b["planes"][0], b["planes"][1] + (w_ref[1] - b["ref"][1]) // 2), b["n"]
 
     # ------------------------------------------------------------------ layers
-    def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None):
+    def conv_op(self, d, x_ref, w_ref, out_ref, bias=None, cscale=None, bnpart=None, alg=None, x6=True):
         """alg: algorithmic FLOPs to book for this launch (default: the descriptor's own 2*M*N*K with all taps).
         Dgrad launches book the layer's FORWARD FLOPs once (alg_dgrad) and pass alg=0, so gather-form overheads
         (padding taps, the 28x28 gather of the 20x20 PrimaryCaps dgrad) never inflate the roofline numerator."""
         self.alg_flops[self.cur] = self.alg_flops.get(self.cur, 0) + (_conv_flops(d) if alg is None else alg)
-        d = self.maybe_x6(d, w_ref)
+        if x6:
+            d = self.maybe_x6(d, w_ref)
         t = D.trim_conv(d)
         self.issued[(self.cur, capi.OP_CONV)] = self.issued.get((self.cur, capi.OP_CONV), 0) + _conv_flops(t)
         w = conv_work(t)
@@ -579,10 +580,16 @@ class Plan:
         elif self.training:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_BNPART | (capi.F_CI3 if ci3 else 0), groups=self.groups)
             d["Ci_real"] = Ci_real
-            d = self.maybe_x6(d, w["fwd"])         # the tile (hence the partial rows) is the bf16-split kernel's where that kernel runs
+            # The trunk's forward convs stay on the fp32-MFMA kernel (PICONS_SPLIT_TRUNK_FWD=1 moves them to the bf16-split kernel): the numerics
+            # gate said no.  Per kernel the split is the more accurate of the two, but EM routing amplifies ANY perturbation of the trunk's
+            # activations into the trunk's gradients, and with these ~20 launches split one per-tensor bar of the full-size suite
+            # (Mixed_4f.b2a.bn.bias, bs-8 JHMDB case) went from 0.80 to 1.06 of its bar; they were worth 0.05 ms.
+            trunk_x6 = os.environ.get("PICONS_SPLIT_TRUNK_FWD", "0") != "0"
+            if trunk_x6:
+                d = self.maybe_x6(d, w["fwd"])     # the tile (hence the partial rows) is the bf16-split kernel's where that kernel runs
             nrows = _bnpart_rows(d)
             part = self.alloc(nrows * 2 * cout)
-            self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part)
+            self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part, x6=trunk_x6)
             self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
                       f=[spec.BN_EPS, spec.BN_MOMENTUM],
                       p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(nrows // self.groups, cout)])

@@ -297,6 +297,7 @@ class StepEngine:
         else:
             a["l"][0] = self.plan.nparams
         ops.run_ops(self.ops["adam"])
+        self.last_adam_split = int(a["l"][0])          # diagnostics / tests: the final Adam covered [0, last_adam_split), the early op the rest
         self._early_armed = False
         self._early_dp, self._early_lo = False, None
         if self.plan.op_adam_early is not None:

@@ -176,3 +176,26 @@ def test_x6_row_segment_wgrad_vs_fp64_and_native(Ci, Co, thw, N, st):
     e_nat, e_x6 = _rel(nat.cpu(), ref), _rel(got.cpu(), ref)
     assert e_x6 <= 1.05 * e_nat + 1e-9, "wgrad: bf16-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_x6, e_nat)
     assert e_x6 < 5e-6
+
+
+@pytest.mark.parametrize("Ci,Co,k,thw,N", [(256, 288, (1, 1, 1), (1, 28, 28), 16), (528, 128, (1, 1, 1), (1, 28, 28), 8), (64, 96, (1, 3, 3), (2, 14, 30), 4)])
+def test_x6_generic_wgrad_vs_fp64_and_native(Ci, Co, k, thw, N):
+    """PC_WG_X6 on the generic split-K weight-gradient kernel (the 1x1x1 layers, widths that are not multiples of 28): 64- and 128-row
+    tiles, fp32 atomics between the K slices."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.relu(torch.randn(N, Ci, *thw, generator=g) * torch.exp(torch.randn(N, Ci, 1, 1, 1, generator=g)))
+    w = (torch.randn(Co, Ci, *k, generator=g) / np.sqrt(Ci * np.prod(k))).double().requires_grad_(True)
+    pads = [spec.same_pad(thw[i], k[i], 1) for i in range(3)]
+    xp = F.pad(x.double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    y = F.conv3d(xp, w, None, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    taps = int(np.prod(k))
+    ref = w.grad.reshape(Co, Ci, taps).permute(0, 2, 1)
+    pf = [p[0] for p in pads]
+    xg, dyg = cl(x), cl(dy)
+    wd = desc.wgrad(N, thw, Co, Co, thw, Ci, Ci, k, (1, 1, 1), pf)
+    nat = ops.conv_wgrad(wd, dyg, xg, torch.zeros(Co, taps, Ci, device=DEV))
+    got = ops.conv_wgrad(dict(wd, flags=capi.WG_X6), dyg, xg, torch.zeros(Co, taps, Ci, device=DEV))
+    e_nat, e_x6 = _rel(nat.cpu(), ref), _rel(got.cpu(), ref)
+    assert e_x6 <= 1.05 * e_nat + 1e-9, "generic wgrad: bf16-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_x6, e_nat)

@@ -7,7 +7,7 @@ mkdir -p $O
 cd $R
 export TMPDIR=/tmp
 timeout 900 python3 -m pytest tests/test_x6_gpu.py -x -q > $O/x6_tests.log 2>&1; echo "rc=$?" >> $O/x6_tests.log; tail -6 $O/x6_tests.log
-timeout 900 python3 -m pytest tests/test_step_gpu.py -x -q -k "trajectory or golden or small" > $O/step_tests.log 2>&1; echo "rc=$?" >> $O/step_tests.log; tail -4 $O/step_tests.log
+timeout 900 python3 -m pytest tests/test_step_gpu.py -x -q -k "trajectory or golden or small or bs8" > $O/step_tests.log 2>&1; echo "rc=$?" >> $O/step_tests.log; tail -4 $O/step_tests.log
 for wg in 1 0; do
   (cd /tmp && PICONS_SPLIT_WGRAD=$wg PICONS_LANES=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_wg$wg -o p -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-kernel-timing --resident-inputs --no-extra-legs > $O/prof_wg$wg.log 2>&1)
   python3 - <<PY

@@ -49,7 +49,7 @@ def load_counter(path, counters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--stats"); ap.add_argument("--fetch"); ap.add_argument("--write"); ap.add_argument("--sq")
-    ap.add_argument("--mfma", help="counter CSV of a pass with SQ_INSTS_VALU_MFMA_MOPS_F32")
+    ap.add_argument("--mfma", help="counter CSV of a pass with SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16")
     ap.add_argument("--steps", type=int, required=True); ap.add_argument("--tag", default="r02")
     a = ap.parse_args()
     stats = {}
@@ -60,6 +60,7 @@ def main():
     out = {"note": "HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) KiB per MI355X_MICROARCH.md; per launch, bench.py workload (bs=8); "
                    "offline rocprofv3 --pmc passes of the committed code, not a measurement of a bench run", "kernels": {}}
     conv = [0, 0.0]
+    convx = [0, 0.0]
     rows = []
     for k in sorted(set(fetch) | set(write)):
         nl = max(nf.get(k, 0), nw.get(k, 0))
@@ -68,12 +69,16 @@ def main():
         out["kernels"][k] = {"launches": nl, "fetch_kib": fetch[k]["FETCH_SIZE"], "write_kib": write[k]["WRITE_SIZE"], "hbm_bytes_per_launch": per_launch}
         if k.startswith("conv_gemm"):
             conv[0] += nl; conv[1] += b
+        if k.startswith("conv_x6_kernel"):
+            convx[0] += nl; convx[1] += b
         if k in stats:
             calls, avg_ns = stats[k]
             rate = per_launch / (avg_ns * 1e-9)
             rows.append((calls * avg_ns / a.steps / 1e6, k, calls / a.steps, avg_ns / 1e3, per_launch / 1e6, rate / 1e12))
     out["conv_gemm_hbm_bytes_per_launch"] = conv[1] / max(conv[0], 1)
     out["conv_gemm_launches"] = conv[0]
+    out["conv_x6_hbm_bytes_per_launch"] = convx[1] / max(convx[0], 1)        # the bf16-split conv / dgrad kernel (bench.py's `roofline.traffic` since round 4)
+    out["conv_x6_launches"] = convx[0]
     json.dump(out, open(os.path.join(ROOT, "profiles", a.tag + "_traffic.json"), "w"), indent=1)
     with open(os.path.join(ROOT, "profiles", a.tag + "_hbm_table.md"), "w") as f:
         f.write("# Per-kernel HBM traffic and rate (%s; bs = 8 bench workload; durations from the --stats run, bytes from the PMC passes)\n\n" % a.tag)
@@ -82,6 +87,7 @@ def main():
         for ms, k, n, us, mb, tbs in sorted(rows, reverse=True):
             f.write("| `%s` | %.3f | %.1f | %.1f | %.1f | %.2f | %.2f |\n" % (k, ms, n, us, mb, tbs, tbs * 1e12 / HBM_ACHIEVABLE))
     print("conv_gemm: %d launches, %.1f MB HBM per launch" % (conv[0], out["conv_gemm_hbm_bytes_per_launch"] / 1e6))
+    print("conv_x6: %d launches, %.1f MB HBM per launch" % (convx[0], out["conv_x6_hbm_bytes_per_launch"] / 1e6))
     if a.mfma:
         # SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 = fp32 MFMA FLOPs the hardware issued; the host-side walk of every launch's tiles
         # (pc_conv_work / pc_wino_work / pc_wgrad_work, what bench.py's roofline numerator is made of) must agree with it per kernel family
@@ -90,23 +96,25 @@ def main():
         import picons_amd  # noqa: F401
         from picons_amd import step as pstep
         from picons_amd.plan import Plan
-        mf, _n = load_counter(a.mfma, {"SQ_INSTS_VALU_MFMA_MOPS_F32", "GRBM_GUI_ACTIVE"})
+        mf, _n = load_counter(a.mfma, {"SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "GRBM_GUI_ACTIVE"})
         p = Plan(24, 224, n=8, groups=2, lanes=1)
         p.build_forward(); p.build_loss(pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)); p.build_backward(); p.build_adam()
-        host = {"conv_gemm": sum(v["mfma"] for v in p.conv_flops_executed().values()), "wino_conv": sum(v["mfma"] for v in p.wino_flops_executed().values()),
-                "wgrad": sum(v["mfma"] for v in p.wgrad_flops_executed().values())}
-        execd = {"conv_gemm": sum(v["executed"] for v in p.conv_flops_executed().values()), "wino_conv": sum(v["executed"] for v in p.wino_flops_executed().values()),
-                 "wgrad": sum(v["executed"] for v in p.wgrad_flops_executed().values())}
-        fam = lambda k: "wino_conv" if k.startswith("wino_conv") else ("conv_gemm" if k.startswith("conv_gemm") else ("wgrad" if k.startswith("wgrad") else None))
+        fams = {"conv_gemm": p.conv_flops_executed(), "conv_x6": p.x6_flops_executed(), "wino_conv": p.wino_flops_executed(), "wgrad": p.wgrad_flops_executed()}
+        host = {k: sum(v["mfma"] for v in f.values()) for k, f in fams.items()}
+        execd = {k: sum(v["executed"] for v in f.values()) for k, f in fams.items()}
+        fam = lambda k: next((f for f in ("wino_conv", "conv_gemm", "conv_x6", "wgrad") if k.startswith(f)), None)
+        # one MOPS count = 512 FLOPs of the counter's own dtype; a bf16-split kernel issues six bf16 products per fp32 product, so its
+        # fp32-EQUIVALENT FLOPs (what the host books) are the bf16 count / 6.  The wgrad family holds kernels of both kinds.
         cnt = collections.defaultdict(float)
         for k, v in mf.items():
             if fam(k):
-                cnt[fam(k)] += v["SQ_INSTS_VALU_MFMA_MOPS_F32"] * 512.0 / a.steps
+                cnt[fam(k)] += (v["SQ_INSTS_VALU_MFMA_MOPS_F32"] + v["SQ_INSTS_VALU_MFMA_MOPS_BF16"] / 6.0) * 512.0 / a.steps
         with open(os.path.join(ROOT, "profiles", a.tag + "_mfma_counter_check.txt"), "w") as f:
-            f.write("# fp32 MFMA FLOPs per step and kernel family: hardware counter (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512, rocprofv3 --pmc, own pass) against the\n"
-                    "# host-side walk of every launch's tiles that bench.py's roofline numerator is made of (issued = whole tiles; executed = real rows x columns)\n")
+            f.write("# fp32(-equivalent) MFMA FLOPs per step and kernel family: hardware counters (SQ_INSTS_VALU_MFMA_MOPS_F32 x 512 + SQ_INSTS_VALU_MFMA_MOPS_BF16 x 512 / 6 --\n"
+                    "# a bf16-split kernel issues six bf16 products per fp32 product --, rocprofv3 --pmc, own pass) against the host-side walk of every launch's tiles\n"
+                    "# that bench.py's roofline numerators are made of (issued = whole tiles; executed = real rows x columns)\n")
             f.write("%-12s %16s %16s %10s %16s %10s\n" % ("family", "counter GFLOP", "host issued", "host/ctr", "host executed", "exec/ctr"))
-            for k in ("conv_gemm", "wino_conv", "wgrad"):
+            for k in ("conv_gemm", "conv_x6", "wino_conv", "wgrad"):
                 c = cnt.get(k, 0.0)
                 f.write("%-12s %16.2f %16.2f %10.4f %16.2f %10.4f\n" % (k, c / 1e9, host[k] / 1e9, host[k] / max(c, 1.0), execd[k] / 1e9, execd[k] / max(c, 1.0)))
                 if c > 0:
@@ -120,7 +128,7 @@ def main():
         with open(os.path.join(ROOT, "profiles", a.tag + "_pmc_sq_gemm.csv"), "w") as f:
             f.write("kernel,launches," + ",".join(names) + ",mfma_util,wait_any_frac,wait_inst_frac,active_inst_frac\n")
             for k in sorted(sq, key=lambda k: -sq[k]["SQ_BUSY_CYCLES"]):
-                if not ("gemm" in k or "wgrad" in k or "em_" in k or "wino" in k):
+                if not ("gemm" in k or "wgrad" in k or "em_" in k or "wino" in k or "conv_x6" in k):
                     continue
                 v = sq[k]
                 busy, wave = v["SQ_BUSY_CYCLES"] / 32.0, max(v["SQ_WAVE_CYCLES"], 1.0)
