@@ -543,8 +543,13 @@ def main():
                  "note": "whole step (all kernels, host gaps, input staging and the loss read-back included) against the fp32 MFMA roof, executed GEMM FLOPs in fp32-equivalent "
                          "multiply-accumulates (pc_conv_work + pc_wino_work + pc_wgrad_work); the launches on the bf16-split kernel have a higher roof (`roofline.peak`), "
                          "so this fraction can exceed what an all-fp32-MFMA step could reach; resident-input step: %.3f ms" % ms_for_step}
-    dtype = ("f32 (conv / dgrad GEMMs: every fp32 operand as the exact sum of 3 bf16 terms, 6 products on the bf16 matrix cores, fp32 accumulate -- error vs fp64 "
-             "<= the fp32 MFMA kernel's, tests/test_x6_gpu.py; weight gradients, Winograd, stem and everything else: fp32 MFMA / VALU)") if split_on else "f32"
+    wg_split = split_on and os.environ.get("PICONS_SPLIT_WGRAD", "1") != "0"
+    n_x6_ops = sum(1 for n in lists for op in pl.lists[n] if op[0] == capi.OP_CONV_X6)
+    n_f32_ops = sum(1 for n in lists for op in pl.lists[n] if op[0] == capi.OP_CONV)
+    dtype = ("f32 (fp32 operands and fp32 accumulation everywhere; %d of the %d conv / input-gradient launches%s multiply on the bf16 matrix cores: every fp32 operand "
+             "as the exact sum of 3 bf16 terms, 6 products on v_mfma_f32_32x32x16_bf16, hi / lo fp32 accumulators -- error vs fp64 <= the fp32-MFMA kernel's on the same "
+             "launch, tests/test_x6_gpu.py; the trunk's forward convs, the Winograd layers, the stem, the spectral-plane weight gradient and every non-GEMM kernel: "
+             "fp32 MFMA / VALU)" % (n_x6_ops, n_x6_ops + n_f32_ops, " and the 3x3x3 / 1x1x1 weight gradients" if wg_split else "")) if split_on else "f32"
     out = {
         "metric": METRIC,
         "value": value, "unit": "clips/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

@@ -99,6 +99,14 @@ int pc_conv_bnpart_rows(const pc_conv_desc* d);
  * pc_conv_x6_ok(d) must hold (Ci % 32 == 0, ldw % 8 == 0, <= 10 taps per dimension); everything else as pc_conv_fwd. */
 int pc_conv_fwd_x6(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
                    const float* cscale, float* out, float* bnpart, pc_stream s);
+/* With a workspace the launch may split the tiles of its last, partly filled round of resident blocks (or all tiles, when it does not fill
+ * one round) into K slices: one block per slice leaves its partial sums in `ws`, the last block to arrive at a tile adds them in slice order
+ * and runs the epilogue -- same results whichever block that is (run-to-run bit-identical), every epilogue supported.  pc_conv_x6_ws_floats(d)
+ * = floats the launch wants (0: it would not split).  The LAST ceil(rem / 4) * 4 floats of that size are per-tile counters: they must be ZERO
+ * before the first launch that uses the workspace, every launch leaves them zero.  ws == NULL: pc_conv_fwd_x6. */
+int64_t pc_conv_x6_ws_floats(const pc_conv_desc* d);
+int pc_conv_fwd_x6_ws(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
+                      const float* cscale, float* out, float* bnpart, float* ws, int64_t ws_floats, pc_stream s);
 int pc_conv_x6_ok(const pc_conv_desc* d);       /* host-only advice for a planner: 1 if the descriptor (with PC_F_X6) can take the bf16-split kernel AND is
                                                   * large enough to gain from it (small launches are faster on pc_conv_fwd) */
 /* planes[p * plane_stride + i] = p-th bf16 term of src[i] (p = 0, 1, 2: h = bf16(x), m = bf16(x - h), l = x - h - m, round to nearest; h + m + l == src[i] exactly for 2^-110 <= |x| < 2^128);
@@ -480,7 +488,7 @@ enum {
     PC_OP_WGRAD_MULTI,              /* p[0] = HOST pointer to pc_wgrad_job[i[0]] (kept alive by the owner of the list): pc_conv_wgrad_multi */
     PC_OP_WINO_CONV,                /* i[0..11] = pc_wino_desc; p = in, U, bias, out, bnpart */
     PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip; l = sO, sT, sI; p = w, U */
-    PC_OP_CONV_X6,                  /* i = pc_conv_desc (flags with PC_F_X6); l[0] = plane stride; p = in, wplanes, bias, cscale, out, bnpart */
+    PC_OP_CONV_X6,                  /* i = pc_conv_desc (flags with PC_F_X6); l[0] = plane stride, l[1] = workspace floats; p = in, wplanes, bias, cscale, out, bnpart, ws (0: none) */
     PC_OP_SPLIT_PLANES,             /* l = n, plane stride; p = src, planes */
     PC_OP_SPLIT_PLANES_MULTI,       /* p[0] = HOST pointer to pc_split_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_WSPEC_MASTER_PLANES,      /* i = Acnt, a0, Atot, B, KY, KX, U, Ur; l[0] = plane stride; p = w, tw, out_f planes, out_t planes */

@@ -80,6 +80,8 @@ _SIGS = {
     "pc_conv_fwd": (i32, [C.POINTER(ConvDesc), vp, vp, vp, vp, vp, vp, vp]),
     "pc_conv_bnpart_rows": (i32, [C.POINTER(ConvDesc)]),
     "pc_conv_fwd_x6": (i32, [C.POINTER(ConvDesc), vp, vp, i64, vp, vp, vp, vp, vp]),
+    "pc_conv_fwd_x6_ws": (i32, [C.POINTER(ConvDesc), vp, vp, i64, vp, vp, vp, vp, vp, i64, vp]),
+    "pc_conv_x6_ws_floats": (i64, [C.POINTER(ConvDesc)]),
     "pc_conv_x6_ok": (i32, [C.POINTER(ConvDesc)]),
     "pc_split_planes": (i32, [vp, vp, i64, i64, vp]),
     "pc_split_planes_multi": (i32, [vp, i32, vp]),

@@ -30,7 +30,7 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_CONV_X6: {
             pc_conv_desc d;
             memcpy(&d, op.i, sizeof(d));
-            return pc_conv_fwd_x6(&d, P(const float*, 0), P(const uint16_t*, 1), op.l[0], P(const float*, 2), P(const float*, 3), P(float*, 4), P(float*, 5), s);
+            return pc_conv_fwd_x6_ws(&d, P(const float*, 0), P(const uint16_t*, 1), op.l[0], P(const float*, 2), P(const float*, 3), P(float*, 4), P(float*, 5), P(float*, 6), op.l[1], s);
         }
         case PC_OP_SPLIT_PLANES:
             return pc_split_planes(P(const float*, 0), P(uint16_t*, 1), op.l[0], op.l[1], s);

@@ -677,7 +677,8 @@ extern "C" int pc_conv_work(const pc_conv_desc* d, int ci_real, int co_real, dou
                 Ktile = (double)cdiv(Kflat, BK) * BK;
                 Kreal = (double)d->ntap[0] * d->ntap[1] * d->ntap[2] * ci_real;
             }
-            issued += (double)c.bm * c.bn * ntiles * Ktile;
+            // the bf16-split kernel: a wave owns 32 rows of the tile and multiplies nothing when none of them is a real row
+            issued += (double)(x6 ? cdiv(rows, 32) * 32 : c.bm) * c.bn * ntiles * Ktile;
             executed += (double)rows * co_real * Kreal;
             valid += vtaps * ci_real * co_real;
         }
@@ -755,7 +756,7 @@ struct WgK {
 
 // X6: the multiplications on the bf16 matrix cores (conv_x6.hip's scheme; both operands are activations, so both are split in registers: a
 // lane's MFMA operand is eight consecutive positions of one column of the [position][column] tiles, read with eight ds_read_b32)
-template <int BM, int BN, int ABL, int KB, bool X6 = false, bool HILO = true, bool ALLOW_PIPE = true>
+template <int BM, int BN, int ABL, int KB, bool X6 = false, bool HILO = true>
 __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     constexpr int BK = KB;                           // positions per chunk (shadows the file-level BK)
     constexpr int TM = BM / 64, TN = BN / 64;        // 2x2 waves
@@ -896,22 +897,14 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
                         WG_MF(A[i][0], B[j][0], acc[i][j]);
                     }
             };
-            constexpr bool PIPE = ALLOW_PIPE && (TM + TN) * 24 + TM * TN * (HILO ? 32 : 16) <= 200;       // both plane sets + the accumulators fit beside two waves per SIMD
-            if constexpr (PIPE) {
-                u4 A[2][TM][3], B[2][TN][3];
-                load_split(0, A[0], B[0]);
+            // (issuing the next step's reads and split in front of this step's MFMAs from a second register set, as wgrad3_x6_kernel does, was
+            // measured on the 64 x 128 tile and bought nothing: 0.734 against 0.737 ms per step over its 19 launches -- two blocks per CU already
+            // cover the split's latency)
 #pragma unroll
-                for (int s16 = 0; s16 < BK / 16; ++s16) {
-                    if (s16 + 1 < BK / 16) load_split(s16 + 1, A[(s16 + 1) & 1], B[(s16 + 1) & 1]);      // the next step's reads and split beside this step's MFMAs
-                    mma(A[s16 & 1], B[s16 & 1]);
-                }
-            } else {
-#pragma unroll
-                for (int s16 = 0; s16 < BK / 16; ++s16) {
-                    u4 A[TM][3], B[TN][3];
-                    load_split(s16, A, B);
-                    mma(A, B);
-                }
+            for (int s16 = 0; s16 < BK / 16; ++s16) {
+                u4 A[TM][3], B[TN][3];
+                load_split(s16, A, B);
+                mma(A, B);
             }
 #undef WG_MF
         } else
@@ -962,9 +955,9 @@ template <int BM, int BN, int ABL = 0, int KB = 32>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgK p) {
     wgrad_body<BM, BN, ABL, KB>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
-template <int BM, int BN, bool HILO = true, bool ALLOW_PIPE = true>
+template <int BM, int BN, bool HILO = true>
 __global__ __launch_bounds__(256, 2) void wgrad_x6_kernel(const WgK p) {
-    wgrad_body<BM, BN, 0, 32, true, HILO, ALLOW_PIPE>(p, xcd_remap(blockIdx.x, gridDim.x));
+    wgrad_body<BM, BN, 0, 32, true, HILO>(p, xcd_remap(blockIdx.x, gridDim.x));
 }
 
 // Several weight-gradient problems in ONE grid (pc_conv_wgrad_multi): the wgrads of one Inception module, or the eight position
@@ -1715,13 +1708,15 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         } else
 #endif
         if (d->flags & PC_WG_X6) {
-            // reserved bit 2 (tests / tools only): one accumulator per tile instead of the hi / lo pair -- to measure what the pair buys
-            const bool one = (d->flags & 4) != 0;
-            static const bool nopipe = getenv("PICONS_WGRAD_X6_NOPIPE") && atoi(getenv("PICONS_WGRAD_X6_NOPIPE"));
-            if (small_m && one) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, false>), grid, dim3(256), 0, s, kk);
-            else if (small_m && nopipe) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, true, false>), grid, dim3(256), 0, s, kk);
-            else if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, dim3(256), 0, s, kk);
-            else if (one) hipLaunchKernelGGL((wgrad_x6_kernel<128, 128, false>), grid, dim3(256), 0, s, kk);
+#ifdef PICONS_DIAG
+            // diagnostic library only (tools/wgrad_x6_acc_probe.py): flag bit 4 = one accumulator per tile instead of the hi / lo pair -- 1.1x the
+            // fp32 kernel's distance from fp64 where the pair is at 0.5 - 0.6x, at the same speed
+            if (d->flags & 4) {
+                if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, false>), grid, dim3(256), 0, s, kk);
+                else hipLaunchKernelGGL((wgrad_x6_kernel<128, 128, false>), grid, dim3(256), 0, s, kk);
+            } else
+#endif
+            if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, dim3(256), 0, s, kk);
             else hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, dim3(256), 0, s, kk);
         } else if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
         else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);

@@ -14,6 +14,13 @@
 //     the inputs and outputs of a split unit keeps the IR passes from hoisting or sinking the pure ALU work);
 //   * LDS reads run one step ahead of the MFMAs, so the two-buffer ring is as deep as a three-buffer one: the barrier sits at the head of
 //     the odd phases (chunk c + 1 landed, every wave has read chunk c), behind it goes the DMA of chunk c + 2 into chunk c's buffer.
+//   * TAIL SPLIT.  A launch of T tiles on S resident-block slots runs floor(T / S) full rounds and then a last round with T mod S blocks: the
+//     320-row spectral planes in 128 x 64 tiles are 1107 = 2 x 512 + 83 blocks of 234 K chunks each -- the chip is 16 % full for a third of the
+//     kernel.  With a workspace the last T mod S tiles (or all tiles of a launch that does not fill one round) are multiplied by `ksplit` blocks each,
+//     one K slice per block; a block leaves its partial accumulators in the workspace, and the block that finds itself last at the tile's
+//     counter adds all slices IN SLICE ORDER (deterministic, whichever block that is) and runs the ordinary epilogue -- so every epilogue
+//     (ReLU, BatchNorm partials, channel-major stores) works unchanged.  The split blocks carry the highest hardware block ids: they are
+//     dispatched last and fill the last round evenly.
 #include "conv_common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -64,7 +71,9 @@ __device__ __forceinline__ void glds16h(dma_rsrc_t rs, unsigned voff, uint8_t* l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)l, 16, voff, 0, 0, 0);
 }
 
-struct ConvX6 { ConvK k; const uint16_t* wp; long long wpstride; };
+// Tail split (below): tiles [0, full) are one block each; tile full + i, i < rem, is multiplied by `ksplit` blocks (one K slice each) that leave
+// their partial accumulators in ws and count up ctr[i]; the block that arrives last adds the slices in slice order and runs the epilogue.
+struct ConvX6 { ConvK k; const uint16_t* wp; long long wpstride; int full, rem, ksplit; float* ws; unsigned* ctr; };
 
 #define PC_MFX6(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, X), __builtin_bit_cast(bf16x8, Y), Cc, 0, 0, 0)
 
@@ -91,7 +100,16 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // hardware blocks [0, full): one tile each; [full, full + rem * ksplit): K slice ks of tile full + tl.  Consecutive logical ids share an XCD,
+    // so the slices of a tile mostly meet in one L2
+    int bid, ks = 0, tl = 0;
+    const bool split = (int)blockIdx.x >= px.full;
+    if (!split) bid = xcd_remap(blockIdx.x, px.full);
+    else {
+        const int q = xcd_remap((int)blockIdx.x - px.full, px.rem * px.ksplit);
+        tl = q / px.ksplit; ks = q % px.ksplit;
+        bid = px.full + tl;
+    }
     const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
     const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
     const int n0 = nt * BN;
@@ -160,7 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
     const int b_lo = any_tap ? __builtin_ctz(bh) : 0, b_hi = any_tap ? 31 - __builtin_clz(bh) : -1;
     const int c_lo = any_tap ? __builtin_ctz(bw) : 0, c_hi = any_tap ? 31 - __builtin_clz(bw) : -1;
     const int nb_ = b_hi - b_lo + 1, nc_ = c_hi - c_lo + 1;
-    const int nchunks = (a_hi - a_lo + 1) * nb_ * nc_ * (p.Ci / BK);
+    const int nchunks_tile = (a_hi - a_lo + 1) * nb_ * nc_ * (p.Ci / BK);
     // the A stream and the B stream of a chunk are issued half a chunk apart: each walks the (tap, channel chunk) sequence on its own
     struct Walk { int a, b, c, ci; };
     Walk wa = {a_lo, b_lo, c_lo, 0}, wb = wa;
@@ -168,6 +186,13 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
         w.ci += BK;
         if (w.ci >= p.Ci) { w.ci = 0; if (++w.c > c_hi) { w.c = c_lo; if (++w.b > b_hi) { w.b = b_lo; ++w.a; } } }
     };
+    int nchunks = nchunks_tile;
+    if (split) {                                                // K slice ks: chunks [c0, c1) of the tile's walk
+        const int c0 = (int)((long long)nchunks_tile * ks / px.ksplit), c1 = (int)((long long)nchunks_tile * (ks + 1) / px.ksplit);
+        for (int i = 0; i < c0; ++i) advance(wa);
+        wb = wa;
+        nchunks = c1 - c0;
+    }
     auto fetchA = [&](int buf) {
         const long long da = ((long long)(wa.a * p.istep[0] * p.Hi + wa.b * p.istep[1]) * p.Wi + wa.c * p.istep[2]) * p.ldi + wa.ci;
         const unsigned sel = (1u << wa.a) | (1u << (10 + wa.b)) | (1u << (20 + wa.c));
@@ -189,7 +214,10 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
     // rounds 16 times -- and `lo` the five small products (2^-8 of the sum and below, so its own roundings are 2^-8 smaller).  With everything
     // in one accumulator the six accumulate steps per 16 k, which the matrix pipe does not round to nearest, left the result 1.1x further
     // from fp64 than the fp32 kernel on one-signed (ReLU) operands; split like this it is closer than the fp32 kernel on every shape tested.
-    static_assert(TM == 1, "one row tile per wave (every configuration of pc_x6_tile)");
+    static_assert(TM == 1 && BM == 32 * WM, "one 32-row tile per wave (every configuration of pc_x6_tile)");
+    // the last row tile of a group may hold fewer than BM rows (the 320-row spectral planes in 128-row tiles): a wave with no real row
+    // multiplies nothing -- its share of the matrix pipe (and of the power budget the bf16 MFMAs run into) goes to the block beside it
+    const bool wave_live = __builtin_amdgcn_readfirstlane(lt * BM + wm * 32 < p.Mg ? 1 : 0) != 0;
     f32x16 acc_hi[TN], acc_lo[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j)
@@ -239,6 +267,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
             if (t >= 2 && (t + 2) / 2 < nchunks) fetchB(buf ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!wave_live) return;                                 // a wave whose 32 rows lie behind the group's last row only fetches and keeps the barriers
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
             const int j = m / 6, pr = m % 6;
@@ -266,7 +295,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
     if (nchunks > 0) { fetchA(0); fetchB(0); }
     if (nchunks > 1) { fetchA(1); fetchB(1); }
     __syncthreads();
-    if (nchunks > 0) {
+    if (nchunks > 0 && wave_live) {
         rdA(0, 0, 0); rdA(1, 0, 0);
 #pragma unroll
         for (int j = 0; j < TN - 1; ++j)
@@ -290,6 +319,46 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
 #pragma unroll
     for (int j = 0; j < TN; ++j) acc[0][j] = acc_hi[j] + acc_lo[j];
     __syncthreads();          // the operand ring is reused as the output staging tile
+    if (split) {
+        // partial accumulators -> workspace, in register order ([wave][j][r][lane]: 256-byte rows); the last arrival adds the slices.
+        // Message passing WITHOUT fences: a device-scope release here is buffer_wbl2 -- every split block would write back its XCD's whole L2,
+        // the launch's own output lines included (measured: 196 tiles in two slices each 21 -> 81 us).  Instead every slice element is stored and
+        // loaded with sc0 sc1 (written through to / read from the level all XCDs share; plain buffer accesses, so 16 loads are in flight at a
+        // time -- as relaxed atomics the compiler issued them one by one), the stores are waited for (vmcnt(0)) before the block's one counter
+        // increment, and the loads are issued behind the barrier that publishes its result.
+        const dma_rsrc_t rsw = dma_rsrc(px.ws + (size_t)tl * px.ksplit * (BM * BN));           // the tile's slices; aux 17 = sc0 sc1
+        const unsigned o_own = (unsigned)((ks * (BM * BN) + wave * (TN * 16 * 64) + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float v = acc[0][j][r];               // (bit_cast straight from the vector element stored element 0 sixteen times)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), rsw, o_own + (unsigned)((j * 16 + r) * 256), 0, 17);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) *tile_or = __hip_atomic_fetch_add(px.ctr + tl, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(px.ksplit - 1) ? 1u : 0u;
+        __syncthreads();
+        if (!*tile_or) return;
+        const unsigned o_all = (unsigned)((wave * (TN * 16 * 64) + lane) * 4);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x16 sum;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sum[r] = 0.f;
+            for (int k = 0; k < px.ksplit; ++k) {               // slice order, whichever block does the adding; 16 loads in flight per slice
+                float t[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    t[r] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsw, o_all + (unsigned)(k * (BM * BN) * 4 + (j * 16 + r) * 256), 0, 17));
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sum[r] += t[r];
+            }
+            acc[0][j] = sum;
+        }
+        if (tid == 0) __hip_atomic_store(px.ctr + tl, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch that uses this workspace
+        __syncthreads();
+    }
 
     // ---- epilogue (as conv_gemm_glds_kernel)
     const bool has_bias = p.flags & PC_F_BIAS, has_cs = p.flags & PC_F_CSCALE, accum = p.flags & PC_F_ACCUM;
@@ -346,11 +415,39 @@ int launch_x6(const ConvX6& kx, hipStream_t s) {
     ConvX6 p = kx;
     p.k.mtiles_g = cdiv(p.k.Mg, BM);
     p.k.ntiles = cdiv(p.k.Co, BN);
-    const dim3 grid(p.k.groups * p.k.mtiles_g * p.k.ntiles), block(64 * WM * WN);
+    const int tiles = p.k.groups * p.k.mtiles_g * p.k.ntiles;
+    if (p.ksplit <= 1 || p.rem <= 0 || !p.ws) { p.full = tiles; p.rem = 0; p.ksplit = 1; }
+    const dim3 grid(p.full + p.rem * p.ksplit), block(64 * WM * WN);
     if (pc_tl_ev_start) hipExtLaunchKernelGGL((conv_x6_kernel<BM, BN, WM, WN>), grid, block, lds, s, pc_tl_ev_start, pc_tl_ev_stop, 0, p);
     else hipLaunchKernelGGL((conv_x6_kernel<BM, BN, WM, WN>), grid, block, lds, s, p);
     PC_CHECK_LAUNCH("conv_x6_kernel");
     return PC_OK;
+}
+
+// Blocks of a tile configuration that are resident on the chip at once (launch_bounds / LDS: 256 x 128 one per CU, the 4-wave tiles two, 64 x 64 three)
+inline int x6_slots(const X6Tile& t) { return 256 * (t.bm == 256 ? 1 : (t.bm == 64 && t.bn == 64 ? 3 : 2)); }
+
+// The tail split of a launch (header): which tiles are split and how far.  Only launches whose K loop is long enough to amortise the fix-up
+// (>= 12 chunks per slice), and only when the last round would be less than 0.6 full.
+struct X6Split { int tiles, full, rem, ksplit; long long ws_floats; };
+inline X6Split x6_split(const pc_conv_desc* d, int groups, const X6Tile& t) {
+    const long long Mg = (long long)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    X6Split r;
+    r.tiles = (int)(groups * cdiv(Mg, t.bm) * cdiv(d->Co, t.bn));
+    r.full = r.tiles; r.rem = 0; r.ksplit = 1; r.ws_floats = 0;
+    static const int off = getenv("PICONS_X6_TAIL_SPLIT") ? !atoi(getenv("PICONS_X6_TAIL_SPLIT")) : 0;
+    if (off) return r;
+    const int S = x6_slots(t);
+    const int rem = r.tiles % S;
+    if (rem == 0 || rem * 10 > S * 6) return r;
+    const int chunks = d->ntap[0] * d->ntap[1] * d->ntap[2] * (d->Ci / BK);     // of a tile whose tap box is the whole kernel
+    int ks = S / rem;
+    if (ks > 8) ks = 8;
+    if (ks > chunks / 12) ks = chunks / 12;
+    if (ks < 2) return r;
+    r.full = r.tiles - rem; r.rem = rem; r.ksplit = ks;
+    r.ws_floats = (long long)rem * ks * t.bm * t.bn + ((rem + 3) / 4) * 4;        // the slices, then one counter per split tile
+    return r;
 }
 
 }  // namespace
@@ -432,8 +529,19 @@ extern "C" int pc_split_planes_multi(const pc_split_job* jobs, int njobs, pc_str
     return PC_OK;
 }
 
+extern "C" int64_t pc_conv_x6_ws_floats(const pc_conv_desc* d) {
+    if (!pc_x6_eligible(d)) return 0;
+    const int groups = d->groups > 0 ? d->groups : 1;
+    return x6_split(d, groups, pc_x6_tile(d, groups)).ws_floats;
+}
+
 extern "C" int pc_conv_fwd_x6(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
                               const float* cscale, float* out, float* bnpart, pc_stream s) {
+    return pc_conv_fwd_x6_ws(d, in, wplanes, plane_stride, bias, cscale, out, bnpart, nullptr, 0, s);
+}
+
+extern "C" int pc_conv_fwd_x6_ws(const pc_conv_desc* d, const float* in, const uint16_t* wplanes, int64_t plane_stride, const float* bias,
+                                 const float* cscale, float* out, float* bnpart, float* ws, int64_t ws_floats, pc_stream s) {
     PC_CHECK_ARG(d && in && wplanes && out, "pc_conv_fwd_x6: null pointer");
     PC_CHECK_ARG(pc_x6_eligible(d), "pc_conv_fwd_x6: the descriptor does not take the bf16-split kernel (PC_F_X6, Ci %% 32 == 0, ldw %% 8 == 0, <= 10 taps per dimension; "
                  "Ci=%d ldi=%d ldw=%d flags=%d)", d->Ci, d->ldi, d->ldw, d->flags);
@@ -471,6 +579,14 @@ extern "C" int pc_conv_fwd_x6(const pc_conv_desc* d, const float* in, const uint
                      "pc_conv_fwd_x6: input (%lld B) or weight planes (%lld B per group) exceed the 4 GiB the LDS-DMA gather addresses", in_bytes, w_bytes);
     }
     const X6Tile c = pc_x6_tile(d, groups);
+    const X6Split sp = x6_split(d, groups, c);
+    kx.full = sp.tiles; kx.rem = 0; kx.ksplit = 1; kx.ws = nullptr; kx.ctr = nullptr;
+    if (ws && sp.ksplit > 1) {
+        PC_CHECK_ARG(ws_floats >= sp.ws_floats && (uintptr_t)ws % 16 == 0, "pc_conv_fwd_x6_ws: the workspace holds %lld floats, this launch needs %lld (pc_conv_x6_ws_floats)",
+                     (long long)ws_floats, (long long)sp.ws_floats);
+        kx.full = sp.full; kx.rem = sp.rem; kx.ksplit = sp.ksplit; kx.ws = ws;
+        kx.ctr = (unsigned*)(ws + (long long)sp.rem * sp.ksplit * c.bm * c.bn);        // zero before the first use; every launch leaves them zero
+    }
     if (c.bm == 256) return launch_x6<256, 128, 8, 1>(kx, (hipStream_t)s);
     if (c.bm == 128 && c.bn == 64) return launch_x6<128, 64, 4, 1>(kx, (hipStream_t)s);
     if (c.bm == 128 && c.bn == 32) return launch_x6<128, 32, 4, 1>(kx, (hipStream_t)s);

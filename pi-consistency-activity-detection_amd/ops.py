@@ -52,11 +52,23 @@ def split_planes(w):
     return planes
 
 
-def conv_fwd_x6(d, x, wplanes, out, bias=None, cscale=None, bnpart=None):
-    """pc_conv_fwd_x6: d as for conv_fwd (PC_F_X6 is added here), wplanes = split_planes(w) of the [Co][taps][ldw] weights."""
+def conv_x6_ws_floats(d):
+    """Floats of workspace pc_conv_fwd_x6_ws would use to split the tiles of the launch's last round into K slices (0: it would not)."""
     dd = dict(d)
     dd["flags"] = int(dd.get("flags", 0)) | capi.F_X6
-    capi.call("pc_conv_fwd_x6", C.byref(conv_desc(dd)), ptr(x), ptr(wplanes), wplanes.shape[1], ptr(bias), ptr(cscale), ptr(out), ptr(bnpart), stream())
+    return int(capi.lib().pc_conv_x6_ws_floats(C.byref(conv_desc(dd))))
+
+
+def conv_fwd_x6(d, x, wplanes, out, bias=None, cscale=None, bnpart=None, ws=None):
+    """pc_conv_fwd_x6: d as for conv_fwd (PC_F_X6 is added here), wplanes = split_planes(w) of the [Co][taps][ldw] weights.
+    ws: a ZEROED float32 device tensor of conv_x6_ws_floats(d) elements (or more) lets the launch split its tail tiles along K."""
+    dd = dict(d)
+    dd["flags"] = int(dd.get("flags", 0)) | capi.F_X6
+    if ws is None:
+        capi.call("pc_conv_fwd_x6", C.byref(conv_desc(dd)), ptr(x), ptr(wplanes), wplanes.shape[1], ptr(bias), ptr(cscale), ptr(out), ptr(bnpart), stream())
+    else:
+        capi.call("pc_conv_fwd_x6_ws", C.byref(conv_desc(dd)), ptr(x), ptr(wplanes), wplanes.shape[1], ptr(bias), ptr(cscale), ptr(out), ptr(bnpart),
+                  ptr(ws), ws.numel(), stream())
     return out
 
 

@@ -89,6 +89,7 @@ class Plan:
         self.x6 = os.environ.get("PICONS_SPLIT", "1") != "0"
         self.wbufs = []           # kernel-layout weight buffers: dict(ref, n floats, lst / lane of the producing ops, planes ref once split)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
+        self.zero_once = []       # (arena ref, floats): buffers the owner zeroes once (upload_consts): workspaces whose counters every launch leaves zero
         # decoder tail as one five-tap transposed conv with a single output channel (csrc/tail6.hip) instead of the
         # 27-channel form + tap sum
         self.merged_tail = os.environ.get("PICONS_TAIL6", "1") != "0"
@@ -181,6 +182,8 @@ class Plan:
         import torch
         for ref, arr in self.consts:
             view(ref, arr.size).copy_(torch.from_numpy(arr.reshape(-1)))
+        for ref, n in self.zero_once:
+            view(ref, n).zero_()
 
     def alloc_kg(self, nfloats):
         o = self.kg_used
@@ -493,7 +496,14 @@ class Plan:
             raise RuntimeError("weights that exist as bf16 planes only met a launch that does not take the bf16-split kernel")
         if t["flags"] & capi.F_X6:
             wp, pstride = self.planes_of(w_ref)
-            il = self.emit(capi.OP_CONV_X6, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, wp, bias, cscale, out_ref, bnpart], l=[pstride])
+            # workspace for the launch's tail split (csrc/conv_x6.hip: the tiles of the last, partly filled round of resident blocks run as K
+            # slices); private to the op, its counters zeroed once by the arena's owner (upload_consts) and left zero by every launch
+            n_ws = int(capi.lib().pc_conv_x6_ws_floats(_cdesc(t))) if os.environ.get("PICONS_X6_TAIL_SPLIT", "1") != "0" else 0
+            ws = None
+            if n_ws > 0:
+                ws = self.alloc(n_ws)
+                self.zero_once.append((ws, n_ws))
+            il = self.emit(capi.OP_CONV_X6, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, wp, bias, cscale, out_ref, bnpart, ws], l=[pstride, n_ws])
         else:
             il = self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
         self.op_work[id(il)] = w          # keyed by the op's own int list (it survives the re-laning of finalize()): tools/launch_table.py

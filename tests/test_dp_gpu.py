@@ -158,6 +158,8 @@ def test_early_adam_under_the_reducer_matches_the_late_adam(tmp_path):
     # the early op took everything behind the bucket that leaves last (the head of the flat buffer: the trunk's first layers) ...
     assert e["final_adam_split"] == e["last_bucket_end"] and 0 < e["final_adam_split"] < e["nparams"] // 4, v
     assert l["final_adam_split"] == l["nparams"], v
-    assert e["step_count"] == l["step_count"] == 1 and e["moved"] > 0.99 and l["moved"] > 0.99, v          # ... and nothing was stepped twice or not at all
+    # ... and nothing was stepped twice or not at all: the same elements move as with one Adam (a parameter whose gradient is exactly zero -- a
+    # class capsule no sample of the minibatch belongs to -- does not move in either)
+    assert e["step_count"] == l["step_count"] == 1 and e["moved"] > 0.5 and abs(e["moved"] - l["moved"]) < 1e-4, v
     assert v["rel_update_diff"] < 2e-2 and v["frac_differ"] < 2e-2, v
     assert abs(e["total"] - l["total"]) <= 1e-6 * abs(l["total"]), v

@@ -199,3 +199,57 @@ def test_x6_generic_wgrad_vs_fp64_and_native(Ci, Co, k, thw, N):
     got = ops.conv_wgrad(dict(wd, flags=capi.WG_X6), dyg, xg, torch.zeros(Co, taps, Ci, device=DEV))
     e_nat, e_x6 = _rel(nat.cpu(), ref), _rel(got.cpu(), ref)
     assert e_x6 <= 1.05 * e_nat + 1e-9, "generic wgrad: bf16-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_x6, e_nat)
+
+
+# (Ci, Co, k, thw, N): launches whose last round of resident blocks is partly filled -- 196 tiles of 128 x 64 on 512 slots (every tile split in
+# two K slices), and 3 x 512 + 32 tiles (the last 32 split eight ways)
+TAIL_CASES = [(64, 128, (3, 3, 3), (2, 28, 28), 8), (64, 128, (3, 3, 3), (4, 28, 28), 32)]
+
+
+@pytest.mark.parametrize("Ci,Co,k,thw,N", TAIL_CASES)
+def test_x6_tail_split_matches_and_is_deterministic(Ci, Co, k, thw, N):
+    """pc_conv_fwd_x6_ws: the tiles of the last, partly filled round run as K slices whose partial sums meet in the workspace; the block that
+    arrives last adds them in slice order and runs the epilogue.  Against fp64 the result is held to the same bar as the unsplit launch
+    (no further than the fp32-MFMA kernel), two runs are bit-identical (the adding order does not depend on which block comes last), the
+    tile counters are back at zero, and the BatchNorm partial sums / ReLU of the epilogue see the complete sums."""
+    g = torch.Generator().manual_seed(41)
+    x = torch.relu(torch.randn(N, Ci, *thw, generator=g) * torch.exp(torch.randn(N, Ci, 1, 1, 1, generator=g)))
+    w = torch.randn(Co, Ci, *k, generator=g) / np.sqrt(Ci * np.prod(k))
+    pads = [spec.same_pad(thw[i], k[i], 1) for i in range(3)]
+    pf = [p[0] for p in pads]
+    d = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, (1, 1, 1), pf, thw)
+    n_ws = ops.conv_x6_ws_floats(d)
+    assert n_ws > 0, "this shape should split its tail"
+    xg, wk = cl(x), w_oki(w)
+    wp = ops.split_planes(wk)
+    ws = torch.zeros(n_ws, device=DEV)
+    plain = ops.conv_fwd_x6(d, xg, wp, torch.empty(N, *thw, Co, device=DEV))
+    a = ops.conv_fwd_x6(d, xg, wp, torch.empty(N, *thw, Co, device=DEV), ws=ws)
+    torch.cuda.synchronize()
+    tiles_split = n_ws - (n_ws // (128 * 64)) * (128 * 64)              # the counters sit behind whole 128 x 64 slices
+    assert tiles_split > 0 and torch.all(ws[-tiles_split:] == 0), "tile counters must be left at zero"
+    b = ops.conv_fwd_x6(d, xg, wp, torch.empty(N, *thw, Co, device=DEV), ws=ws)
+    assert torch.equal(a, b), "two runs of the split launch differ"
+    assert not torch.equal(a, plain)                                     # it did split (another summation order) ...
+    assert (a - plain).abs().max().item() <= 2e-6 * plain.abs().max().item()      # ... of the same sums
+    if N <= 8:                                                           # fp64 reference on the CPU for the smaller case
+        xp = F.pad(x.double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+        y64 = F.conv3d(xp, w.double(), None, 1)
+        nat = ops.conv_fwd(d, xg, wk, torch.empty(N, *thw, Co, device=DEV))
+        e_nat, e_sp = _rel(uncl(nat), y64), _rel(uncl(a), y64)
+        assert e_sp <= 1.05 * e_nat + 1e-9, "tail-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_sp, e_nat)
+    # epilogue on complete sums: BatchNorm partials and ReLU (+ bias), grouped as the step runs them
+    bias = torch.randn(Co, generator=g).to(DEV)
+    d2 = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, (1, 1, 1), pf, thw, flags=capi.F_BNPART, groups=2)
+    assert ops.conv_x6_ws_floats(d2) > 0
+    rows = ops.conv_bnpart_rows(dict(d2, flags=d2["flags"] | capi.F_X6))
+    p0 = torch.zeros(rows, 2, Co, device=DEV); p1 = torch.zeros(rows, 2, Co, device=DEV)
+    ws2 = torch.zeros(ops.conv_x6_ws_floats(d2), device=DEV)
+    o0 = ops.conv_fwd_x6(d2, xg, wp, torch.empty(N, *thw, Co, device=DEV), bnpart=p0)
+    o1 = ops.conv_fwd_x6(d2, xg, wp, torch.empty(N, *thw, Co, device=DEV), bnpart=p1, ws=ws2)
+    assert torch.allclose(o0, o1, rtol=0, atol=2e-6 * o0.abs().max().item())
+    assert torch.allclose(p0.sum(0), p1.sum(0), rtol=1e-5, atol=1e-4)
+    d3 = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, (1, 1, 1), pf, thw, act=capi.ACT_RELU, flags=capi.F_BIAS)
+    r0 = ops.conv_fwd_x6(d3, xg, wp, torch.empty(N, *thw, Co, device=DEV), bias=bias)
+    r1 = ops.conv_fwd_x6(d3, xg, wp, torch.empty(N, *thw, Co, device=DEV), bias=bias, ws=torch.zeros(ops.conv_x6_ws_floats(d3), device=DEV))
+    assert torch.allclose(r0, r1, rtol=0, atol=2e-6 * r0.abs().max().item()) and (r1 >= 0).all()

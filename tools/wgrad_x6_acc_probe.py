@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """What the hi / lo accumulator pair buys in the generic bf16-split weight gradient (csrc/conv.hip wgrad_body<..., X6, HILO>):
 error against an fp64 torch gradient and time per launch for native fp32 MFMA, the split with the pair, and the split with one accumulator
-(reserved flag bit 4).  Runs on the GPU box:  python tools/wgrad_x6_acc_probe.py"""
+(flag bit 4, diagnostic library only).  Runs on the GPU box:  make -C pi-consistency-activity-detection_amd/csrc diag && python tools/wgrad_x6_acc_probe.py"""
 import os, sys
+os.environ.setdefault("PICONS_DIAG_LIB", "1")      # the one-accumulator variant lives in libpicons_diag.so only
 import numpy as np, torch, torch.nn.functional as F
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
