@@ -180,51 +180,36 @@ def dry_launch(a, json_fd):
 
 class StagedInputs:
     """The reference's per-step input work inside the timed region (main_ucf101.py:52-79: casts, cat, randperm shuffle, H2D), done
-    the MI355X way: the decoded uint8 frames of the step's 8 samples go up (1.8 MB each), pc_clip_from_u8 writes data / aug_data /
-    loc_msk on the device, StepEngine.stage concatenates + shuffles into the arena.  The next step's samples are prepared on a
-    side stream while the current step runs (what tools/bench_step_u8.py measures as 'overlapped')."""
+    the MI355X way: the decoded uint8 frames of the step's 8 samples go up (1.8 MB each) and pc_clip_from_u8 writes data / aug_data /
+    loc_msk of every sample straight into ITS PLACE (after cat + shuffle) of the next step's minibatch, in the layout the first conv reads
+    ([2 bs][T][H][W][4]) -- a double buffer the stem's conv and weight gradient are pointed at (StepEngine.sample_stager) -- on a side stream
+    while the current step runs.  (Rounds 2-3 stacked, concatenated, gathered and copied the samples into the arena and converted NCDHW ->
+    NDHWC on the main stream at the head of the step: five passes over the clips.)"""
 
     def __init__(self, eng, bs, ncls, rank):
         from picons_amd import inputpipe, synthetic
         self.eng, self.bs, self.ip = eng, bs, inputpipe
         self.vids = [synthetic.make_decoded_video(100 + 97 * rank + i, labeled=(i % bs) < bs // 2, num_classes=ncls) for i in range(2 * bs)]
-        self.side = torch.cuda.Stream(device=eng.dev)
+        self.st = eng.sample_stager()
         self.g = torch.Generator().manual_seed(1234 + rank)
         np.random.seed(1234 + rank)          # the loader's own np.random draws (crop offsets, frame choice)
 
-    @staticmethod
-    def collate(samples):
-        return {'data': torch.stack([s['data'] for s in samples]), 'aug_data': torch.stack([s['aug_data'] for s in samples]),
-                'loc_msk': torch.stack([s['loc_msk'] for s in samples]), 'action': torch.stack([s['action'] for s in samples]),
-                'label_vid': torch.tensor([s['label_vid'] for s in samples])}
-
-    def prep(self, i):
-        n, nv, h = self.bs, len(self.vids), self.bs // 2
-        with torch.cuda.stream(self.side):
-            lab = self.collate([self.ip.get_item(*self.vids[(n * i + j) % nv], train=True) for j in range(h)])
-            unl = self.collate([self.ip.get_item(*self.vids[(n * i + h + j) % nv], train=True) for j in range(h)])
-            ev = torch.cuda.Event()
-            ev.record(self.side)
+    def prep(self, i, slot):
+        n, nv = self.bs, len(self.vids)
         perm = torch.randperm(n, generator=self.g).numpy()
         drops = [(torch.rand(n, c, generator=self.g) < 0.5).float().numpy() * 2 for c in (832, 128, 832, 128)]
-        return lab, unl, perm, drops, ev
+        self.st.prepare(slot, lambda j, out: self.ip.get_item(*self.vids[(n * i + j) % nv], train=True, out=out, ndhwc4=True), n // 2, perm, drops)
 
     def run(self, steps, epoch, ramp, reducer, lr, timed_kind=None, time_every=0):
         """`steps` full steps, each on a fresh minibatch; returns (seconds, last losses, steps that carried kernel-timing events)."""
-        eng = self.eng
-        nxt = self.prep(0)
+        eng, st = self.eng, self.st
+        self.prep(0, 0)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out, ntimed = None, 0
-        main = torch.cuda.current_stream()
         for i in range(steps):
-            lab, unl, perm, drops, ev = nxt
-            main.wait_event(ev)
-            for d_ in (lab, unl):            # the samples were made on the side stream and are read here: keep the allocator from handing
-                for t in d_.values():        # their blocks back to that stream while this stream still reads them (ADVICE r3)
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(main)
-            eng.stage(lab, unl, perm, drops)
+            slot = i & 1
+            st.commit(slot)                   # the main stream waits for the slot; the clip conversion reads it in place
             tk = timed_kind if (timed_kind is not None and time_every and i % time_every == 0) else None
             ntimed += tk is not None
             if reducer is not None and reducer.active and tk is None:
@@ -237,9 +222,11 @@ class StagedInputs:
                 reducer.wait()
                 gscale = reducer.gscale
             eng.adam(lr, gscale)
-            nxt = self.prep(i + 1)            # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above
+            st.release(slot)
+            self.prep(i + 1, slot ^ 1)        # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above
             out = eng.read_scalars()
         torch.cuda.synchronize()
+        eng._restore_input_ops()
         return time.perf_counter() - t0, out, ntimed
 
 

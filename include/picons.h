@@ -295,6 +295,11 @@ int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* sp
 int pc_clip_from_u8_masks(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
                           const uint8_t* maskframes, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls,
                           pc_stream s);
+/* pc_clip_from_u8 with data / aug written as [8][S][S][4] float32 (r, g, b, 0) -- the NDHWC layout with the RGB clip padded to one 16-byte piece per
+ * position that the network's first conv reads (Conv3d_1a_7x7, PC_F_CI3) -- so that a sample written into its place of the next step's minibatch
+ * needs no layout conversion at all (StepEngine.sample_stager); mask as pc_clip_from_u8.  data / aug 16-byte aligned. */
+int pc_clip_from_u8_ndhwc4(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
+                           const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s);
 /* cv2.resize on uint8 images [n][H][W][C] -> [n][Ho][Wo][C] (C <= 4), the calls of the reference's loaders:
  * datasets/jhmdb_dataloader.py:252 (frames, INTER_AREA 320x240 -> 256x256), :267,:281 (puppet masks, INTER_NEAREST),
  * :192,:208 and ucf_dataloader.py:165,171 (224 crop -> frame size, INTER_LINEAR; the identity at 224).  OpenCV's 8-bit

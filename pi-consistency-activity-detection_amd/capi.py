@@ -113,6 +113,7 @@ _SIGS = {
     "pc_seg_frame_counts": (i32, [vp, vp, i64, i64, vp, vp]),
     "pc_map_accumulate": (i32, [vp, i64, i32, i32, vp, vp, vp, vp, vp]),
     "pc_clip_from_u8": (i32, [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, i32, vp, vp, vp, vp]),
+    "pc_clip_from_u8_ndhwc4": (i32, [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, i32, vp, vp, vp, vp]),
     "pc_clip_from_u8_masks": (i32, [vp, i32, i32, i32, C.POINTER(C.c_int32), i32, i32, i32, vp, C.POINTER(C.c_int32), vp, vp, vp, vp, vp]),
     "pc_resize_tables": (i64, [i32, i32, i32, i32, i32, vp, i64]),
     "pc_resize_u8": (i32, [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, vp]),

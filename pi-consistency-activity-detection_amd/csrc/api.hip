@@ -70,6 +70,7 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_act_bwd(P(const float*, 0), op.i[0], P(const float*, 1), op.i[1], op.i[2], op.i[3], op.l[0], P(float*, 2), op.i[4],
                               P(float*, 3), op.i[5], P(float*, 4), s);
         case PC_OP_TO_NDHWC:
+            if (op.i[1] == 0) return PC_OK;        // N = 0: the clip is already where the network reads it (StepEngine.sample_stager re-points its readers)
             return pc_ncdhw_to_ndhwc(P(const void*, 0), op.i[0], op.i[1], op.i[2], op.l[0], op.i[3], op.i[4], op.i[5], P(float*, 1), s);
         case PC_OP_TO_NCDHW:
             return pc_ndhwc_to_ncdhw(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], P(float*, 1), s);

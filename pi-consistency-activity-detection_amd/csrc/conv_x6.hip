@@ -73,7 +73,7 @@ __device__ __forceinline__ void glds16h(dma_rsrc_t rs, unsigned voff, uint8_t* l
 
 // Tail split (below): tiles [0, full) are one block each; tile full + i, i < rem, is multiplied by `ksplit` blocks (one K slice each) that leave
 // their partial accumulators in ws and count up ctr[i]; the block that arrives last adds the slices in slice order and runs the epilogue.
-struct ConvX6 { ConvK k; const uint16_t* wp; long long wpstride; int full, rem, ksplit; float* ws; unsigned* ctr; };
+struct ConvX6 { ConvK k; const uint16_t* wp; long long wpstride; int full, rem, ksplit; float* ws; unsigned* ctr; int mfast; };
 
 #define PC_MFX6(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, X), __builtin_bit_cast(bf16x8, Y), Cc, 0, 0, 0)
 
@@ -110,8 +110,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
         tl = q / px.ksplit; ks = q % px.ksplit;
         bid = px.full + tl;
     }
-    const int nt = bid % p.ntiles, mtl = bid / p.ntiles;
-    const int g = mtl / p.mtiles_g, lt = mtl % p.mtiles_g;
+    // Tile order.  Default: column tiles fastest (neighbours share the gathered rows).  mfast: ROW tiles of one (group, column tile) fastest --
+    // for the spectral GEMMs, whose weight planes (1 GB for PrimaryCaps) dwarf their 320 / 448 rows per group: the row tiles that read the same
+    // 3 - 4 MB of weights run side by side in one XCD's L2 instead of re-reading them from HBM (4.2 GB per launch measured for 1.1 GB of operands).
+    int nt, g, lt;
+    if (px.mfast) { lt = bid % p.mtiles_g; const int q = bid / p.mtiles_g; nt = q % p.ntiles; g = q / p.ntiles; }
+    else { nt = bid % p.ntiles; const int mtl = bid / p.ntiles; g = mtl / p.mtiles_g; lt = mtl % p.mtiles_g; }
     const int n0 = nt * BN;
     const uint16_t* wbase = px.wp + (size_t)g * p.wgstride;
     const float* bbase = p.bias + (size_t)g * p.bgstride;
@@ -417,6 +421,8 @@ int launch_x6(const ConvX6& kx, hipStream_t s) {
     p.k.ntiles = cdiv(p.k.Co, BN);
     const int tiles = p.k.groups * p.k.mtiles_g * p.k.ntiles;
     if (p.ksplit <= 1 || p.rem <= 0 || !p.ws) { p.full = tiles; p.rem = 0; p.ksplit = 1; }
+    static const int mf = getenv("PICONS_X6_MFAST") ? atoi(getenv("PICONS_X6_MFAST")) : 1;
+    p.mfast = mf && p.k.mtiles_g <= 8 && p.k.mtiles_g > 1 && (long long)p.k.K * BN * 6 >= (2ll << 20);     // few row tiles over >= 2 MB of weights per column tile
     const dim3 grid(p.full + p.rem * p.ksplit), block(64 * WM * WN);
     if (pc_tl_ev_start) hipExtLaunchKernelGGL((conv_x6_kernel<BM, BN, WM, WN>), grid, block, lds, s, pc_tl_ev_start, pc_tl_ev_stop, 0, p);
     else hipLaunchKernelGGL((conv_x6_kernel<BM, BN, WM, WN>), grid, block, lds, s, p);

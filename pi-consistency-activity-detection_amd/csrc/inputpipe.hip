@@ -17,6 +17,7 @@ struct ClipK {
     const int32_t* rects; int R;         // [8][R][4] = x0, x1, y0, y1 in frame coordinates (empty: x1 <= x0)
     const uint8_t* maskf; int valid[8]; float* mask_cls;   // JHMDB form: per-pixel truth frames [F][H][W] (> 0 = foreground), frames that carry truth
     float* data; float* aug; float* mask;   // [3][8][S][S], [3][8][S][S], [8][S][S]
+    int nhwc4;                              // 1: data / aug as [8][S][S][4] (r, g, b, 0): the layout the network's first conv reads
 };
 
 __global__ __launch_bounds__(256) void clip_from_u8_kernel(const ClipK p) {
@@ -26,6 +27,13 @@ __global__ __launch_bounds__(256) void clip_from_u8_kernel(const ClipK p) {
         const int w = (int)(idx % S), h = (int)((idx / S) % S), t = (int)(idx / ((int64_t)S * S));
         const int f = p.span[t], y = h + p.h0, x = w + p.w0;
         const uint8_t* px = p.video + (((size_t)f * p.H + y) * p.W + x) * 3;
+        if (p.nhwc4) {
+            float4 v;
+            v.x = (float)((double)px[0] / 255.0); v.y = (float)((double)px[1] / 255.0); v.z = (float)((double)px[2] / 255.0); v.w = 0.f;
+            const size_t row = ((size_t)t * S + h) * S;
+            ((float4*)p.data)[row + w] = v;
+            ((float4*)p.aug)[row + (S - 1 - w)] = v;
+        } else
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const float v = (float)((double)px[c] / 255.0);          // img / 255. in float64, then the caller's float32 cast
@@ -49,7 +57,7 @@ __global__ __launch_bounds__(256) void clip_from_u8_kernel(const ClipK p) {
 }  // namespace
 
 static int clip_launch(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S, const int32_t* rects, int R,
-                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s);
+                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s, int nhwc4 = 0);
 
 extern "C" int pc_clip_from_u8(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
                                const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s) {
@@ -63,13 +71,19 @@ extern "C" int pc_clip_from_u8_masks(const uint8_t* video, int F, int H, int W, 
     return clip_launch(video, F, H, W, span8, h0, w0, S, nullptr, 0, maskframes, valid8, data, aug, mask, mask_cls, s);
 }
 
+extern "C" int pc_clip_from_u8_ndhwc4(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S,
+                                      const int32_t* rects, int R, float* data, float* aug, float* mask, pc_stream s) {
+    PC_CHECK_ARG(((uintptr_t)data % 16 == 0) && ((uintptr_t)aug % 16 == 0), "pc_clip_from_u8_ndhwc4: data / aug must be 16-byte aligned");
+    return clip_launch(video, F, H, W, span8, h0, w0, S, rects, R, nullptr, nullptr, data, aug, mask, nullptr, s, 1);
+}
+
 static int clip_launch(const uint8_t* video, int F, int H, int W, const int32_t* span8, int h0, int w0, int S, const int32_t* rects, int R,
-                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s) {
+                       const uint8_t* maskf, const int32_t* valid8, float* data, float* aug, float* mask, float* mask_cls, pc_stream s, int nhwc4) {
     PC_CHECK_ARG(video && span8 && data && aug && mask && (rects || R == 0), "pc_clip_from_u8: null pointer");
     PC_CHECK_ARG(F >= 1 && S >= 1 && h0 >= 0 && w0 >= 0 && h0 + S <= H && w0 + S <= W && R >= 0, "pc_clip_from_u8: crop %d+%d x %d+%d outside %d x %d", h0, S, w0, S, H, W);
     ClipK k;
     k.video = video; k.F = F; k.H = H; k.W = W; k.h0 = h0; k.w0 = w0; k.S = S; k.rects = rects; k.R = R; k.data = data; k.aug = aug; k.mask = mask;
-    k.maskf = maskf; k.mask_cls = mask_cls;
+    k.maskf = maskf; k.mask_cls = mask_cls; k.nhwc4 = nhwc4;
     for (int t = 0; t < 8; ++t) k.valid[t] = valid8 ? valid8[t] : 0;
     for (int t = 0; t < 8; ++t) {
         PC_CHECK_ARG(span8[t] >= 0 && span8[t] < F, "pc_clip_from_u8: frame %d outside [0, %d)", span8[t], F);

@@ -148,18 +148,35 @@ def _resized_sample(video8, mask8, size):
     return data, torch.flip(data, [3]), m.to(torch.float32)
 
 
-def get_item(frames, annotations, train=True, device="cuda", size=CROP):
+def get_item(frames, annotations, train=True, device="cuda", size=CROP, out=None, ndhwc4=False):
     """One sample as `UCF101DataLoader.__getitem__` returns it, with fp32 device tensors instead of float64 host tensors
     (the train loop casts to `torch.cuda.FloatTensor` first thing, main_ucf101.py:52-56).  frames: decoded uint8 [F,H,W,3]
     (numpy, or a device tensor when the decoder already writes to HBM), None when the reader failed (:90-98).
-    size: the loader's frame size `[h, w]` (square); every caller of the reference uses 224, where the resize is the identity."""
+    size: the loader's frame size `[h, w]` (square); every caller of the reference uses 224, where the resize is the identity.
+    out: (data [3,8,S,S], aug_data [3,8,S,S], loc_msk [1,8,S,S]) float32 device views to write the sample into -- its place in a minibatch
+    staging buffer (StepEngine.sample_stager) -- instead of fresh tensors; the returned dict then holds those views.
+    ndhwc4 (with out, size 224): data / aug_data views are [8,S,S,4] and are written as (r, g, b, 0) per position -- the layout the network's
+    first conv reads -- instead of the loader's [3,8,S,S]."""
+    if ndhwc4 and (out is None or size != CROP):
+        raise ValueError("get_item: ndhwc4 is the staging layout of StepEngine.sample_stager (out=..., size 224)")
+
+    def _into_out(e):
+        if out is not None:
+            for k, t in zip(("data", "aug_data", "loc_msk"), out):
+                src = e[k]
+                if ndhwc4 and k != "loc_msk":
+                    t.zero_(); t[..., :3].copy_(src.permute(1, 2, 3, 0))
+                else:
+                    t.copy_(src.reshape(t.shape))
+                e[k] = t
+        return e
     if frames is None:
-        return _empty(device, size)
+        return _into_out(_empty(device, size))
     vlen, clip_h, clip_w = int(frames.shape[0]), int(frames.shape[1]), int(frames.shape[2])
     label, annot_frames, labeled_vid = frame_meta(annotations)
     span = choose_window(annot_frames, vlen)
     if span is None:
-        return _empty(device, size)
+        return _into_out(_empty(device, size))
     per_frame = boxes_of(annotations, vlen, span)
     if train:
         h0 = np.random.randint(0, clip_h - CROP); w0 = np.random.randint(0, clip_w - CROP)       # :146-149
@@ -181,8 +198,13 @@ def get_item(frames, annotations, train=True, device="cuda", size=CROP):
         crop8 = video.contiguous()[torch.as_tensor(np.asarray(ids), device=video.device).long(), h0:h0 + CROP, w0:w0 + CROP].contiguous()
         _d, _a, m224 = ops.clip_from_u8(video.contiguous(), ids, h0, w0, rects_d, CROP)          # the box mask of the crop
         data, aug, mask = _resized_sample(crop8, m224.to(torch.uint8), size)
+        if out is not None:
+            for src, t in zip((data, aug, mask), out):
+                t.copy_(src.reshape(t.shape))
+            data, aug, mask = out
     else:
-        data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, rects_d, CROP)
+        data, aug, mask = ops.clip_from_u8(video.contiguous(), ids, h0, w0, rects_d, CROP,
+                                           out=None if out is None else (out[0], out[1], out[2].view(DEPTH, size, size)), ndhwc4=ndhwc4)
     return {'data': data, 'loc_msk': mask.view(1, DEPTH, size, size), 'action': torch.Tensor([label]), 'aug_data': aug, 'label_vid': labeled_vid}
 
 

@@ -405,18 +405,27 @@ def map_accumulate(counts, label, frame_hits, video_hits, n_frames, n_vids):
               ptr(n_frames), ptr(n_vids), stream())
 
 
-def clip_from_u8(video, span, h0, w0, rects, S=224):
+def clip_from_u8(video, span, h0, w0, rects, S=224, out=None, ndhwc4=False):
     """video: uint8 device tensor [F,H,W,3]; span: 8 frame ids; rects: int32 device tensor [8,R,4] (x0,x1,y0,y1) or None.
-    -> data, aug [3,8,S,S] float32, mask [8,S,S] float32 (pc_clip_from_u8)."""
+    -> data, aug [3,8,S,S] float32, mask [8,S,S] float32 (pc_clip_from_u8).  out: (data, aug, mask) contiguous float32 device tensors of those
+    sizes to write into -- a sample's place in a minibatch staging buffer -- instead of fresh ones.  ndhwc4: data / aug as [8,S,S,4] (r, g, b, 0),
+    the layout the network's first conv reads (pc_clip_from_u8_ndhwc4)."""
     if video.dtype != torch.uint8 or video.dim() != 4 or video.shape[3] != 3 or not video.is_contiguous():
         raise ValueError("clip_from_u8: contiguous uint8 [F,H,W,3] frames")
     F, H, W, _ = video.shape
     R = 0 if rects is None else int(rects.shape[1])
     if rects is not None and (rects.dtype != torch.int32 or not rects.is_contiguous() or rects.shape[0] != 8 or rects.shape[2] != 4):
         raise ValueError("clip_from_u8: rects must be contiguous int32 [8,R,4]")
-    data = torch.empty(3, 8, S, S, device=video.device); aug = torch.empty_like(data); mask = torch.empty(8, S, S, device=video.device)
+    nch = 4 if ndhwc4 else 3
+    if out is None:
+        data = torch.empty((8, S, S, 4) if ndhwc4 else (3, 8, S, S), device=video.device); aug = torch.empty_like(data); mask = torch.empty(8, S, S, device=video.device)
+    else:
+        data, aug, mask = out
+        for t, n_ in ((data, nch * 8 * S * S), (aug, nch * 8 * S * S), (mask, 8 * S * S)):
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n_ or t.device != video.device:
+                raise ValueError("clip_from_u8: out tensors must be contiguous float32 device tensors of %d*8*S*S / %d*8*S*S / 8*S*S elements" % (nch, nch))
     sp = (C.c_int32 * 8)(*[int(v) for v in span])
-    capi.call("pc_clip_from_u8", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(rects) if R else None, R, ptr(data), ptr(aug), ptr(mask), stream())
+    capi.call("pc_clip_from_u8_ndhwc4" if ndhwc4 else "pc_clip_from_u8", ptr(video), F, H, W, sp, int(h0), int(w0), S, ptr(rects) if R else None, R, ptr(data), ptr(aug), ptr(mask), stream())
     return data, aug, mask
 
 

@@ -912,6 +912,7 @@ class Plan:
         self.in_drop832 = self.alloc(N * spec.TRUNK_OUT_CH)
         self.in_drop128 = self.alloc(N * 128)
         x = self.tensor(N, (T, hw, hw), 4, "img")
+        self.img = x              # the clip as the first conv reads it ([2 bs][T][hw][hw][4]); StepEngine.sample_stager re-points its readers
         self.op_to_ndhwc = []
         for g in range(self.groups):
             self.op_to_ndhwc.append(len(self.lists["fwd"]))

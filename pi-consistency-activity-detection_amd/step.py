@@ -190,11 +190,20 @@ class StepEngine:
             self._stager = HostDictStager(self)
         return self._stager
 
+    def sample_stager(self):
+        """-> SampleStager bound to this engine (created once): device-made samples written straight into the next step's minibatch."""
+        if getattr(self, "_sstager", None) is None:
+            self._sstager = SampleStager(self)
+        return self._sstager
+
     def _restore_input_ops(self):
         """stage() feeds the fp32 arena staging buffers: undo a HostDictStager.commit() that pointed the clip conversion at its own."""
         for idx, (flag, ptr) in getattr(self, "_to_ndhwc_orig", {}).items():
             self.ops["fwd"][idx]["i"][0] = flag
+            self.ops["fwd"][idx]["i"][1] = self.bs
             self.ops["fwd"][idx]["p"][0] = ptr
+        for name, idx, q, offb in getattr(self, "_img_readers", ()):
+            self.ops[name][idx]["p"][q] = self._img_base + offb
 
     # ------------------------------------------------------------------ execution
     def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
@@ -405,12 +414,13 @@ class HostDictStager:
                     into the arena, the per-sample scalars and Dropout3d draws follow in one small packed upload.
     The host never waits for the GPU here; its only wait stays StepEngine.read_scalars()."""
 
-    def __init__(self, eng):
+    def __init__(self, eng, dtype=torch.float64, host=True):
         self.eng = eng
         n, hw, T = eng.bs, eng.hw, spec.FRAMES
+        self.dtype = dtype
         self.shapes = dict(data=(n, 3, T, hw, hw), aug_data=(n, 3, T, hw, hw), loc_msk=(n, 1, T, hw, hw))
-        self.pin = [{k: torch.empty(shp, dtype=torch.float64).pin_memory() for k, shp in self.shapes.items()} for _ in range(2)]
-        self.dev = [{k: torch.empty(shp, dtype=torch.float64, device=eng.dev) for k, shp in self.shapes.items()} for _ in range(2)]
+        self.pin = [{k: torch.empty(shp, dtype=dtype).pin_memory() for k, shp in self.shapes.items()} for _ in range(2)] if host else None
+        self.dev = [{k: torch.empty(shp, dtype=dtype, device=eng.dev) for k, shp in self.shapes.items()} for _ in range(2)]
         self.nsmall = 2 * n + 2 * n * spec.TRUNK_OUT_CH + 2 * n * 128           # action, labeled flag, the four Dropout3d draws
         self.pin_small = [torch.empty(self.nsmall, dtype=torch.float32).pin_memory() for _ in range(2)]
         self.dev_small = [torch.empty(self.nsmall, dtype=torch.float32, device=eng.dev) for _ in range(2)]
@@ -422,7 +432,7 @@ class HostDictStager:
         # the 180 MB gather is 24 sample-sized memcpys: one thread moves ~5 GB/s (33 ms per step, more than the step itself); tensor.copy_
         # releases the GIL, so a small pool brings it to a few ms
         from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("PICONS_STAGE_THREADS", "8")))
+        self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("PICONS_STAGE_THREADS", "8"))) if host else None
         if not hasattr(eng, "_to_ndhwc_orig"):
             eng._to_ndhwc_orig = {idx: (int(eng.ops["fwd"][idx]["i"][0]), int(eng.ops["fwd"][idx]["p"][0])) for idx in eng.plan.op_to_ndhwc}
 
@@ -447,6 +457,18 @@ class HostDictStager:
             lab_flag = torch.cat([torch.ones(nl), torch.zeros(n - nl)])[perm]
         else:
             lab_flag = torch.cat([T_(label_mb["label_vid"]), T_(unlabel_mb["label_vid"])]).float()[perm]
+        self._pack_small(slot, act, lab_flag, drops)
+        with torch.cuda.stream(self.copy_stream):
+            for k in self.shapes:
+                self.dev[slot][k].copy_(self.pin[slot][k], non_blocking=True)
+            self.dev_small[slot].copy_(self.pin_small[slot], non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        self.used[slot] = True
+
+    def _pack_small(self, slot, act, lab_flag, drops):
+        """Per-sample scalars and the four Dropout3d draws of a step into the slot's page-locked vector (uploaded in one copy)."""
+        n = self.eng.bs
+        T_ = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))
         ps = self.pin_small[slot]
         ps[:n] = act
         ps[n:2 * n] = lab_flag
@@ -455,12 +477,6 @@ class HostDictStager:
             ps[o:o + n * c] = T_(d).reshape(-1).float()
             o += n * c
         self.host[slot] = (lab_flag.to(torch.int32), act.clone())
-        with torch.cuda.stream(self.copy_stream):
-            for k in self.shapes:
-                self.dev[slot][k].copy_(self.pin[slot][k], non_blocking=True)
-            self.dev_small[slot].copy_(ps, non_blocking=True)
-            self.ready[slot].record(self.copy_stream)
-        self.used[slot] = True
 
     def commit(self, slot):
         """Head of the step (main stream): wait for the slot's upload, point the clip conversion at its float64 staging, cast the mask
@@ -468,12 +484,17 @@ class HostDictStager:
         eng, p, n = self.eng, self.eng.plan, self.eng.bs
         main = torch.cuda.current_stream(eng.dev)
         main.wait_event(self.ready[slot])
+        eng._restore_input_ops()                      # whatever another stager left re-pointed
         fwd = eng.ops["fwd"]
         for g, idx in enumerate(p.op_to_ndhwc):
-            fwd[idx]["i"][0] = 1                                              # src_is_f64
+            fwd[idx]["i"][0] = 1 if self.dtype == torch.float64 else 0        # src_is_f64
             fwd[idx]["p"][0] = self.dev[slot]["data" if g == 0 else "aug_data"].data_ptr()
+        self._commit_small(slot)
+
+    def _commit_small(self, slot):
+        eng, p, n = self.eng, self.eng.plan, self.eng.bs
         per = spec.FRAMES * eng.hw * eng.hw
-        eng.aview(p.in_seg, n * per).copy_(self.dev[slot]["loc_msk"].reshape(-1))         # f64 -> f32 on the device
+        eng.aview(p.in_seg, n * per).copy_(self.dev[slot]["loc_msk"].reshape(-1))         # (f64 -> f32 on the device)
         ds = self.dev_small[slot]
         eng.aview(p.in_cls, 2 * n).copy_(torch.cat([ds[:n], ds[:n]]))
         eng.aview(p.in_labeled, 2 * n, torch.int32).copy_(torch.cat([ds[n:2 * n], ds[n:2 * n]]).to(torch.int32))
@@ -486,3 +507,65 @@ class HostDictStager:
         """Behind the step that consumed the slot (its last reader is the loss list / the backward's dropout ops reading the arena -- the
         float64 staging itself is only read by the first two kernels)."""
         self.consumed[slot].record(torch.cuda.current_stream(self.eng.dev))
+
+
+class SampleStager(HostDictStager):
+    """The DEVICE input pipeline taken one step ahead: the per-sample work of the loaders' __getitem__ (inputpipe.get_item: frame choice, crop,
+    /255, flip, box mask from the decoded uint8 frames) writes every sample straight into ITS PLACE of the next step's minibatch -- position j
+    of a double buffer, where j is where torch.cat + the randperm shuffle of main_ucf101.py:65-79 put the sample -- on a side stream while the
+    current step runs, and IN THE LAYOUT THE FIRST CONV READS ([2 bs][T][H][W][4]: clip and flipped clip, RGB padded to one 16-byte piece,
+    pc_clip_from_u8_ndhwc4).  No stack, no cat, no gather, no copy into the arena and no NCDHW -> NDHWC conversion: commit() re-points the
+    readers of the clip (the stem's conv and its weight gradient) at the buffer and switches the conversion ops off; the only per-step copies left
+    are the mask (6 MB) and the small vectors."""
+
+    def __init__(self, eng):
+        super().__init__(eng, dtype=torch.float32, host=False)
+        n, hw, T = eng.bs, eng.hw, spec.FRAMES
+        self.x = [torch.empty(2 * n, T, hw, hw, 4, dtype=torch.float32, device=eng.dev) for _ in range(2)]
+        for d in self.dev:                             # the planar staging of the base class is not used here
+            d.pop("data"); d.pop("aug_data")
+        img = eng.plan.img
+        if not hasattr(eng, "_img_readers"):           # every pointer of the forward / backward lists that points into the clip tensor
+            eng._img_base = int(eng.bases[img.ref[0]] + img.ref[1])
+            nbytes = 4 * 2 * n * T * hw * hw * 4
+            eng._img_readers = [(name, idx, q, int(op["p"][q]) - eng._img_base) for name in ("fwd", "bwd") for idx, op in enumerate(eng.ops[name])
+                                for q in range(len(op["p"])) if eng._img_base <= int(op["p"][q]) < eng._img_base + nbytes
+                                and not (name == "fwd" and idx in eng.plan.op_to_ndhwc)]
+            if not eng._img_readers:
+                raise RuntimeError("no op reads the clip tensor: the plan changed under SampleStager")
+
+    def prepare(self, slot, make_sample, nl, perm, drops):
+        """make_sample(i, out) -> the sample dict of dataset position i (0 .. nl-1 labeled, then unlabeled) written into
+        out = (data, aug_data, loc_msk) views (inputpipe.get_item(..., out=out, ndhwc4=True)); called in dataset order, so the loader's own
+        random draws come in the reference's order whatever the shuffle."""
+        eng, n = self.eng, self.eng.bs
+        perm = np.asarray(perm)
+        where = np.empty(n, np.int64)
+        where[perm] = np.arange(n)                     # sample i lands at position where[i]
+        if self.used[slot]:
+            self.consumed[slot].synchronize()          # the step that read this slot was enqueued two steps ago: long done
+        x, m = self.x[slot], self.dev[slot]["loc_msk"]
+        with torch.cuda.stream(self.copy_stream):
+            samples = [make_sample(i, (x[where[i]], x[n + where[i]], m[where[i]])) for i in range(n)]
+            act = torch.tensor([float(torch.as_tensor(smp["action"]).reshape(-1)[0]) for smp in samples])[perm]
+            if eng.jhmdb:                              # main_jhmdb.py:68-70
+                lab_flag = torch.cat([torch.ones(nl), torch.zeros(n - nl)])[perm]
+            else:
+                lab_flag = torch.tensor([float(smp["label_vid"]) for smp in samples])[perm]
+            self._pack_small(slot, act, lab_flag, drops)
+            self.dev_small[slot].copy_(self.pin_small[slot], non_blocking=True)
+            self.ready[slot].record(self.copy_stream)
+        self.used[slot] = True
+
+    def commit(self, slot):
+        """Head of the step (main stream): wait for the slot, point the clip's readers at it, switch the layout conversion off, copy the mask
+        and scatter the small inputs into the arena."""
+        eng, p, n = self.eng, self.eng.plan, self.eng.bs
+        main = torch.cuda.current_stream(eng.dev)
+        main.wait_event(self.ready[slot])
+        for idx in p.op_to_ndhwc:
+            eng.ops["fwd"][idx]["i"][1] = 0                                    # N = 0: nothing to convert
+        base = self.x[slot].data_ptr()
+        for name, idx, q, offb in eng._img_readers:
+            eng.ops[name][idx]["p"][q] = base + offb
+        self._commit_small(slot)

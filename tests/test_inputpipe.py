@@ -123,3 +123,58 @@ def test_device_pipeline_matches_reference_jhmdb_loader(k):
     assert float(s["action"][0]) == G["jsums_%d" % k][4]
     if k == 1:
         assert 0 < G["jmcls_%d" % k].sum() < 8            # the sparse case really has frames without truth inside the window
+
+
+@pytest.mark.gpu
+def test_sample_stager_writes_the_minibatch_in_place():
+    """StepEngine.sample_stager(): get_item(..., out=...) writes every sample into its place (after cat + randperm shuffle, main_ucf101.py:65-79)
+    of the next step's float32 staging and the step reads it there.  Same clips, same draws, through get_item + StepEngine.stage (stack, cat,
+    gather, copy into the arena): bit-identical losses and outputs, and the staging holds exactly the staged minibatch."""
+    from picons_amd import inputpipe as ip, step as pstep, synthetic
+    dev = "cuda:0"
+    bs = 4
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    vids = [synthetic.make_decoded_video(300 + i, labeled=i < bs // 2, num_classes=24) for i in range(bs)]
+    perm = np.array([2, 0, 3, 1])
+    drops = [(np.random.RandomState(5 + q).rand(bs, c) < 0.5).astype(np.float32) * 2 for q, c in enumerate((832, 128, 832, 128))]
+    ramp = pstep.exp_rampup(100)(1)
+
+    def collate(samples):
+        return {'data': torch.stack([s['data'] for s in samples]), 'aug_data': torch.stack([s['aug_data'] for s in samples]),
+                'loc_msk': torch.stack([s['loc_msk'] for s in samples]), 'action': torch.stack([s['action'] for s in samples]),
+                'label_vid': torch.tensor([s['label_vid'] for s in samples])}
+    eng = pstep.StepEngine(args, bs=bs, hw=224, device=dev)
+    np.random.seed(77)
+    smp = [ip.get_item(*v, train=True) for v in vids]
+    eng.stage(collate(smp[:bs // 2]), collate(smp[bs // 2:]), perm, drops)
+    eng.forward_backward(1, ramp)
+    a = eng.read_scalars()
+    out_a = [t.clone() for t in eng.outputs()]
+    want = torch.stack([s['data'] for s in smp])[torch.as_tensor(perm)]
+
+    st = eng.sample_stager()
+    np.random.seed(77)
+    st.prepare(0, lambda i, out: ip.get_item(*vids[i], train=True, out=out, ndhwc4=True), bs // 2, perm, drops)
+    st.commit(0)
+    eng.forward_backward(1, ramp)
+    st.release(0)
+    b = eng.read_scalars()
+    out_b = eng.outputs()
+    torch.cuda.synchronize()
+    x = st.x[0]                                                  # [2 bs][T][H][W][4]: the clips, then the flipped clips, RGB + a zero
+    assert torch.equal(x[:bs, ..., :3], want.permute(0, 2, 3, 4, 1)) and torch.equal(x[bs:, ..., :3], torch.flip(want, [4]).permute(0, 2, 3, 4, 1))
+    assert torch.all(x[..., 3] == 0)
+    for k in ("total", "loc", "cls", "cons"):
+        assert a[k] == b[k], (k, a[k], b[k])
+    for x, y in zip(out_a, out_b):
+        assert torch.equal(x, y)
+    assert torch.equal(eng.labels_host, torch.tensor([smp[i]['label_vid'] for i in perm], dtype=torch.int32))
+    # back on the arena path (stage() undoes the re-pointing): the first result again, and the planar out= form of get_item
+    eng.stage(collate(smp[:bs // 2]), collate(smp[bs // 2:]), perm, drops)
+    eng.forward_backward(1, ramp)
+    c = eng.read_scalars()
+    assert c["total"] == a["total"]
+    np.random.seed(77)
+    d0, a0, m0 = torch.empty(3, 8, 224, 224, device=dev), torch.empty(3, 8, 224, 224, device=dev), torch.empty(1, 8, 224, 224, device=dev)
+    s0 = ip.get_item(*vids[0], train=True, out=(d0, a0, m0))
+    assert torch.equal(d0, smp[0]["data"]) and torch.equal(a0, smp[0]["aug_data"]) and torch.equal(m0, smp[0]["loc_msk"]) and s0["data"] is d0

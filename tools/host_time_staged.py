@@ -8,17 +8,17 @@ from picons_amd import step as pstep
 args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
 eng = pstep.StepEngine(args, bs=8, hw=224)
 si = bench.StagedInputs(eng, 8, 24, 0)
-T = dict(wait=0, stage=0, fb=0, adam=0, prep=0, read=0)
-nxt = si.prep(0)
+T = dict(commit=0, fb=0, adam=0, prep=0, read=0)
+st = si.st
+si.prep(0, 0)
 for i in range(60):
     if i == 40:
         torch.cuda.synchronize(); T = {k: 0 for k in T}; t00 = time.perf_counter()
-    lab, unl, perm, drops, ev = nxt
-    t = time.perf_counter(); torch.cuda.current_stream().wait_event(ev); T['wait'] += time.perf_counter() - t
-    t = time.perf_counter(); eng.stage(lab, unl, perm, drops); T['stage'] += time.perf_counter() - t
+    slot = i & 1
+    t = time.perf_counter(); st.commit(slot); T['commit'] += time.perf_counter() - t
     t = time.perf_counter(); eng.arm_early_adam(1e-4, True); eng.forward_backward(1, 0.01, None); T['fb'] += time.perf_counter() - t
-    t = time.perf_counter(); eng.adam(1e-4, 1.0); T['adam'] += time.perf_counter() - t
-    t = time.perf_counter(); nxt = si.prep(i + 1); T['prep'] += time.perf_counter() - t
+    t = time.perf_counter(); eng.adam(1e-4, 1.0); st.release(slot); T['adam'] += time.perf_counter() - t
+    t = time.perf_counter(); si.prep(i + 1, slot ^ 1); T['prep'] += time.perf_counter() - t
     t = time.perf_counter(); out = eng.read_scalars(); T['read'] += time.perf_counter() - t
 torch.cuda.synchronize()
 tot = time.perf_counter() - t00
