@@ -424,7 +424,10 @@ class HostDictStager:
         self.nsmall = 2 * n + 2 * n * spec.TRUNK_OUT_CH + 2 * n * 128           # action, labeled flag, the four Dropout3d draws
         self.pin_small = [torch.empty(self.nsmall, dtype=torch.float32).pin_memory() for _ in range(2)]
         self.dev_small = [torch.empty(self.nsmall, dtype=torch.float32, device=eng.dev) for _ in range(2)]
-        self.copy_stream = torch.cuda.Stream(device=eng.dev)
+        # A normal-priority stream.  (A high-priority one -- a hardware queue of its own instead of sharing a lane's, DESIGN.md 5 -- was measured
+        # and is SLOWER: the staged step 19.92 - 20.04 ms against 19.33 - 19.43, tools/gpu/r04_o.sh: its kernels then pre-empt the lanes' blocks.
+        # PICONS_STAGE_STREAM_PRIO=-1 selects it.)
+        self.copy_stream = torch.cuda.Stream(device=eng.dev, priority=int(os.environ.get("PICONS_STAGE_STREAM_PRIO", "0")))
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
