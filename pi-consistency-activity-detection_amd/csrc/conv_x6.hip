@@ -500,6 +500,8 @@ extern "C" int pc_conv_x6_ok(const pc_conv_desc* d) {
     const int groups = d->groups > 0 ? d->groups : 1;
     const X6Tile t = pc_x6_tile(d, groups);
     const long long Mg = (long long)(d->N / groups) * d->Tq * d->Hq * d->Wq;
+    // (A rule on K as well -- the seven launches of <= 4 chunks, K <= 128, on the 4-wave tiles run 0.73 - 0.92x the fp32 kernel,
+    // profiles/r04_x6_launches.txt -- is worth 0.04 ms per step and was not adopted: DESIGN.md 8.)
     return (long long)groups * cdiv(Mg, t.bm) * cdiv(d->Co, t.bn) >= 150 ? 1 : 0;
 }
 

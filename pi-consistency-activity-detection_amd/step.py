@@ -196,14 +196,32 @@ class StepEngine:
             self._sstager = SampleStager(self)
         return self._sstager
 
+    def readers_of(self, ref, nfloats, skip=()):
+        """(base address, [(list, op index, pointer slot, byte offset)]) of every op pointer that points into the arena buffer `ref`: what a
+        stager re-points at its own double buffer instead of copying into the arena."""
+        base = int(self.bases[ref[0]] + ref[1])
+        out = []
+        for name, arr in self.ops.items():
+            if name.startswith("_"):
+                continue
+            for idx in range(len(arr)):
+                if (name, idx) in skip:
+                    continue
+                pp = arr[idx]["p"]
+                for q in range(len(pp)):
+                    if base <= int(pp[q]) < base + 4 * nfloats:
+                        out.append((name, idx, q, int(pp[q]) - base))
+        return base, out
+
     def _restore_input_ops(self):
         """stage() feeds the fp32 arena staging buffers: undo a HostDictStager.commit() that pointed the clip conversion at its own."""
         for idx, (flag, ptr) in getattr(self, "_to_ndhwc_orig", {}).items():
             self.ops["fwd"][idx]["i"][0] = flag
             self.ops["fwd"][idx]["i"][1] = self.bs
             self.ops["fwd"][idx]["p"][0] = ptr
-        for name, idx, q, offb in getattr(self, "_img_readers", ()):
-            self.ops[name][idx]["p"][q] = self._img_base + offb
+        for base, readers in getattr(self, "_patched", {}).values():
+            for name, idx, q, offb in readers:
+                self.ops[name][idx]["p"][q] = base + offb
 
     # ------------------------------------------------------------------ execution
     def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
@@ -524,18 +542,38 @@ class SampleStager(HostDictStager):
     def __init__(self, eng):
         super().__init__(eng, dtype=torch.float32, host=False)
         n, hw, T = eng.bs, eng.hw, spec.FRAMES
+        p = eng.plan
         self.x = [torch.empty(2 * n, T, hw, hw, 4, dtype=torch.float32, device=eng.dev) for _ in range(2)]
         for d in self.dev:                             # the planar staging of the base class is not used here
             d.pop("data"); d.pop("aug_data")
-        img = eng.plan.img
-        if not hasattr(eng, "_img_readers"):           # every pointer of the forward / backward lists that points into the clip tensor
-            eng._img_base = int(eng.bases[img.ref[0]] + img.ref[1])
-            nbytes = 4 * 2 * n * T * hw * hw * 4
-            eng._img_readers = [(name, idx, q, int(op["p"][q]) - eng._img_base) for name in ("fwd", "bwd") for idx, op in enumerate(eng.ops[name])
-                                for q in range(len(op["p"])) if eng._img_base <= int(op["p"][q]) < eng._img_base + nbytes
-                                and not (name == "fwd" and idx in eng.plan.op_to_ndhwc)]
-            if not eng._img_readers:
-                raise RuntimeError("no op reads the clip tensor: the plan changed under SampleStager")
+        # the small inputs in the slot exactly as the ops read them -- class ids and labeled flags once per pass, the Dropout3d draws of both
+        # passes -- so that they too are re-pointed instead of copied: [cls 2n | labeled 2n (int32) | drop832 2n x 832 | drop128 2n x 128]
+        self.o_cls, self.o_lab, self.o_d832 = 0, 2 * n, 4 * n
+        self.o_d128 = self.o_d832 + 2 * n * spec.TRUNK_OUT_CH
+        self.nsmall = self.o_d128 + 2 * n * 128
+        self.pin_small = [torch.empty(self.nsmall, dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.dev_small = [torch.empty(self.nsmall, dtype=torch.float32, device=eng.dev) for _ in range(2)]
+        if not hasattr(eng, "_patched"):               # every pointer of the op lists into the clip tensor / the arena's input buffers
+            conv_ops = tuple(("fwd", idx) for idx in p.op_to_ndhwc)
+            per = T * hw * hw
+            eng._patched = dict(img=eng.readers_of(p.img.ref, 2 * n * per * 4, skip=conv_ops), seg=eng.readers_of(p.in_seg, n * per),
+                                cls=eng.readers_of(p.in_cls, 2 * n), lab=eng.readers_of(p.in_labeled, 2 * n),
+                                d832=eng.readers_of(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH), d128=eng.readers_of(p.in_drop128, 2 * n * 128))
+            if not eng._patched["img"][1] or not eng._patched["seg"][1]:
+                raise RuntimeError("no op reads the clip tensor / the mask: the plan changed under SampleStager")
+
+    def _pack_small(self, slot, act, lab_flag, drops):
+        n = self.eng.bs
+        T_ = lambda a: a if torch.is_tensor(a) else torch.from_numpy(np.asarray(a))
+        ps = self.pin_small[slot]
+        ps[self.o_cls:self.o_cls + n] = act; ps[self.o_cls + n:self.o_cls + 2 * n] = act
+        li = ps.view(torch.int32)
+        li[self.o_lab:self.o_lab + n] = lab_flag.to(torch.int32); li[self.o_lab + n:self.o_lab + 2 * n] = lab_flag.to(torch.int32)
+        o = self.o_d832
+        for d, c in zip((drops[0], drops[2], drops[1], drops[3]), (spec.TRUNK_OUT_CH, spec.TRUNK_OUT_CH, 128, 128)):
+            ps[o:o + n * c] = T_(d).reshape(-1).float()
+            o += n * c
+        self.host[slot] = (lab_flag.to(torch.int32), act.clone())
 
     def prepare(self, slot, make_sample, nl, perm, drops):
         """make_sample(i, out) -> the sample dict of dataset position i (0 .. nl-1 labeled, then unlabeled) written into
@@ -561,14 +599,16 @@ class SampleStager(HostDictStager):
         self.used[slot] = True
 
     def commit(self, slot):
-        """Head of the step (main stream): wait for the slot, point the clip's readers at it, switch the layout conversion off, copy the mask
-        and scatter the small inputs into the arena."""
-        eng, p, n = self.eng, self.eng.plan, self.eng.bs
-        main = torch.cuda.current_stream(eng.dev)
-        main.wait_event(self.ready[slot])
+        """Head of the step (main stream): wait for the slot and point every reader of the clip, the mask and the small inputs at it; the layout
+        conversion is switched off.  No kernel, no copy."""
+        eng, p = self.eng, self.eng.plan
+        torch.cuda.current_stream(eng.dev).wait_event(self.ready[slot])
         for idx in p.op_to_ndhwc:
             eng.ops["fwd"][idx]["i"][1] = 0                                    # N = 0: nothing to convert
-        base = self.x[slot].data_ptr()
-        for name, idx, q, offb in eng._img_readers:
-            eng.ops[name][idx]["p"][q] = base + offb
-        self._commit_small(slot)
+        ds = self.dev_small[slot].data_ptr()
+        where = dict(img=self.x[slot].data_ptr(), seg=self.dev[slot]["loc_msk"].data_ptr(), cls=ds + 4 * self.o_cls, lab=ds + 4 * self.o_lab,
+                     d832=ds + 4 * self.o_d832, d128=ds + 4 * self.o_d128)
+        for key, (_base, readers) in eng._patched.items():
+            for name, idx, q, offb in readers:
+                eng.ops[name][idx]["p"][q] = where[key] + offb
+        eng.labels_host, eng.action_host = self.host[slot]

@@ -38,6 +38,10 @@ for s_ in range(nsteps):
         # distance of this engine and of the reference's own fp32 run from the reference's fp64 run, and the two fp32 runs from each other
         loss_vs_f64={k: abs(got[k] - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
         ref32_vs_f64={k: abs(F("s%d::%s" % (s_, k)) - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
+        # the reference's fp32 run again under other intra-op thread counts (other reduction orders): informational -- how far its fp32 trajectory
+        # is from itself (the bar stays on the one run above)
+        ref32_other_threads_vs_f64={k: [abs(F("t%d::s%d::%s" % (t, s_, k)) - F("f64::s%d::%s" % (s_, k))) for t in (S["spread_threads"].tolist() if "spread_threads" in S.files else [])]
+                                    for k in ("total", "loc", "cls", "cons")},
         loss_vs_ref32={k: abs(got[k] - F("s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
         logits_vs_f64=float((pred.cpu().double() - p64).abs().max()), logits_ref32_vs_f64=float((p32.double() - p64).abs().max()),
         logits_vs_ref32=float((pred.cpu() - p32).abs().max()), total=got["total"]))

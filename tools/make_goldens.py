@@ -289,14 +289,17 @@ TRAJ_PARAMS = ["conv_caps.beta_u", "conv_caps.beta_a", "smooth.weight", "smooth.
 TRAJ_BUFS = ["conv1.Conv3d_1a_7x7", "conv1.Conv3d_2c_3x3", "conv1.Mixed_3b.b1b", "conv1.Mixed_4c.b0", "conv1.Mixed_4f.b3b"]
 
 
-def gen_trajectory(bs=2, nsteps=3):
+def gen_trajectory(bs=2, nsteps=3, spread_only=False, spread_threads=(1, 3, 5)):
     """The reference's own training loop for `nsteps` steps (main_ucf101.py:171-184: zero_grad -> train_model_interface -> backward ->
     optimizer.step(), optimizer = Adam(lr 1e-4, weight_decay 0, eps 1e-6) of main_ucf101.py:416), a FRESH minibatch per step, scripted
     permutation / dropout draws -- once in fp32 and once in fp64 (the anchor: Adam's first updates are +-lr per element whatever the
     gradient's size, so two fp32 implementations whose gradient NOISE differs drift apart from step 2 on; the fp64 run says how far the
     reference's own fp32 arithmetic is from the exact trajectory).  Stored per run: the loss scalars and class predictions of every step,
     the BatchNorm running statistics and num_batches_tracked after 2 * nsteps forward passes, a few small parameters and the norm of every
-    parameter after the last step."""
+    parameter after the last step.
+    Plus (`--only traj_spread` adds them to an existing fixture): the fp32 run again under other intra-op thread counts -- other reduction orders, the
+    only knob the reference's arithmetic has -- loss scalars and class predictions only, prefix `t<k>::`: how far the reference's fp32 trajectory is
+    from ITSELF, i.e. the spread the single fp32 run samples once."""
     import importlib
     import torch.nn as nn
     from oracle.step import default_args
@@ -308,7 +311,11 @@ def gen_trajectory(bs=2, nsteps=3):
     d = dict(bs=np.array(bs), nsteps=np.array(nsteps), stepids=np.array(TRAJ_STEPIDS[:nsteps]), lr=np.array(lr), epoch=np.array(epoch), ramp=np.array(ramp),
              args=np.array(repr(sorted(vars(args).items()))))
 
-    def run(double, pre):
+    if spread_only:
+        old = np.load(os.path.join(OUT, "traj_bv5.npz"))
+        d = {k: old[k] for k in old.files if not (k[0] == "t" and k[1].isdigit())}
+
+    def run(double, pre, light=False):
         ref_import.install_shims(double=double)
         from models.capsules_ucf101 import CapsNet
         from utils.losses import SpreadLoss, DiceLoss
@@ -341,8 +348,11 @@ def gen_trajectory(bs=2, nsteps=3):
             opt.step()
             for k, v in (("total", total), ("loc", loc), ("cls", cls), ("cons", cons), ("predicted_action", pred_action),
                          ("output_frame_sum", output.sum(dim=(-1, -2)))):
-                d["%ss%d::%s" % (pre, s, k)] = v
+                if not (light and k == "output_frame_sum"):
+                    d["%ss%d::%s" % (pre, s, k)] = v
             print("%strajectory step %d: total %.6f loc %.6f cls %.6f cons %.6f  (%.0f s)" % (pre, s, float(total), float(loc), float(cls), float(cons), time.time() - t0))
+        if light:
+            return
         sd = model.state_dict()
         for p_ in TRAJ_BUFS:
             for nm in ("running_mean", "running_var", "num_batches_tracked"):
@@ -353,8 +363,18 @@ def gen_trajectory(bs=2, nsteps=3):
         d[pre + "param_names"] = np.array(list(params.keys()))
         d[pre + "param_norms"] = np.array([float(p.detach().double().norm()) for p in params.values()])
         d[pre + "param_delta_norms"] = np.array([float((p.detach().double() - torch.from_numpy(np.array(state[n])).double()).norm()) for n, p in params.items()])
-    run(False, "")
-    run(True, "f64::")
+    if not spread_only:
+        run(False, "")
+        run(True, "f64::")
+    nt = torch.get_num_threads()
+    for k in spread_threads:
+        torch.set_num_threads(k)
+        try:
+            run(False, "t%d::" % k, light=True)
+        finally:
+            torch.set_num_threads(nt)
+    d["spread_threads"] = np.array(list(spread_threads))
+    d["default_threads"] = np.array(nt)
     ref_import.install_shims(double=False)
     d["seconds"] = np.array(time.time() - t0)
     save("traj_bv5.npz", d)
@@ -374,5 +394,7 @@ if __name__ == "__main__":
         gen_masks()
     if a.only in (None, "steps"):
         gen_steps(a.steps.split(",") if a.steps else None)
+    if a.only == "traj_spread":
+        gen_trajectory(spread_only=True)
     if a.only in (None, "traj"):
         gen_trajectory()
