@@ -31,6 +31,7 @@ struct WinoK {
     const float* in; const float* U; const float* bias; float* out; float* bnpart;
     int N, T, H, W, Ci, ldi, Co, ldo;
     int TH, TW, BTH, BTW, nbh, nbw, nct, nc8;
+    int scalar_epi;                         // PICONS_WINO_SCALAR_EPI=1: four-byte stores straight from the accumulators (A/B switch)
     int KT, act, flags;
     int Ti, ta, tc, tden;
     int btw_magic;
@@ -291,6 +292,12 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const bool accum = p.flags & PC_F_ACCUM;
     float s1 = 0.f, s2 = 0.f;
     const size_t plane_out = (size_t)p.H * p.W * p.ldo;
+    // Output path (round 4): the block's 2 BTH x 2 BTW output positions x 64 channels go through LDS (the operand images are dead: the K
+    // loop ended with a barrier) and leave as row-contiguous 16-byte stores, 16 per thread -- instead of 64 four-byte stores per thread, each
+    // with its own 64-bit address (12 k cycles of a conv112 block's 130 k).  Needs 16-byte aligned channel slices; otherwise the scalar path.
+    const bool vec_ok = !(VAR & (8 | 32)) && !p.scalar_epi && p.ldo % 4 == 0 && ((uintptr_t)p.out % 16 == 0);
+    float* Tst = smem;                                    // [2 BTH * 2 BTW positions][WC channels]
+    const int OW2 = 2 * p.BTW;
     float* obase = p.out + ((size_t)n * p.T + t) * plane_out + co;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -318,10 +325,29 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
                 float v = y[a][b] + bv;
                 s1 += v; s2 += v * v;
                 if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
+                if (vec_ok) { Tst[((2 * li + a) * OW2 + 2 * lj + b) * WC + wn * 32 + (lane & 31)] = v; continue; }
                 float* o = obase + ((size_t)(2 * oi + a) * p.W + 2 * oj + b) * p.ldo;
                 if (accum) v += *o;
                 if (!(VAR & 8) || v == 12345.678f) *o = v;
             }
+    }
+    if (vec_ok) {
+        __syncthreads();
+        const int c4 = tid & 15, co0 = ct * WC + c4 * 4;              // this thread's 16-byte channel chunk of every 16th position
+        const int npo = 4 * p.BTH * p.BTW;
+        float* ob = p.out + ((size_t)n * p.T + t) * plane_out + co0;
+        if (co0 < p.Co) {
+#pragma unroll 4
+            for (int pos = tid >> 4; pos < npo; pos += 16) {
+                const int lr = ((pos >> 1) * p.btw_magic) >> 16, lc = pos - lr * OW2;       // pos / (2 BTW)
+                const int orow = 2 * bh * p.BTH + lr, ocol = 2 * bw * p.BTW + lc;
+                if (orow >= 2 * p.TH || ocol >= 2 * p.TW) continue;
+                f32x4 v = *(const f32x4*)(Tst + pos * WC + c4 * 4);
+                float* o = ob + ((size_t)orow * p.W + ocol) * p.ldo;
+                if (accum) v += *(const f32x4*)o;
+                *(f32x4*)o = v;
+            }
+        }
     }
     if (VAR & 32) {
         stamp[3] = __builtin_amdgcn_s_memtime();
@@ -369,6 +395,8 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     k.nbh = cdiv(k.TH, k.BTH); k.nbw = cdiv(k.TW, k.BTW);
     k.btw_magic = (65536 + k.BTW - 1) / k.BTW;
     k.nct = cdiv(d->Co, WC); k.nc8 = d->Ci / WK;
+    static const int scalar_epi = getenv("PICONS_WINO_SCALAR_EPI") ? atoi(getenv("PICONS_WINO_SCALAR_EPI")) : 0;
+    k.scalar_epi = scalar_epi;
     k.KT = d->KT; k.act = d->act; k.flags = d->flags;
     PC_CHECK_ARG(d->Ti >= 1 && d->ta >= 1 && d->tden >= 1, "pc_wino: Ti / ta / tden must be >= 1 (Ti=%d ta=%d tden=%d)", d->Ti, d->ta, d->tden);
     k.Ti = d->Ti; k.ta = d->ta; k.tc = d->tc; k.tden = d->tden;

@@ -479,6 +479,8 @@ def test_training_trajectory_vs_reference(tmp_path, mode):
     import socket
     import subprocess
     import sys
+    if os.environ.get("PICONS_LANES", "4") != "4":
+        pytest.skip("the trajectory is pinned at the product default of four lanes (tools/gpu/switch_matrix.sh runs this file with PICONS_LANES=1)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
     out = str(tmp_path / "traj.json")
