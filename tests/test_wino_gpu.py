@@ -62,6 +62,10 @@ def test_wino_channel_slices_and_bn_partials():
     ops.wino_conv(d, xd[..., 8:], U, outw[..., 4:], bnpart=part)
     assert (outw[..., 4:4 + Co].cpu().double() - ref).abs().max().item() <= 2e-5
     assert outw[..., :4].abs().max().item() == 0 and outw[..., 4 + Co:].abs().max().item() == 0
+    # a slice that is not 16-byte aligned (channel offset 2): the kernel falls back from its row-contiguous 16-byte stores to 4-byte ones
+    out2 = torch.zeros(N, T, H, W, ldo, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, 3), xd[..., 8:], U, out2[..., 2:])
+    assert torch.equal(out2[..., 2:2 + Co], outw[..., 4:4 + Co]) and out2[..., :2].abs().max().item() == 0 and out2[..., 2 + Co:].abs().max().item() == 0
     per = rows // N
     for n in range(N):
         s = part[n * per:(n + 1) * per].sum(0).cpu().double()
