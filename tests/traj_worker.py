@@ -37,6 +37,7 @@ for s_ in range(nsteps):
     res["steps"].append(dict(
         # distance of this engine and of the reference's own fp32 run from the reference's fp64 run, and the two fp32 runs from each other
         loss_vs_f64={k: abs(got[k] - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
+        loss_f64={k: F("f64::s%d::%s" % (s_, k)) for k in ("total", "loc", "cls", "cons")},
         ref32_vs_f64={k: abs(F("s%d::%s" % (s_, k)) - F("f64::s%d::%s" % (s_, k))) for k in ("total", "loc", "cls", "cons")},
         # the reference's fp32 run again under other intra-op thread counts (other reduction orders): informational -- how far its fp32 trajectory
         # is from itself (the bar stays on the one run above)
