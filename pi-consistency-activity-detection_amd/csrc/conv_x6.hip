@@ -500,8 +500,12 @@ extern "C" int pc_conv_x6_ok(const pc_conv_desc* d) {
     const int groups = d->groups > 0 ? d->groups : 1;
     const X6Tile t = pc_x6_tile(d, groups);
     const long long Mg = (long long)(d->N / groups) * d->Tq * d->Hq * d->Wq;
-    // (A rule on K as well -- the seven launches of <= 4 chunks, K <= 128, on the 4-wave tiles run 0.73 - 0.92x the fp32 kernel,
-    // profiles/r04_x6_launches.txt -- is worth 0.04 ms per step and was not adopted: DESIGN.md 8.)
+    // ... and a K loop long enough to pay for the pipeline's prologue: launches of <= 4 chunks (K <= 128: the 1 x 1 x 1 layers over 32 - 128
+    // channels) run 0.73 - 0.92x the fp32 kernel on the 4-wave tiles, 1.02 - 1.04x on the 256 x 128 tile (profiles/r04_x6_launches.txt).
+    // PICONS_X6_KMIN = least number of 32-channel chunks (default 5; 1 = no rule)
+    static const int kmin = getenv("PICONS_X6_KMIN") ? atoi(getenv("PICONS_X6_KMIN")) : 5;
+    const int chunks = d->ntap[0] * d->ntap[1] * d->ntap[2] * (d->Ci / BK);
+    if (chunks < kmin && t.bm != 256) return 0;
     return (long long)groups * cdiv(Mg, t.bm) * cdiv(d->Co, t.bn) >= 150 ? 1 : 0;
 }
 
