@@ -381,6 +381,9 @@ def main():
         si.run(min(3, a.steps), a.epoch, ramp, reducer, args.lr)                      # warm-up (pinned buffers, first uploads)
         if world > 1:
             torch.distributed.barrier()
+        if reducer is not None:
+            torch.cuda.synchronize()
+            reducer.stats()                    # reset: the diagnostics below cover the headline leg only
         sec, last, timed_steps = si.run(a.steps, a.epoch, ramp, reducer, args.lr, timed_kind=main_kind, time_every=max(1, a.time_every))
         if world > 1:
             torch.distributed.barrier()
@@ -388,10 +391,19 @@ def main():
         inputs_note = ("staged inside the timed region: every step prepares a fresh minibatch from host uint8 frames (upload of the 8 selected frames per sample, "
                        "pc_clip_from_u8, cat + shuffle into the arena; the next step's samples on a side stream) -- main_ucf101.py:52-79 is part of the step")
     else:
+        if reducer is not None:
+            torch.cuda.synchronize()
+            reducer.stats()
         ms_total, last, timed_steps = timed_resident(eng, a.steps, main_kind, max(1, a.time_every), reducer)
         inputs_note = "resident in HBM before the timed region (--resident-inputs / --jhmdb: no per-step input staging in this run)"
     if main_kind is not None:
         eng.collect_timing()
+    # per-step diagnostics of the headline leg's collectives (host time in reducer.wait(), device time the main stream sat behind its last
+    # backward kernel until the last collective finished): what a SCALE line is explained with
+    reducer_stats = {}
+    if reducer is not None:
+        torch.cuda.synchronize()
+        reducer_stats = reducer.stats()
     ms_step = ms_total / a.steps
     value = world * a.bs * a.steps / (ms_total / 1e3)
     main_ms, main_count = eng.kind_ms, eng.kind_count
@@ -406,20 +418,40 @@ def main():
         ms_r, last_r, _ = timed_resident(eng, n_leg, red=reducer)
         resident = {"value": world * a.bs * n_leg / (ms_r / 1e3), "unit": "clips/s", "ms_per_step": ms_r / n_leg, "steps": n_leg, "loss_total": last_r["total"]}
 
-    # ---- the other GEMM families' kernels get their event pairs in two extra single-stream steps each (one op kind per timed replay)
-    def kind_leg(kind):
-        eng.kind_ms, eng.kind_count = 0.0, 0
-        for _ in range(2):
-            eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=kind, collect=False)
+    # ---- every GEMM family's kernels get their event pairs in single-stream replays of their own (one op kind per timed replay): one warm
+    # replay that carries events and is thrown away, then `reps` measured ones.  A leg whose replays disagree by more than 1.5x is reported
+    # as null with the reason (one driver-side line carried a 4.8x outlier for one leg).
+    def kind_leg(kind, reps=3):
+        eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=kind, collect=False)
         torch.cuda.synchronize()
         eng.collect_timing()
-        return eng.kind_ms / 2, eng.kind_count // 2
-    wino_ms = wino_count = f32c_ms = f32c_count = 0
+        per = []
+        for _ in range(reps):
+            eng.kind_ms, eng.kind_count = 0.0, 0
+            eng.run_staged(a.epoch, ramp, reducer=reducer, timed_kind=kind, collect=False)
+            torch.cuda.synchronize()
+            eng.collect_timing()
+            per.append((eng.kind_ms, eng.kind_count))
+        return per
+
+    def leg_summary(per, also_ms=None):
+        """-> (total ms, total launches, replays, None) or (0, 0, 0, reason)."""
+        if not per or not per[0][1]:
+            return 0.0, 0, 0, "no launch of this kind in the step"
+        ms = [m for m, _c in per] + ([also_ms] if also_ms else [])
+        if len({c for _m, c in per}) != 1:
+            return 0.0, 0, 0, "replays timed different launch counts: %s" % [c for _m, c in per]
+        if max(ms) > 1.5 * min(ms):
+            return 0.0, 0, 0, "replays disagree by more than 1.5x (kernel ms per step: %s)" % ["%.3f" % m for m in ms]
+        return sum(m for m, _c in per), sum(c for _m, c in per), len(per), None
+    legs = {}
     if main_kind is not None:
         eng.stage(lab, unl, perm, drops)
-        wino_ms, wino_count = kind_leg(capi.OP_WINO_CONV)
+        in_region = (main_ms / timed_steps) if (timed_steps and main_count) else None
+        legs["main"] = leg_summary(kind_leg(main_kind), in_region)
+        legs["wino"] = leg_summary(kind_leg(capi.OP_WINO_CONV))
         if split_on:
-            f32c_ms, f32c_count = kind_leg(capi.OP_CONV)
+            legs["f32c"] = leg_summary(kind_leg(capi.OP_CONV))
 
     # ---- the reference's own minibatch contract inside the timed region: float64 host dicts -> pinned double buffer -> copy stream
     dict_leg = None
@@ -457,10 +489,11 @@ def main():
     busy_steps = 0
     if not a.no_extra_legs:
         eng.stage(lab, unl, perm, drops)
-        while time.perf_counter() - t_gpu0 < 3.0 or busy_steps < 20:
+        t_busy0 = time.perf_counter()
+        while time.perf_counter() - t_busy0 < 3.0 or busy_steps < 20:      # >= 3 s of GPU work measured from the phase's own start
             eng.run_staged(a.epoch, ramp, reducer=reducer)
             busy_steps += 1
-            if busy_steps >= 400:
+            if busy_steps >= 600:
                 break
         torch.cuda.synchronize()
 
@@ -488,42 +521,51 @@ def main():
             except Exception:
                 traffic = None
 
-    def roof(kernel, exec_f, issued_f, valid_f, kms, count, steps_t, peak, extra=None):
-        if not count or not steps_t:
-            return None
+    def roof(kernel, exec_f, issued_f, valid_f, leg, peak, extra=None):
+        kms, count, steps_t, why = leg if leg is not None else (0.0, 0, 0, "leg not run")
+        if why is not None or not count or not steps_t:
+            return {"bound": "mfma", "kernel": kernel, "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None, "invalid": why}
         ms_s = kms / steps_t
         tf = lambda f: f / (ms_s * 1e-3) / 1e12
         r = {"bound": "mfma", "kernel": kernel, "achieved": tf(exec_f), "peak": peak, "unit": "TFLOP/s", "frac": tf(exec_f) / peak,
              "frac_mfma_issued": tf(issued_f) / peak, "frac_valid": tf(valid_f) / peak,
              "launches_per_step": count // steps_t, "avg_launch_ms": kms / count, "kernel_ms_per_step": ms_s, "timed_steps": steps_t,
-             "flops_per_launch": exec_f * steps_t / count,
+             "flops_per_launch": exec_f * steps_t / count, "traffic": None,
+             "timing": "hipEvent pair in every launch's own dispatch, single-stream replays of the step (one warm replay discarded, %d measured; replays within 1.5x)" % steps_t,
              "flops_counted": "executed: per launch the host walks the kernel's tiles (pc_conv_work) and counts real rows x real columns x the K each block "
                               "walks -- taps that are padding for a whole tile are skipped by the kernel and NOT counted"}
         r.update(extra or {})
         return r
-    roofline = roof_f32conv = None
+    roof_x6 = roof_f32conv = roof_wino = None
     if main_kind is not None and split_on:
-        roofline = roof("conv_x6_kernel (fp32 conv / dgrad / convT multiplied on the bf16 matrix cores: 3 bf16 terms per operand, 6 products on "
-                        "v_mfma_f32_32x32x16_bf16, fp32 accumulate)", x6_exec, tot(fx, "mfma"), tot(fx, "valid"), main_ms, main_count, timed_steps,
-                        PEAK_BF16_MFMA_TFLOPS / 6.0,
-                        {"peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate = %.1f TFLOP/s of fp32-equivalent work; the chip holds "
-                                      "1.35 - 1.5 GHz of its 2.4 GHz in this kernel (in-kernel clock stamps, profiles/r04_x6_tile_probe.txt)" % (PEAK_BF16_MFMA_TFLOPS / 6.0),
-                         "traffic": traffic, "traffic_source": traffic_src})
+        roof_x6 = roof("conv_x6_kernel (fp32 conv / dgrad / convT multiplied on the bf16 matrix cores: 3 bf16 terms per operand, 6 products on "
+                       "v_mfma_f32_32x32x16_bf16, fp32 accumulate)", x6_exec, tot(fx, "mfma"), tot(fx, "valid"), legs.get("main"),
+                       PEAK_BF16_MFMA_TFLOPS / 6.0,
+                       {"peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate = %.1f TFLOP/s of fp32-equivalent work; the chip holds "
+                                     "1.35 - 1.5 GHz of its 2.4 GHz in this kernel (in-kernel clock stamps, profiles/r04_x6_tile_probe.txt)" % (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                        "traffic": traffic, "traffic_source": traffic_src,
+                        "in_region_kernel_ms_per_step": (main_ms / timed_steps) if timed_steps else None, "in_region_timed_steps": timed_steps})
         roof_f32conv = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: the launches that stay on v_mfma_f32_32x32x2_f32 -- the RGB stem, "
-                            "channel counts that are not multiples of 32, launches too small to gain)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"), f32c_ms * 2, f32c_count * 2, 2,
+                            "channel counts that are not multiples of 32, launches too small to gain)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"), legs.get("f32c"),
                             PEAK_FP32_MFMA_TFLOPS)
-        if roofline:
-            roofline["frac_of_fp32_mfma_peak"] = roofline["achieved"] / PEAK_FP32_MFMA_TFLOPS
+        if roof_x6.get("achieved"):
+            roof_x6["frac_of_fp32_mfma_peak"] = roof_x6["achieved"] / PEAK_FP32_MFMA_TFLOPS
     elif main_kind is not None:
-        roofline = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: conv fwd / dgrad / convT)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"),
-                        main_ms, main_count, timed_steps, PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic, "traffic_source": traffic_src})
-    roof_wino = None
-    if wino_count:
+        roof_f32conv = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: conv fwd / dgrad / convT)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"),
+                            legs.get("main"), PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic, "traffic_source": traffic_src})
+    if main_kind is not None:
         fzd = sum(pl.flops_reference_counted_wino()[n] for n in lists)
         roof_wino = roof("wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
-                         wino_ms * 2, wino_count * 2, 2, PEAK_FP32_MFMA_TFLOPS,
-                         {"direct_equivalent_tflops": fzd / (wino_ms * 1e-3) / 1e12,      # the 3x3x3 formulation's FLOPs over the same time (2.25x the transform-domain work)
-                          "flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"})
+                         legs.get("wino"), PEAK_FP32_MFMA_TFLOPS,
+                         {"flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"})
+        if roof_wino.get("kernel_ms_per_step"):
+            roof_wino["direct_equivalent_tflops"] = fzd / (roof_wino["kernel_ms_per_step"] * 1e-3) / 1e12      # the 3x3x3 formulation's FLOPs over the same time
+    # `roofline` = the GEMM family with the LARGEST single-stream kernel time per step (the dominant kernel); the others keep their own blocks
+    fam = [r for r in (roof_x6, roof_f32conv, roof_wino) if r is not None and r.get("kernel_ms_per_step")]
+    roofline = max(fam, key=lambda r: r["kernel_ms_per_step"]) if fam else None
+    if roofline is not None:
+        roofline = dict(roofline, dominant_by="largest single-stream kernel time per step among the conv families (%s)"
+                        % ", ".join("%s %.2f ms" % (r["kernel"].split(" ")[0], r["kernel_ms_per_step"]) for r in fam))
     ms_for_step = resident["ms_per_step"] if resident else ms_step
     roof_step = {"executed_gflop_per_step": step_exec / 1e9, "achieved": step_exec / (ms_step * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
                  "unit": "TFLOP/s", "frac": step_exec / (ms_step * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
@@ -556,13 +598,14 @@ def main():
         "dict_contract": dict_leg,
         "split_off": split_off,
         "roofline": roofline,
+        "roofline_conv_x6": roof_x6,
         "roofline_fp32_conv": roof_f32conv,
         "roofline_winograd": roof_wino,
         "roofline_step": roof_step,
         "ranks_observed": ranks_observed,
         "busy_steps_outside_timed_regions": busy_steps,
-        "reducer": None if reducer is None else {"buckets": len(reducer.buckets), "backend": torch.distributed.get_backend(),
-                                                 "forced_single_rank": forced},
+        "reducer": None if reducer is None else dict(reducer_stats, buckets=len(reducer.buckets), backend=torch.distributed.get_backend(),
+                                                     forced_single_rank=forced, bucket_table=reducer.bucket_table()),
     }
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

@@ -12,6 +12,10 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 DIAG = os.environ.get("PICONS_DIAG_LIB", "0") not in ("", "0")
 DIAG_SWITCHES = ("PICONS_CONV_ABLATE", "PICONS_WGRAD_ABLATE", "PICONS_WINO_VARIANT")
 LIB_PATH = os.path.join(_HERE, "libpicons_diag.so" if DIAG else "libpicons.so")
+# development only (tools/gpu/*.sh A/B runs): another BUILD of this same library, by file name inside the package directory -- e.g. the
+# previous commit's build kept as libpicons_base.so -- so that two builds can be timed in one gpurun call on one box
+if os.environ.get("PICONS_LIB_NAME"):
+    LIB_PATH = os.path.join(_HERE, os.path.basename(os.environ["PICONS_LIB_NAME"]))
 _lib = None
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

@@ -299,15 +299,20 @@ extern "C" int pc_run_ops_timed_collect(float* ms, int* count) {
     float total = 0.f;
     const int pairs = (int)g_pending.size() / 2;
     if (pairs) (void)hipEventSynchronize(g_pending.back());
+    static const char* dump = getenv("PICONS_TIMED_DUMP");       // diagnostics: one line per collected pair (ms) appended to this file
+    FILE* df = dump ? fopen(dump, "a") : nullptr;
+    if (df) fprintf(df, "# collect %d pairs\n", pairs);
     for (int i = 0; i < pairs; ++i) {
         float e = 0.f;
         (void)hipEventSynchronize(g_pending[2 * i + 1]);
         (void)hipEventElapsedTime(&e, g_pending[2 * i], g_pending[2 * i + 1]);
+        if (df) fprintf(df, "%d %.4f\n", i, e);
         total += e;
         g_ev_pool.push_back(g_pending[2 * i]);
         g_ev_pool.push_back(g_pending[2 * i + 1]);
     }
     g_pending.clear();
+    if (df) fclose(df);
     if (ms) *ms = total;
     if (count) *count = pairs;
     return PC_OK;

@@ -1654,7 +1654,10 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.nchunks = d->N * d->Tq * d->Hq * q.nseg;
         q.mt = cdiv(d->Cd, geo.bm); q.ncs = d->Cs / (csb64 ? 64 : 32);
         const int64_t tiles = (int64_t)q.mt * q.ncs * q.ntap_t * q.ntap_h;
-        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(rounds * ((bkp == 56 || geo.x6) ? 512 : 768) / (tiles * nprob)));
+        // resident-block slots of the variant that will run: the fp32 kernels hold three blocks per CU (two with 56-position segments), the
+        // bf16-split ones two -- except wgrad3_x6_kernel<128, 64, 32, 4>, whose 82 KiB of LDS admit ONE block per CU
+        const int slots = geo.x6 ? ((!csb64 && bkp == 64) ? 256 : 512) : (bkp == 56 ? 512 : 768);
+        int splitk = d->splitk > 0 ? d->splitk : (d->splitk == -1 ? 1 : (int)(rounds * slots / (tiles * nprob)));
         const int maxsplit = q.nchunks / 8 > 0 ? q.nchunks / 8 : 1;
         if (splitk > maxsplit) splitk = maxsplit;
         if (splitk < 1) splitk = 1;

@@ -3,6 +3,7 @@
 // backward, layout changes, batched transposes for weight re-layout, fill/axpy, fused Adam.
 // All loads/stores are float4 along the channel (innermost NDHWC) dimension.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -442,11 +443,12 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, int
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                                                   int64_t n, float lr_bc1, float b1, float b2, float eps, float inv_sqrt_bc2, float gscale) {
+                                                   int64_t n, float lr_bc1, float b1, float b2, float omb1, float omb2, float eps, float inv_sqrt_bc2,
+                                                   float gscale) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * gscale;
-        const float mi = b1 * m[i] + (1.f - b1) * gi;
-        const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+        const float mi = b1 * m[i] + omb1 * gi;
+        const float vi = b2 * v[i] + omb2 * gi * gi;
         m[i] = mi; v[i] = vi;
         p[i] -= lr_bc1 * mi / (sqrtf(vi) * inv_sqrt_bc2 + eps);
     }
@@ -482,6 +484,16 @@ inline int grid_for(int64_t n, int per_thread = 1) {
     if (b > 256 * 16) b = 256 * 16;
     if (b < 1) b = 1;
     return (int)b;
+}
+// the double nearest to the shortest decimal string that converts back to exactly this float (0.999f -> 0.999, 0.9f -> 0.9)
+inline double pc_decimal_of_float(float x) {
+    char buf[40];
+    for (int prec = 1; prec <= 9; ++prec) {
+        snprintf(buf, sizeof(buf), "%.*g", prec, (double)x);
+        const double d = strtod(buf, nullptr);
+        if ((float)d == x) return d;
+    }
+    return (double)x;
 }
 inline int64_t red_rows_per_block(int64_t rows) {
     int64_t r = (rows + 1023) / 1024;
@@ -705,9 +717,13 @@ extern "C" int pc_adam_step(float* p, const float* g, float* m, float* v, int64_
                             float gscale, pc_stream s) {
     PC_CHECK_ARG(p && g && m && v && step >= 1 && n >= 0, "pc_adam_step: bad args");
     if (n == 0) return PC_OK;                  // an un-armed early-Adam op of the backward list
-    const double bc1 = 1.0 - pow((double)b1, step), bc2 = 1.0 - pow((double)b2, step);
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, (float)(lr / bc1), b1, b2, eps,
-                       (float)(1.0 / sqrt(bc2)), gscale);
+    // torch.optim.Adam (main_ucf101.py:416) holds its betas as Python doubles: 1 - beta and the bias corrections 1 - beta^t are computed in
+    // double and only then rounded to fp32 (1 - 0.999 -> 0.001f; in fp32, 1.f - 0.999f = 0.00100004673: 4.7e-5 off in every second-moment
+    // increment).  The ABI carries floats, so the double the caller meant is recovered as the shortest decimal that round-trips the float.
+    const double b1d = pc_decimal_of_float(b1), b2d = pc_decimal_of_float(b2);
+    const double bc1 = 1.0 - pow(b1d, step), bc2 = 1.0 - pow(b2d, step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n, 4)), dim3(256), 0, (hipStream_t)s, p, g, m, v, n, (float)(lr / bc1), b1, b2,
+                       (float)(1.0 - b1d), (float)(1.0 - b2d), eps, (float)(1.0 / sqrt(bc2)), gscale);
     PC_CHECK_LAUNCH("adam");
     return PC_OK;
 }

@@ -35,6 +35,7 @@ struct WinoK {
     int KT, act, flags;
     int Ti, ta, tc, tden;
     int btw_magic;
+    int rpitch, rhalf;                      // raw-patch image: positions per patch row / offset of the odd columns inside a row (choose_pitch)
 };
 
 constexpr int WT = 64;            // tiles per block (rows of the transform-domain GEMMs)
@@ -85,9 +86,13 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, long long sO, l
 // K chunk = 8 input channels of one temporal tap.  Three LDS images per chunk, all filled by LDS-DMA or by the block itself:
 //   R  the raw (2 BTH + 2) x (2 BTW + 2) input patch of the block, [position][8 channels] (32 B per position, zero line for padding):
 //      each input element is fetched ONCE per block (per-tile register loads fetched it ~4.5 times as 16-byte pieces of 64 different
-//      cache lines per instruction, and cost a third of the kernel),
-//   V  the transformed patch B^T d B, [xi*4+nu][k half][tile][4], written by the block: thread = (tile, 4-channel half, two of the
-//      four B^T rows): 12 ds_read_b128 of R, 16 float4 adds, 8 ds_write_b128,
+//      cache lines per instruction, and cost a third of the kernel).  Round 5: the positions of a patch row are stored EVEN COLUMNS FIRST
+//      (position (r, c) at r * rpitch + (c & 1) * rhalf + c / 2) and a lane of the transform is (tile lane / 2, channel half lane % 2): the
+//      16 lanes of a ds_read_b128 group then read 8 tiles x 2 halves = 16 consecutive 16-byte slots of one parity block instead of 16
+//      slots 64 bytes apart (4-way conflicts: SQ_LDS_BANK_CONFLICT was 37 % of the kernel's LDS-active cycles in rounds 3 and 4); rpitch is
+//      chosen on the host so that the tiles of a group that sit in different tile rows do not meet either (choose_pitch),
+//   V  the transformed patch B^T d B, [xi*4+nu][k half][tile ^ 4 (k half)][4], written by the block: thread = (tile, 4-channel half, two of the
+//      four B^T rows): 12 ds_read_b128 of R, 16 float4 adds, 8 ds_write_b128 (the XOR keeps the two halves of a store group on different banks),
 //   U  the transformed weights, contiguous in HBM by construction.
 // R runs two chunks ahead (its DMA has a whole chunk to land), U one; one barrier per chunk.
 // VAR (diagnostics, PICONS_WINO_VARIANT; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no U DMA, 4 = no transform stores,
@@ -117,19 +122,21 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     unsigned roff[3];                  // byte offset inside the source plane, DMA_OOB for padding positions (the DMA writes zeros there)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int q = (wave + 4 * j) * 32 + (lane >> 1);
-        const int pr = q / PW, pc = q - pr * PW;
+        const int q = (wave + 4 * j) * 32 + (lane >> 1);                 // slot of the image: row q / rpitch, even columns first
+        const int pr = q / p.rpitch, rem = q - pr * p.rpitch;
+        const int odd = rem >= p.rhalf ? 1 : 0, idx = rem - odd * p.rhalf;
+        const int pc = 2 * idx + odd;
         const int h = h0 + pr, w = w0 + pc;
-        const bool ok = q < npos && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
+        const bool ok = pr < PH && idx < p.BTW + 1 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         roff[j] = ok ? (unsigned)(((h * p.W + w) * p.ldi + (lane & 1) * 4) * 4) : DMA_OOB;
     }
     const unsigned uoff = lane * 16;   // U pieces are contiguous images
 
-    // transform role: thread = (tile, k half, row pair); reads 3 rows x 4 columns of R
-    const int ttile = lane, tkh = wave & 1, thalf = wave >> 1;
+    // transform role: thread = (tile, k half, row pair); reads 3 rows x 4 columns of R.  Lane = (tile lane / 2 of the wave's 32, k half lane % 2)
+    const int ttile = (wave & 1) * 32 + (lane >> 1), tkh = lane & 1, thalf = wave >> 1;
     const int tli = ttile / p.BTW, tlj = ttile - tli * p.BTW;
     const bool tval = ttile < p.BTH * p.BTW;       // (tiles beyond the image read zero lines: their patch positions are padding)
-    const int rbase = tval ? (((2 * tli + thalf) * PW + 2 * tlj) * 2 + tkh) * 4 : 0;      // float offset of patch (row thalf, col 0) in R
+    const int rbase = tval ? (((2 * tli + thalf) * p.rpitch + tlj) * 2 + tkh) * 4 : tkh * 4;      // float offset of patch (row thalf, col 0) in R
     // temporal taps whose source frame exists: tap kt reads input frame (t * ta + kt + tc) / tden when that is an integer in [0, Ti)
     int nkt = 0, ktl0 = 0, ktl1 = 0, ktl2 = 0, ttl0 = 0, ttl1 = 0, ttl2 = 0;
     for (int kt = 0; kt < p.KT; ++kt) {
@@ -174,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     float* vb = nullptr;
     auto read2 = [&](int g, int c0) {             // two columns of patch row g of this thread's three rows (tiles beyond the block's
 #pragma unroll                                    // rectangle read some valid position: their rows are never stored)
-        for (int c = c0; c < c0 + 2; ++c) d[g * 4 + c] = *(const f32x4*)(rsrc + (g * PW + c) * 8);
+        for (int c = c0; c < c0 + 2; ++c) d[g * 4 + c] = *(const f32x4*)(rsrc + (g * p.rpitch + (c & 1) * p.rhalf + (c >> 1)) * 8);
     };
     // B^T rows held by this thread: half 0 -> rows 0, 1 (d0 - d2, d1 + d2) of patch rows (d0, d1, d2); half 1 -> rows 3, 2 (d1 - d3, d2 - d1)
     // of patch rows (d1, d2, d3).  q = 0: first of the pair; q = 1: second, as d[1] + ca * d[0] + cb * d[2] with wave-uniform (ca, cb) =
@@ -218,7 +225,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     if (VAR & 32) stamp[0] = __builtin_amdgcn_s_memtime();
 
     const int kh = lane >> 5;
-    const int aoff = (kh * 64 + wm * 32 + (lane & 31)) * 4, boff = (kh * 64 + wn * 32 + (lane & 31)) * 4;
+    const int aoff = (kh * 64 + ((wm * 32 + (lane & 31)) ^ (kh * 4))) * 4, boff = (kh * 64 + wn * 32 + (lane & 31)) * 4;
+    const int voff = (tkh * 64 + (ttile ^ (tkh * 4))) * 4;             // this thread's slot of a V plane
     // prologue: R(0), R(1), U(0) in flight; V(0) from R(0)
     if (nchunks > 0) {
         issue_r(r_base(rq, rc8), 0);
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     __syncthreads();
     if (nchunks > 0) {
         rsrc = Rs + rbase;
-        vb = Vs + (tkh * 64 + ttile) * 4;
+        vb = Vs + voff;
 #pragma unroll
         for (int g = 0; g < 3; ++g) { read2(g, 0); read2(g, 2); }
 #pragma unroll
@@ -254,7 +262,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         ul = Us + (buf ^ 1) * PLANE + wave * 8 * 256;
         advance(uq, uc8);
         rsrc = Rs + (buf ^ 1) * RPLANE + rbase;
-        vb = Vs + (buf ^ 1) * PLANE + (tkh * 64 + ttile) * 4;
+        vb = Vs + (buf ^ 1) * PLANE + voff;
         const float* va = Vs + buf * PLANE + aoff;
         const float* ub = Us + buf * PLANE + boff;
         f32x4 a0 = *(const f32x4*)va, b0 = *(const f32x4*)ub, a1, b1;
@@ -294,8 +302,9 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const size_t plane_out = (size_t)p.H * p.W * p.ldo;
     // Output path (round 4): the block's 2 BTH x 2 BTW output positions x 64 channels go through LDS (the operand images are dead: the K
     // loop ended with a barrier) and leave as row-contiguous 16-byte stores, 16 per thread -- instead of 64 four-byte stores per thread, each
-    // with its own 64-bit address (12 k cycles of a conv112 block's 130 k).  Needs 16-byte aligned channel slices; otherwise the scalar path.
-    const bool vec_ok = !(VAR & (8 | 32)) && !p.scalar_epi && p.ldo % 4 == 0 && ((uintptr_t)p.out % 16 == 0);
+    // with its own 64-bit address (12 k cycles of a conv112 block's 130 k).  Needs 16-byte aligned channel slices AND whole 4-channel chunks
+    // (Co % 4 == 0: a chunk that straddles Co would overwrite the neighbouring slice of a wider tensor); otherwise the scalar path.
+    const bool vec_ok = !(VAR & (8 | 32)) && !p.scalar_epi && p.ldo % 4 == 0 && p.Co % 4 == 0 && ((uintptr_t)p.out % 16 == 0);
     float* Tst = smem;                                    // [2 BTH * 2 BTW positions][WC channels]
     const int OW2 = 2 * p.BTW;
     float* obase = p.out + ((size_t)n * p.T + t) * plane_out + co;
@@ -372,12 +381,41 @@ void choose_block(int TH, int TW, int& bth, int& btw) {
         int h = 64 / w;
         if (h > TH) h = TH;
         if (h < 1) continue;
-        if ((2 * h + 2) * (2 * w + 2) * 2 > RMAX * 64) continue;          // the raw patch image must fit its LDS-DMA pieces
+        if ((2 * h + 2) * (2 * w + 2) * 2 > RMAX * 64) continue;          // the raw patch image must fit its LDS-DMA pieces (choose_pitch may pad its rows)
         const double blocks = (double)cdiv(TH, h) * cdiv(TW, w);
         const double waste = blocks * 64.0 / ((double)TH * TW);
         const double aspect = (double)(2 * w + 2) * (2 * h + 2) / (4.0 * w * h);      // patch read amplification: prefer square-ish
         const double cost = waste * (1.0 + 0.05 * aspect);
         if (cost < best - 1e-9) { best = cost; bth = h; btw = w; }
+    }
+}
+
+// Row pitch of the raw-patch image (positions): the transform's ds_read_b128 of patch position (2 ti + r, 2 tj + c) is issued by lane groups
+// of 16 = 8 tiles x 2 channel halves ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32: MI355X_MICROARCH.md, LDS), and a group is
+// conflict-free when its 8 tiles sit on 8 different 32-byte positions modulo 8.  Tiles of one tile row are consecutive positions of a
+// parity block; tiles of different rows are 2 rpitch apart per row -- pick the pitch (>= the patch width, image <= RMAX * 32 positions)
+// with the fewest extra LDS cycles over all groups of both wave halves.
+void choose_pitch(int bth, int btw, int& rpitch, int& rhalf) {
+    const int PW = 2 * btw + 2, PH = 2 * bth + 2;
+    rhalf = btw + 1;
+    static const int lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
+    int best = 1 << 30;
+    rpitch = PW;
+    for (int pitch = PW; pitch <= PW + 15 && PH * pitch <= RMAX * 32; ++pitch) {
+        int cost = 0;
+        for (int half = 0; half < 4; ++half)            // (wave & 1, lanes 0-31 / 32-63): tiles 16 half ..
+            for (int gset = 0; gset < 2; ++gset) {
+                int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mx = 0;
+                for (int q = 0; q < 16; q += 2) {
+                    const int tile = half * 16 + (lanes[gset][q] >> 1);
+                    if (tile >= bth * btw) continue;
+                    const int ti = tile / btw, tj = tile - ti * btw;
+                    const int c = ++cnt[(2 * ti * pitch + tj) & 7];
+                    mx = c > mx ? c : mx;
+                }
+                cost += mx > 1 ? mx - 1 : 0;
+            }
+        if (cost < best) { best = cost; rpitch = pitch; }
     }
 }
 
@@ -392,6 +430,7 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     k.N = d->N; k.T = d->T; k.H = d->H; k.W = d->W; k.Ci = d->Ci; k.ldi = d->ldi; k.Co = d->Co; k.ldo = d->ldo;
     k.TH = d->H / 2; k.TW = d->W / 2;
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
+    choose_pitch(k.BTH, k.BTW, k.rpitch, k.rhalf);
     k.nbh = cdiv(k.TH, k.BTH); k.nbw = cdiv(k.TW, k.BTW);
     k.btw_magic = (65536 + k.BTW - 1) / k.BTW;
     k.nct = cdiv(d->Co, WC); k.nc8 = d->Ci / WK;

@@ -141,6 +141,22 @@ WGRAD_FIELDS = ["N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds
 POOL_FIELDS = ["N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo", "k", "s", "padf"]
 
 
+CONV_VEC3 = ("ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep")
+
+
+def unflatten_conv(flat):
+    """Inverse of flatten(d, CONV_FIELDS): the int list an OP_CONV / OP_CONV_X6 op carries -> descriptor dict."""
+    d, q = {}, 0
+    for f in CONV_FIELDS:
+        if f in CONV_VEC3:
+            d[f] = [int(x) for x in flat[q:q + 3]]
+            q += 3
+        else:
+            d[f] = int(flat[q])
+            q += 1
+    return d
+
+
 def flatten(d, fields):
     """dict -> flat list of ints in struct order (what pc_op.i carries)."""
     out = []

@@ -40,16 +40,23 @@ def check_replicas_agree(flat_params, group=None, what="parameters", rtol=0.0):
     so the default tolerance is zero."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return True
-    x = flat_params.detach().double()
-    n = x.numel()
-    w = torch.arange(1, n + 1, device=x.device, dtype=torch.float64) / n
-    chk = torch.stack([x.sum(), (x * x).sum(), (x * w).sum()])
+    flat = flat_params.detach().reshape(-1)
+    n = flat.numel()
+    chk = torch.zeros(3, dtype=torch.float64, device=flat.device)
+    CH = 1 << 22                          # float64 temporaries of one chunk at a time (not 3 x 8 B per parameter)
+    for a in range(0, n, CH):
+        x = flat[a:a + CH].double()
+        w = torch.arange(a + 1, a + x.numel() + 1, device=x.device, dtype=torch.float64) / n
+        chk += torch.stack([x.sum(), (x * x).sum(), (x * w).sum()])
     dev = chk.device if dist.get_backend(group) == "nccl" else torch.device("cpu")
     lo, hi = chk.to(dev).clone(), chk.to(dev).clone()
+    # a NaN / Inf checksum compares false against everything: carry "this rank's checksum is finite" through the MIN reduction explicitly
+    finite = torch.tensor([1.0 if bool(torch.isfinite(chk).all()) else 0.0], dtype=torch.float64, device=dev)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
     dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(finite, op=dist.ReduceOp.MIN, group=group)
     spread = (hi - lo).abs()
-    bad = bool((spread > rtol * hi.abs().clamp_min(1e-300)).any())
+    bad = finite.item() < 1.0 or not bool((spread <= rtol * hi.abs().clamp_min(1e-300)).all())
     if bad:
         raise RuntimeError("data-parallel ranks do not hold the same %s: checksum (sum, sum of squares, weighted sum) spans %s .. %s across the "
                            "%d ranks (this rank: %s) -- seed every rank alike or broadcast rank 0's state before training"
@@ -82,6 +89,13 @@ class GradReducer:
         self.handles = []
         self.launched = []
         self._work = {}                  # bucket index -> the collective's Work handle (RCCL path; wait_buckets_on)
+        # per-step diagnostics (bench.py's `reducer` block): host time spent in wait(), and -- device side -- how long the main stream sat
+        # between the last backward kernel and the last collective's completion (the EXPOSED communication time).  Event pairs are kept
+        # pending and read by stats() after a synchronize, so the step itself gains no host wait.
+        self.comm_wait_ms = []
+        self._exposed_pending = []
+        self._exposed_ms = []
+        self._ev_pool = []
 
     def launch(self, i, streams=()):
         """Start bucket i's all-reduce behind everything enqueued so far on torch's current stream and on `streams`
@@ -131,8 +145,40 @@ class GradReducer:
                 if w is not None:
                     w.wait()
 
+    def bucket_table(self):
+        """[(bytes, ready-op index in the backward list, first float, last float)] per bucket, in launch order."""
+        es = self.g.element_size()
+        return [dict(bytes=int((b - a) * es), ready_op=int(ready), first=int(a), last=int(b)) for ready, a, b in self.buckets]
+
+    def stats(self, reset=True):
+        """Per-step diagnostics since the last reset: call after the device is idle (the pending event pairs are read here).
+        comm_wait_ms: host time in wait(); exposed_ms: time the main stream spent waiting for collectives behind its last backward
+        kernel (gloo / host-staged paths: the host time of the same span)."""
+        import statistics
+        for e0, e1 in self._exposed_pending:
+            e1.synchronize()
+            self._exposed_ms.append(e0.elapsed_time(e1))
+            self._ev_pool += [e0, e1]
+        self._exposed_pending = []
+        med = lambda v: float(statistics.median(v)) if v else None
+        out = dict(steps=len(self.comm_wait_ms), comm_wait_ms=med(self.comm_wait_ms), comm_wait_ms_max=max(self.comm_wait_ms) if self.comm_wait_ms else None,
+                   exposed_ms=med(self._exposed_ms), exposed_ms_max=max(self._exposed_ms) if self._exposed_ms else None)
+        if reset:
+            self.comm_wait_ms, self._exposed_ms = [], []
+        return out
+
     def wait(self):
         """Join every launched bucket before the optimiser reads the gradient."""
+        import time
+        if not self.active or not self.launched:
+            self.handles, self.launched, self._work = [], [], {}
+            return
+        t0 = time.perf_counter()
+        ev = None
+        if self.cuda:
+            ev = (self._ev_pool.pop() if self._ev_pool else torch.cuda.Event(enable_timing=True),
+                  self._ev_pool.pop() if self._ev_pool else torch.cuda.Event(enable_timing=True))
+            ev[0].record(torch.cuda.current_stream())          # behind the backward's last kernel on the main stream
         if self.host_staged and self.launched:
             self.comm_stream.synchronize()
             for i in self.launched:
@@ -149,6 +195,16 @@ class GradReducer:
         self._work = {}
         if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
+            ev[1].record(torch.cuda.current_stream())          # the main stream gets here once every collective has finished
+            self._exposed_pending.append(ev)
+            if len(self._exposed_pending) > 4096:               # nobody reads the diagnostics: do not grow without bound
+                self._ev_pool += list(self._exposed_pending.pop(0))
+        dt = (time.perf_counter() - t0) * 1e3
+        self.comm_wait_ms.append(dt)
+        if len(self.comm_wait_ms) > 65536:
+            del self.comm_wait_ms[:32768]
+        if not self.cuda:
+            self._exposed_ms.append(dt)
 
     @property
     def gscale(self):

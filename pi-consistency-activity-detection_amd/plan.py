@@ -512,7 +512,7 @@ class Plan:
         """Emit a weight-gradient launch and book the FLOPs its (already trimmed) descriptor multiplies.  Inside a wgrad_group the
         launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op."""
         if self.x6 and os.environ.get("PICONS_SPLIT_WGRAD", "1") != "0":
-            d = dict(d, flags=int(d.get("flags", 0)) | capi.WG_X6)       # honoured by the row-segment route only
+            d = dict(d, flags=int(d.get("flags", 0)) | capi.WG_X6)       # row-segment and generic split-K routes (the stem and the 9-tap spectral planes stay fp32)
         self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
         w = wgrad_work(d)
         for key, v in (("wg_mfma", w["issued"]), ("wg_executed", w["executed"]), ("wg_valid", w["valid"])):

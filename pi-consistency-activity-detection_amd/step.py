@@ -201,6 +201,12 @@ class StepEngine:
         stager re-points at its own double buffer instead of copying into the arena."""
         base = int(self.bases[ref[0]] + ref[1])
         out = []
+        # pointers that live in HOST job tables (OP_WGRAD_MULTI, OP_TRANSPOSE_MULTI, OP_SPLIT_PLANES_MULTI) are not re-pointable through the
+        # op arrays: a reader grouped into such a table would keep reading the arena buffer a stager never writes -- refuse instead (ADVICE r4)
+        for tab in self.ops.get("_tjobs", []):
+            for f in tab.dtype.names:
+                if tab.dtype[f] == np.uint64 and bool(((tab[f] >= base) & (tab[f] < base + 4 * nfloats)).any()):
+                    raise RuntimeError("an op's host job table points into the buffer at arena offset %d: re-pointing its readers would miss it" % ref[1])
         for name, arr in self.ops.items():
             if name.startswith("_"):
                 continue
@@ -224,7 +230,26 @@ class StepEngine:
                 self.ops[name][idx]["p"][q] = base + offb
 
     # ------------------------------------------------------------------ execution
+    def reset_workspaces(self):
+        """Zero the workspaces whose counters every launch must find (and leaves) at zero -- the tail-split arrival counters of the bf16-split
+        conv launches (csrc/conv_x6.hip).  Done once when the arena is created; again here after a step that raised, because a launch that
+        failed or never ran can leave a counter mid-count, after which that tile's epilogue would never run again."""
+        torch.cuda.synchronize(self.dev)
+        for ref, n in self.plan.zero_once:
+            self.aview(ref, n).zero_()
+        torch.cuda.synchronize(self.dev)
+
     def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
+        try:
+            return self._forward_backward(epoch, wt_ramp, reducer, timed_kind)
+        except Exception:
+            try:
+                self.reset_workspaces()
+            except Exception:          # the device itself is gone: the first error is the one to report
+                pass
+            raise
+
+    def _forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
         """prep -> forward (both passes batched) -> losses -> backward.  With a dist.GradReducer the
         backward list is replayed in segments and each gradient bucket's all-reduce is launched as soon
         as the ops that finalise it are enqueued.  timed_kind: accumulate hipEvent time of that op kind
@@ -561,6 +586,12 @@ class SampleStager(HostDictStager):
                                 d832=eng.readers_of(p.in_drop832, 2 * n * spec.TRUNK_OUT_CH), d128=eng.readers_of(p.in_drop128, 2 * n * 128))
             if not eng._patched["img"][1] or not eng._patched["seg"][1]:
                 raise RuntimeError("no op reads the clip tensor / the mask: the plan changed under SampleStager")
+            # the readers this stager is built for: the stem's conv in the forward and the stem's weight gradient in the backward (training
+            # plans); anything else reading the clip would be re-pointed too, but if one of THESE is missing it was folded into something
+            # readers_of() cannot see
+            kinds = {(name, int(eng.ops[name][idx]["kind"])) for name, idx, _q, _o in eng._patched["img"][1]}
+            if ("fwd", capi.OP_CONV) not in kinds or (p.training and ("bwd", capi.OP_WGRAD) not in kinds):
+                raise RuntimeError("SampleStager: the stem's conv / weight gradient are not among the clip's readers (%s)" % sorted(kinds))
 
     def _pack_small(self, slot, act, lab_flag, drops):
         n = self.eng.bs

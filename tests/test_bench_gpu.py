@@ -43,8 +43,14 @@ def test_bench_line_contract():
     rs = j["resident"]
     assert rs["unit"] == "clips/s" and abs(rs["value"] - 8 * 1000.0 / rs["ms_per_step"]) < 1e-6 * rs["value"] and j["value_resident"] == rs["value"]
     assert j["ms_per_step"] < 1.5 * rs["ms_per_step"] + 5.0
-    r = j["roofline"]                                       # dominant conv kernel: fp32 on the bf16 matrix cores, roof = bf16 peak / 6 products
+    fams = [j[k] for k in ("roofline_conv_x6", "roofline_fp32_conv", "roofline_winograd")]
+    assert all(f.get("invalid") is None and f["timed_steps"] == 3 for f in fams)             # every leg: three measured replays that agree within 1.5x
+    d = j["roofline"]                                       # = the family with the largest single-stream kernel time per step
+    assert d["bound"] == "mfma" and d["kernel_ms_per_step"] == max(f["kernel_ms_per_step"] for f in fams) and "dominant_by" in d
+    assert abs(d["frac"] - d["achieved"] / d["peak"]) < 1e-9 and 0.1 < d["frac"] < 1.0 and d["kernel_ms_per_step"] < j["ms_per_step"]
+    r = j["roofline_conv_x6"]                               # fp32 on the bf16 matrix cores, roof = bf16 peak / 6 products
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 2500.0 / 6) < 1e-6 and "conv_x6_kernel" in r["kernel"]
+    assert r["in_region_timed_steps"] >= 1 and 0.67 < r["in_region_kernel_ms_per_step"] / r["kernel_ms_per_step"] < 1.5
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.1 < r["frac"] < 1.0
     assert r["launches_per_step"] > 30 and abs(r["avg_launch_ms"] * r["launches_per_step"] - r["kernel_ms_per_step"]) < 1e-6 * r["kernel_ms_per_step"]
     assert r["kernel_ms_per_step"] < j["ms_per_step"]                                    # event time of the conv kernels fits inside the step
@@ -68,8 +74,9 @@ def test_bench_split_off_keeps_the_native_path():
     """PICONS_SPLIT=0: every conv launch on the fp32 MFMA kernels, dtype and roofline say so."""
     j = _run("--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-extra-legs", env={"PICONS_SPLIT": "0"})
     assert j["dtype"] == "f32" and j["config"]["bf16_split_conv"] is False and j["split_off"] is None
-    r = j["roofline"]
+    r = j["roofline_fp32_conv"]
     assert r["peak"] == 157.3 and "conv_gemm" in r["kernel"] and r["launches_per_step"] > 50 and 0.3 < r["frac"] < 1.0
+    assert j["roofline_conv_x6"] is None and j["roofline"]["kernel_ms_per_step"] >= r["kernel_ms_per_step"]
     assert j["roofline_step"]["gflop_by_family"]["conv_bf16_split"] == 0
 
 
@@ -85,3 +92,10 @@ def test_bench_dp_schedule_through_rccl_on_one_rank():
              env={"PICONS_FORCE_REDUCER": "1", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(_free_port())})
     assert j["ranks_observed"] == 1 and j["reducer"]["backend"] == "nccl" and j["reducer"]["buckets"] >= 3 and j["reducer"]["forced_single_rank"]
     assert j["ms_per_step"] < 60.0 and j["loss"]["total"] == j["loss"]["total"]
+    # the diagnostics a SCALE line is explained with: host time in reducer.wait(), device time the main stream sat behind its last backward
+    # kernel until the last collective finished, and the bucket table (bytes, ready-op index)
+    rd = j["reducer"]
+    assert rd["steps"] == 3 and 0.0 <= rd["comm_wait_ms"] < 50.0 and 0.0 <= rd["exposed_ms"] < 50.0 and rd["exposed_ms_max"] >= rd["exposed_ms"]
+    tab = rd["bucket_table"]
+    assert len(tab) == rd["buckets"] and all(t["bytes"] > 0 and t["ready_op"] > 0 for t in tab)
+    assert [t["ready_op"] for t in tab] == sorted(t["ready_op"] for t in tab) and sum(t["bytes"] for t in tab) > 150e6

@@ -108,6 +108,10 @@ def _replica_worker(rank, world, port, perturb, q):
         P[4242] += 1e-6                                                           # ... one element moved by one part in a million on one rank
     if perturb == "swap" and rank == world - 1:
         P[[10, 20]] = P[[20, 10]]                                                 # ... or two elements swapped (sum and sum of squares unchanged)
+    if perturb == "nan" and rank == 1:
+        P[77] = float("nan")                                                      # ... or a corrupt checkpoint: NaN compares false against everything
+    if perturb == "inf_all":
+        P[5] = float("inf")                                                       # ... even when EVERY rank holds the same non-finite value
     try:
         pdist.check_replicas_agree(P)
         verdict = "agree"
@@ -117,7 +121,7 @@ def _replica_worker(rank, world, port, perturb, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("perturb,expect", [("none", "agree"), ("value", "refused"), ("swap", "refused")])
+@pytest.mark.parametrize("perturb,expect", [("none", "agree"), ("value", "refused"), ("swap", "refused"), ("nan", "refused"), ("inf_all", "refused")])
 def test_replicas_must_start_from_identical_parameters(perturb, expect):
     """VERDICT r3 #8a: at reducer creation every rank's parameter checksum is compared (one MIN + one MAX all-reduce of three numbers);
     a rank that was seeded differently / loaded another checkpoint makes EVERY rank refuse to train."""
@@ -138,7 +142,12 @@ def _skew_worker(rank, world, port, nparams, buckets, q):
     assert red.reduced_from() is None                      # CPU tensors: the early-optimiser shortcut is for RCCL in place only
     red.wait()
     expect = sum(torch.randn(nparams, generator=torch.Generator().manual_seed(200 + k)) for k in range(world))
-    q.put((rank, bool(torch.allclose(flat, expect, atol=1e-5)), red.gscale))
+    # the diagnostics bench.py prints in its `reducer` block: one step recorded, host wait and exposed time measured, and a
+    # bucket table that covers the flat buffer with the plan's ready-op indices
+    st, tab = red.stats(), red.bucket_table()
+    diag = (st["steps"] == 1 and st["comm_wait_ms"] is not None and st["comm_wait_ms"] >= 0.0 and st["exposed_ms"] is not None
+            and sum(t["bytes"] for t in tab) == 4 * nparams and [t["ready_op"] for t in tab] == [b[0] for b in buckets])
+    q.put((rank, bool(torch.allclose(flat, expect, atol=1e-5)) and diag, red.gscale))
     dist.destroy_process_group()
 
 

@@ -73,6 +73,23 @@ def test_wino_channel_slices_and_bn_partials():
         assert (s[1] - (ref[n] ** 2).sum(dim=(0, 1, 2))).abs().max().item() <= 1e-3 * max(1.0, (ref[n] ** 2).sum(dim=(0, 1, 2)).max().item())
 
 
+@pytest.mark.parametrize("Co", [6, 66])
+def test_wino_output_slice_with_ragged_channel_count_leaves_neighbours_untouched(Co):
+    """Co % 4 != 0 inside a wider tensor (ldo > Co, 16-byte aligned slice): the row-contiguous 16-byte epilogue must not be taken -- its last
+    chunk would run over columns Co .. Co + 3, which belong to the neighbouring channel slice."""
+    N, T, H, W, Ci, ldo = 2, 2, 12, 12, 16, 80
+    g = torch.Generator().manual_seed(Co)
+    x = torch.randn(N, T, H, W, Ci, generator=g)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * 0.1
+    b = torch.randn(Co, generator=g)
+    ref = _ref(x.double(), w.double(), b.double(), 3)
+    U = ops.wino_weights(w.cuda().contiguous(), Co, Ci, 3)
+    outw = torch.full((N, T, H, W, ldo), 7.25, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, Ci, Co, ldo, 3, flags=capi.F_BIAS), x.cuda(), U, outw[..., 4:], bias=b.cuda())
+    assert (outw[..., 4:4 + Co].cpu().double() - ref).abs().max().item() <= 2e-5 * max(1.0, ref.abs().max().item())
+    assert torch.all(outw[..., :4] == 7.25) and torch.all(outw[..., 4 + Co:] == 7.25)
+
+
 @pytest.mark.parametrize("KT", [3, 1])
 def test_wino_input_gradient_through_flipped_weights(KT):
     """d(x) of y = conv(x, w) is the same correlation of d(y) with the taps mirrored and the channel roles exchanged:

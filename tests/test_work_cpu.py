@@ -120,3 +120,29 @@ def test_winograd_layers_in_the_plan_and_their_accounting(monkeypatch):
     q = build()
     assert count(q, capi.OP_WINO_CONV) == 0 and count(q, capi.OP_CONV) > count(p, capi.OP_CONV)
     assert sum(v["executed"] for v in q.conv_flops_executed().values()) > sum(v["executed"] for v in p.conv_flops_executed().values())
+
+
+def test_every_bf16_split_conv_op_in_the_plan_has_the_shape_the_kernel_is_gated_on():
+    """at the bench size (bs 8, 224^2, four lanes) no OP_CONV_X6 op may carry a channel count the LDS-DMA tiles cannot take
+    (Ci % 32 != 0) or fewer than 150 blocks of its tile (measured slower than the fp32 kernel there), and every one is accepted by the
+    library's own gate; the kernel-level numerics gates of tests/test_x6_gpu.py only cover shapes that satisfy this."""
+    import ctypes as C
+    from picons_amd.plan import _cdesc
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    p = Plan(24, 224, n=8, groups=2, lanes=4)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam(); p.finalize()
+    x6 = [op for n in p.lists for op in p.lists[n] if op[0] == capi.OP_CONV_X6]
+    assert len(x6) >= 25
+    lib = capi.lib()
+    for op in x6:
+        d = D.unflatten_conv(op[1])
+        assert D.flatten(d, D.CONV_FIELDS) == [int(v) for v in op[1]]
+        w = p.op_work[id(op[1])]
+        assert d["flags"] & capi.F_X6 and d["Ci"] % 32 == 0 and d["Ci"] >= 32, d
+        assert w["blocks"] >= 150, (d, w["blocks"])
+        assert lib.pc_conv_x6_ok(_cdesc(d)) == 1
+    # and nothing that the gate would accept was left on the fp32 kernel by accident in the BACKWARD (the forward's trunk convs stay fp32 on
+    # purpose: DESIGN.md 4, the numerics gate)
+    asx6 = lambda op: dict(D.unflatten_conv(op[1]), flags=D.unflatten_conv(op[1])["flags"] | capi.F_X6)
+    left = [op for op in p.lists["bwd"] if op[0] == capi.OP_CONV and lib.pc_conv_x6_ok(_cdesc(asx6(op))) == 1]
+    assert not left, "%d backward conv ops pass pc_conv_x6_ok but run on the fp32 kernel" % len(left)

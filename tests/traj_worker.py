@@ -63,6 +63,35 @@ for k in S.files:
                                     max_vs_f64=float(np.abs(got - r64).max()), frac_over_lr=float((np.abs(got - r64) > lr).mean()),
                                     ref32_frac_over_lr=float((np.abs(r32 - r64) > lr).mean()))
 names = [str(x) for x in S["param_names"]]
+# the optimiser's state after the last step: Adam's moments are smooth in the gradients -- a wrong step count, a doubled or a
+# skipped (early-)Adam range moves them by tens of percent, where the loss scalars above ride on EM routing's noise
+res["adam"] = {}
+flat_of = lambda buf, n: buf[eng.plan.poff[n]:eng.plan.poff[n] + int(np.prod(eng.plan.pshape[n]))].view(eng.plan.pshape[n]).cpu().double().numpy()
+rel = lambda a, b: float(np.linalg.norm((a - b).ravel()) / max(np.linalg.norm(b.ravel()), 1e-300))
+for k in S.files:
+    if k.startswith("adam_m::") or k.startswith("adam_v::"):
+        n, buf = k[8:], (eng.M if k.startswith("adam_m::") else eng.V)
+        r32, r64 = S[k].astype(np.float64), S["f64::" + k]
+        res["adam"][k] = dict(vs_f64=rel(flat_of(buf, n), r64), ref32_vs_f64=rel(r32, r64))
+for tag, buf in (("adam_m_norms", eng.M), ("adam_v_norms", eng.V)):
+    got = np.array([float(np.linalg.norm(flat_of(buf, n).ravel())) for n in names])
+    r32, r64 = S[tag].astype(np.float64), S["f64::" + tag]
+    # per tensor: log-ratio of the moment's norm to the fp64 run's, beside the reference's own fp32 run's (from step 2 on the trunk's
+    # gradients are noise through EM routing -- the reference's fp32 moments are 40 - 70 % from its fp64 ones ELEMENT-wise there -- but a
+    # tensor's norm mostly stays within tens of percent: measured worst case x2.0 for the first and x4.2 for the second moment of
+    # primary_caps.a.bias, whose exact gradient nearly cancels; the bar is a factor 5)
+    lg = np.abs(np.log(np.maximum(got, 1e-300) / np.maximum(r64, 1e-300)))
+    lr32 = np.abs(np.log(np.maximum(r32, 1e-300) / np.maximum(r64, 1e-300)))
+    ex = lg - np.maximum(3 * lr32, np.log(5.0))
+    i = int(np.argmax(ex))
+    order = np.argsort(-lg)[:5]
+    res[tag] = dict(worst_excess=float(ex[i]), worst=names[i], worst_log_ratio=float(lg[i]), worst_ref32_log_ratio=float(lr32[i]),
+                    largest=[(names[q], float(lg[q]), float(lr32[q])) for q in order],
+                    stem=[(n, float(lg[names.index(n)]), float(lr32[names.index(n)])) for n in names if n.startswith("conv1.Conv3d_1a_7x7.")],
+                    max_log_ratio=float(lg.max()), ref32_max_log_ratio=float(lr32.max()),
+                    median_rel=float(np.median(np.abs(got - r64) / np.maximum(r64, 1e-30))),
+                    ref32_median_rel=float(np.median(np.abs(r32 - r64) / np.maximum(r64, 1e-30))))
+res["adam_step_ref"] = [int(S["adam_step"].min()), int(S["adam_step"].max())]
 norms = {n: float(sd[n].double().norm()) for n in names}
 # every parameter tensor's norm after the last step: distance from the fp64 run beyond 3x the reference's own fp32 distance, relative to max(norm, 1)
 # (biases start at zero: after three steps their norm IS the handful of +-lr moves, sign noise included)

@@ -289,7 +289,7 @@ TRAJ_PARAMS = ["conv_caps.beta_u", "conv_caps.beta_a", "smooth.weight", "smooth.
 TRAJ_BUFS = ["conv1.Conv3d_1a_7x7", "conv1.Conv3d_2c_3x3", "conv1.Mixed_3b.b1b", "conv1.Mixed_4c.b0", "conv1.Mixed_4f.b3b"]
 
 
-def gen_trajectory(bs=2, nsteps=3, spread_only=False, spread_threads=(1, 3, 5)):
+def gen_trajectory(bs=2, nsteps=3, spread_only=False, spread_threads=(1, 3, 5), adam_only=False):
     """The reference's own training loop for `nsteps` steps (main_ucf101.py:171-184: zero_grad -> train_model_interface -> backward ->
     optimizer.step(), optimizer = Adam(lr 1e-4, weight_decay 0, eps 1e-6) of main_ucf101.py:416), a FRESH minibatch per step, scripted
     permutation / dropout draws -- once in fp32 and once in fp64 (the anchor: Adam's first updates are +-lr per element whatever the
@@ -314,6 +314,13 @@ def gen_trajectory(bs=2, nsteps=3, spread_only=False, spread_threads=(1, 3, 5)):
     if spread_only:
         old = np.load(os.path.join(OUT, "traj_bv5.npz"))
         d = {k: old[k] for k in old.files if not (k[0] == "t" and k[1].isdigit())}
+    if adam_only:
+        # `--only traj_adam` (round 5): the fp32 and fp64 runs again, adding the optimiser's state after the last step -- Adam's exp_avg /
+        # exp_avg_sq of the TRAJ_PARAMS tensors, the norms of both for every parameter and the step count -- to the existing fixture.  The
+        # runs are bit-reproducible at a fixed thread count: every key the fixture already holds must come out identical (checked below).
+        old = np.load(os.path.join(OUT, "traj_bv5.npz"))
+        keep = {k: old[k] for k in old.files}
+        assert int(old["default_threads"]) == torch.get_num_threads(), "run with the thread count the fixture was made with (%d)" % int(old["default_threads"])
 
     def run(double, pre, light=False):
         ref_import.install_shims(double=double)
@@ -363,6 +370,30 @@ def gen_trajectory(bs=2, nsteps=3, spread_only=False, spread_threads=(1, 3, 5)):
         d[pre + "param_names"] = np.array(list(params.keys()))
         d[pre + "param_norms"] = np.array([float(p.detach().double().norm()) for p in params.values()])
         d[pre + "param_delta_norms"] = np.array([float((p.detach().double() - torch.from_numpy(np.array(state[n])).double()).norm()) for n, p in params.items()])
+        # the optimiser's state after the last step: a wrong step count, a doubled or a skipped update shows here directly
+        for n in TRAJ_PARAMS:
+            if params[n].numel() > 20000:                       # full moments of the small tensors only (norms of every tensor below)
+                continue
+            st = opt.state[params[n]]
+            d["%sadam_m::%s" % (pre, n)] = st["exp_avg"].detach()
+            d["%sadam_v::%s" % (pre, n)] = st["exp_avg_sq"].detach()
+        d[pre + "adam_m_norms"] = np.array([float(opt.state[p]["exp_avg"].double().norm()) for p in params.values()])
+        d[pre + "adam_v_norms"] = np.array([float(opt.state[p]["exp_avg_sq"].double().norm()) for p in params.values()])
+        d[pre + "adam_step"] = np.array([int(opt.state[p]["step"]) for p in params.values()])
+    if adam_only:
+        run(False, "")
+        run(True, "f64::")
+        for k, v in keep.items():
+            if k in d and k not in ("seconds",):
+                a_, b_ = np.asarray(v), np.asarray(d[k].detach().numpy() if torch.is_tensor(d[k]) else d[k])
+                if a_.dtype.kind in "fc":
+                    assert np.array_equal(a_, b_.astype(a_.dtype).reshape(a_.shape)), "the re-run does not reproduce the fixture's %s" % k
+        new = {k: v for k, v in d.items() if k not in keep}
+        keep.update(new)
+        ref_import.install_shims(double=False)
+        print("added:", sorted(new))
+        save("traj_bv5.npz", keep)
+        return
     if not spread_only:
         run(False, "")
         run(True, "f64::")
@@ -396,5 +427,7 @@ if __name__ == "__main__":
         gen_steps(a.steps.split(",") if a.steps else None)
     if a.only == "traj_spread":
         gen_trajectory(spread_only=True)
+    if a.only == "traj_adam":
+        gen_trajectory(adam_only=True)
     if a.only in (None, "traj"):
         gen_trajectory()

@@ -83,6 +83,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// MODE 3 (16x16x32 fragments: a lane holds k = 8 (lane / 16) .. + 7 of one of 16 rows): a ds_read_b128 lane group mixes two k groups
+// (rows 0-3, 12-15 of k group g with rows 4-11 of k group g + 1), so the slot swizzles are chosen such that the rows {0-3, 12-15} map onto a
+// slot set that is closed under XOR with the distance of the two k groups (2 fp32 slots / 1 plane slot): conflict-free by enumeration.
+__device__ __forceinline__ int swzA16(int r) { const int q = (r >> 1) & 7; return (q & 4) | ((q & 1) << 1) | ((q >> 1) & 1); }
+__device__ __forceinline__ int swzB16(int r) { const int q = (r >> 2) & 3; return (((q ^ (q >> 1)) & 1) << 1) | (q >> 1); }
+
 template <int MODE, int BM, int BN, int WM, int WN, int ABL = 0>
 __global__ __launch_bounds__(256, 2) void gemm_tile(const float* __restrict__ A, const float* __restrict__ W, const uint16_t* __restrict__ Wp,
                                                     float* __restrict__ C, int M, int N, int K) {
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile(const float* __restrict__ A,
 #pragma unroll
     for (int j = 0; j < AR; ++j) {
         const int row = lrow + 32 * j;
-        const int ks = (slot ^ ((row >> 1) & 7)) * 4;
+        const int ks = (slot ^ (MODE == 3 ? swzA16(row) : ((row >> 1) & 7))) * 4;
         adma[j] = (m0 + row) < M ? (unsigned)(((size_t)(m0 + row) * K + ks) * 4) : DMA_OOB;
     }
     if constexpr (!BPRE) {
@@ -122,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tile(const float* __restrict__ A,
         for (int j = 0; j < BR; ++j) {
             const int pl = j / (BN / 64), jj = j % (BN / 64);
             const int row = (tid >> 2) + 64 * jj;
-            const int sl = (tid & 3) ^ ((row >> 2) & 3);
+            const int sl = (tid & 3) ^ (MODE == 3 ? swzB16(row) : ((row >> 2) & 3));
             bdma[j] = (unsigned)(((size_t)pl * N * K + (size_t)(n0 + row) * K + sl * 8) * 2);
         }
     }
@@ -167,7 +173,50 @@ __global__ __launch_bounds__(256, 2) void gemm_tile(const float* __restrict__ A,
     auto mma_chunk = [&](int buf) {
         const uint8_t* a = As0 + buf * ABYTES;
         const uint8_t* b = Bs0 + buf * BBYTES;
-        if constexpr (MODE == 0) {
+        if constexpr (MODE == 3) {
+            // one k32 step per chunk on v_mfma_f32_16x16x32_bf16: the 32x32 tile (i, j) is four 16x16 accumulators, registers 4 (2 ii + jj) ..
+            typedef __attribute__((ext_vector_type(4))) float f32x4a;
+            const int l15 = lane & 15, kg = lane >> 4;
+            u32x4 ah[TM][2], am[TM][2], al[TM][2], bh[TN][2], bm[TN][2], bl[TN][2];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int r = wm * (BM / WM) + i * 32 + ii * 16 + l15, sw = swzA16(r);
+                    const f32x4 x = *(const f32x4*)(a + r * (BK * 4) + (((2 * kg) ^ sw) << 4));
+                    const f32x4 y = *(const f32x4*)(a + r * (BK * 4) + (((2 * kg + 1) ^ sw) << 4));
+                    if constexpr (ABL & 1) { ah[i][ii] = __builtin_bit_cast(u32x4, x); am[i][ii] = __builtin_bit_cast(u32x4, y); al[i][ii] = ah[i][ii] ^ am[i][ii]; }
+                    else split8(x, y, ah[i][ii], am[i][ii], al[i][ii]);
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int r = wn * (BN / WN) + j * 32 + jj * 16 + l15;
+                    const unsigned o = (unsigned)(r * 64 + ((kg ^ swzB16(r)) << 4));
+                    bh[j][jj] = *(const u32x4*)(b + o);
+                    bm[j][jj] = *(const u32x4*)(b + BN * 64 + o);
+                    bl[j][jj] = *(const u32x4*)(b + 2 * BN * 64 + o);
+                }
+#define MF16(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, X), __builtin_bit_cast(bf16x8, Y), Cc, 0, 0, 0)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int ii = 0; ii < 2; ++ii)
+#pragma unroll
+                        for (int jj = 0; jj < 2; ++jj) {
+                            f32x4a c;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) c[r] = acc[i][j][(ii * 2 + jj) * 4 + r];
+                            MF16(ah[i][ii], bl[j][jj], c); MF16(al[i][ii], bh[j][jj], c); MF16(am[i][ii], bm[j][jj], c);
+                            MF16(ah[i][ii], bm[j][jj], c); MF16(am[i][ii], bh[j][jj], c); MF16(ah[i][ii], bh[j][jj], c);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) acc[i][j][(ii * 2 + jj) * 4 + r] = c[r];
+                        }
+#undef MF16
+        } else if constexpr (MODE == 0) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 f32x4 af[TM], bf[TN];
@@ -244,9 +293,16 @@ __global__ __launch_bounds__(256, 2) void gemm_tile(const float* __restrict__ A,
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
+            if constexpr (MODE == 3) {      // register 4 (2 ii + jj) + q: row 16 ii + 4 (lane / 16) + q, column 16 jj + lane % 16
+                const int ii = r >> 3, jj = (r >> 2) & 1, q = r & 3;
+                const int row = wm * (BM / WM) + i * 32 + ii * 16 + 4 * (lane >> 4) + q;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + jj * 16 + (lane & 15)] = acc[i][j][r];
+            } else {
             const int row = wm * (BM / WM) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
 #pragma unroll
             for (int j = 0; j < TN; ++j) T[row * BN + wn * (BN / WN) + j * 32 + (lane & 31)] = acc[i][j][r];
+            }
         }
     __syncthreads();
     for (int e = tid; e < BM * BN / 4; e += 256) {
@@ -630,6 +686,13 @@ int main(int argc, char** argv) {
     run<0, 128, 128, 2, 2>("128x128 fp32 mfma", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<1, 128, 128, 2, 2>("128x128 x6 split A,B in regs", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<2, 128, 128, 2, 2>("128x128 x6 B planes", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<3, 128, 128, 2, 2>("128x128 x6 B planes 16x16x32", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<2, 128, 128, 2, 2>("128x128 x6 B planes (again)", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<3, 128, 128, 2, 2>("128x128 x6 B planes 16x16x32", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<2, 128, 128, 2, 2, 1>("  32x32x16 abl: no split", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<3, 128, 128, 2, 2, 1>("  16x16x32 abl: no split", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<2, 128, 128, 2, 2, 3>("  32x32x16 abl: no split/DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<3, 128, 128, 2, 2, 3>("  16x16x32 abl: no split/DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<4, 128, 128, 2, 2>("128x128 x6 pipelined", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<4, 128, 128, 2, 2, 1>("  pipe abl: no split", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<4, 128, 128, 2, 2, 2>("  pipe abl: no DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
