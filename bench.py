@@ -212,11 +212,13 @@ class StagedInputs:
             st.commit(slot)                   # the main stream waits for the slot; the clip conversion reads it in place
             tk = timed_kind if (timed_kind is not None and time_every and i % time_every == 0) else None
             ntimed += tk is not None
-            if reducer is not None and reducer.active and tk is None:
+            # a timed step of THIS leg is the ordinary four-lane step with event pairs riding in the dominant kernel's dispatches
+            # (timed_on_lanes): it costs what every other step costs; the kernels' own durations come from the single-stream legs
+            if reducer is not None and reducer.active:
                 eng.arm_early_adam_dp(lr, reducer)
             else:
-                eng.arm_early_adam(lr, on=(reducer is None or not reducer.active) and tk is None)
-            eng.forward_backward(epoch, ramp, reducer, timed_kind=tk)
+                eng.arm_early_adam(lr, on=True)
+            eng.forward_backward(epoch, ramp, reducer, timed_kind=tk, timed_on_lanes=True)
             gscale = 1.0
             if reducer is not None:
                 reducer.wait()
@@ -363,7 +365,7 @@ def main():
         for it in range(steps):
             tk = kind if (kind is not None and every and it % every == 0) else None
             nt += tk is not None
-            last = e.run_staged(a.epoch, ramp, reducer=red, timed_kind=tk, collect=False)
+            last = e.run_staged(a.epoch, ramp, reducer=red, timed_kind=tk, collect=False, timed_on_lanes=True)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -447,8 +449,7 @@ def main():
     legs = {}
     if main_kind is not None:
         eng.stage(lab, unl, perm, drops)
-        in_region = (main_ms / timed_steps) if (timed_steps and main_count) else None
-        legs["main"] = leg_summary(kind_leg(main_kind), in_region)
+        legs["main"] = leg_summary(kind_leg(main_kind))
         legs["wino"] = leg_summary(kind_leg(capi.OP_WINO_CONV))
         if split_on:
             legs["f32c"] = leg_summary(kind_leg(capi.OP_CONV))
@@ -544,7 +545,9 @@ def main():
                        {"peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate = %.1f TFLOP/s of fp32-equivalent work; the chip holds "
                                      "1.35 - 1.5 GHz of its 2.4 GHz in this kernel (in-kernel clock stamps, profiles/r04_x6_tile_probe.txt)" % (PEAK_BF16_MFMA_TFLOPS / 6.0),
                         "traffic": traffic, "traffic_source": traffic_src,
-                        "in_region_kernel_ms_per_step": (main_ms / timed_steps) if timed_steps else None, "in_region_timed_steps": timed_steps})
+                        "in_region_kernel_ms_per_step": (main_ms / timed_steps) if timed_steps else None, "in_region_timed_steps": timed_steps,
+                        "in_region_note": "hipEvent pairs in the same kernel's dispatches during the headline leg's timed steps (the ordinary four-lane step: durations "
+                                          "as stretched by the kernels running beside them on the other lanes); the fractions above come from the single-stream replays"})
         roof_f32conv = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: the launches that stay on v_mfma_f32_32x32x2_f32 -- the RGB stem, "
                             "channel counts that are not multiples of 32, launches too small to gain)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"), legs.get("f32c"),
                             PEAK_FP32_MFMA_TFLOPS)

@@ -218,6 +218,14 @@ int pc_bn_finalize_ws(const float* part, int nparts_per_group, int groups, int C
 int pc_bn_apply(const float* z, int ldz, const float* stat, int C, int64_t rows, int groups, float* y,
                 int ldy, int relu, pc_stream s);
 /* eval mode: stat[4][C] from running stats */
+/* pc_bn_finalize + pc_bn_apply in ONE launch, for layers with at most 256 partial rows per batch group (pc_bn_finalize_apply_ok): every block
+ * of the apply kernel reduces the partial rows of its own 64 channels (doubles, fixed order) and streams its rows; row block 0 of group 0 writes
+ * `stat` and the running statistics (groups in order).  Round 5: one dispatch fewer per BatchNorm site on the step's dependency chain
+ * (/root/reference/models/pytorch_i3d.py:116-119).  Arguments as the two calls it replaces; rows = all rows of z (every group). */
+int pc_bn_finalize_apply_ok(int nparts_per_group, int C);
+int pc_bn_finalize_apply(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group, const float* gamma, const float* beta,
+                         float eps, float momentum, float* running_mean, float* running_var, float* stat, const float* z, int ldz, int64_t rows,
+                         float* y, int ldy, int relu, pc_stream s);
 int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean,
                     const float* running_var, float eps, int C, float* stat, pc_stream s);
 /* backward: dy (grad after ReLU, row stride lddy), z -> dz; dgamma/dbeta (+)= if accum.
@@ -497,6 +505,7 @@ enum {
     PC_OP_SPLIT_PLANES,             /* l = n, plane stride; p = src, planes */
     PC_OP_SPLIT_PLANES_MULTI,       /* p[0] = HOST pointer to pc_split_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_WSPEC_MASTER_PLANES,      /* i = Acnt, a0, Atot, B, KY, KX, U, Ur; l[0] = plane stride; p = w, tw, out_f planes, out_t planes */
+    PC_OP_BN_FIN_APPLY,             /* i = npg, groups, C, ldz, ldy, relu; l = count per group, rows; f = eps, momentum; p = part, gamma, beta, running_mean, running_var, stat, z, y */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

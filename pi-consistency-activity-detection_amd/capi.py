@@ -61,7 +61,7 @@ OP_DTYPE = np.dtype([("kind", np.int32), ("i", np.int32, 48), ("f", np.float32, 
  OP_ACT_BWD, OP_TO_NDHWC, OP_TO_NCDHW, OP_TRANSPOSE, OP_FILL, OP_AXPY, OP_EM_FWD, OP_EM_BWD, OP_CMASK_FWD, OP_CMASK_BWD,
  OP_TAPSUM_FWD, OP_TAPSUM_BWD, OP_LOSS, OP_SPREAD, OP_ADAM, OP_TAIL_COMBINE, OP_TAIL_COLSUM, OP_TAIL_GRADS, OP_COL2IM,
  OP_AXIS, OP_WSPEC_FWD, OP_WSPEC_BWD, OP_WSPEC_MASTER_FWD, OP_WSPEC_MASTER_BWD, OP_TAIL6_WEIGHTS, OP_TAIL6_GATHER, OP_TAIL6_SCATTER, OP_TAIL6_WGRAD_MAP, OP_TAIL6_BIAS_SUMS,
- OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS, OP_CONV_X6, OP_SPLIT_PLANES, OP_SPLIT_PLANES_MULTI, OP_WSPEC_MASTER_PLANES) = range(1, 49)
+ OP_TRANSPOSE_MULTI, OP_FORK, OP_JOIN, OP_WGRAD_MULTI, OP_WINO_CONV, OP_WINO_WEIGHTS, OP_CONV_X6, OP_SPLIT_PLANES, OP_SPLIT_PLANES_MULTI, OP_WSPEC_MASTER_PLANES, OP_BN_FIN_APPLY) = range(1, 50)
 MAX_LANES = 8
 
 # numpy mirror of struct pc_wgrad_job (pc_wgrad_desc = 42 int32, then D, S, g)
@@ -101,6 +101,8 @@ _SIGS = {
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),
     "pc_bn_finalize_ws": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, vp]),
     "pc_bn_finalize_ws_floats": (i64, [i32, i32, i32]),
+    "pc_bn_finalize_apply_ok": (i32, [i32, i32]),
+    "pc_bn_finalize_apply": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp, i32, i64, vp, i32, i32, vp]),
     "pc_bn_apply": (i32, [vp, i32, vp, i32, i64, i32, vp, i32, i32, vp]),
     "pc_bn_eval_stat": (i32, [vp, vp, vp, vp, f32, i32, vp, vp]),
     "pc_bn_bwd_ws_floats": (i64, [i64, i32, i32]),

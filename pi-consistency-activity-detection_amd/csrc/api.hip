@@ -49,6 +49,9 @@ static int run_one(const pc_op& op, pc_stream s) {
                                      P(float*, 3), P(float*, 4), P(float*, 5), P(float*, 6), s);
         case PC_OP_BN_APPLY:
             return pc_bn_apply(P(const float*, 0), op.i[0], P(const float*, 1), op.i[1], op.l[0], op.i[2], P(float*, 2), op.i[3], op.i[4], s);
+        case PC_OP_BN_FIN_APPLY:
+            return pc_bn_finalize_apply(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], P(const float*, 1), P(const float*, 2), op.f[0], op.f[1], P(float*, 3),
+                                        P(float*, 4), P(float*, 5), P(const float*, 6), op.i[3], op.l[1], P(float*, 7), op.i[4], op.i[5], s);
         case PC_OP_BN_EVAL_STAT:
             return pc_bn_eval_stat(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), op.f[0], op.i[0], P(float*, 4), s);
         case PC_OP_BN_BWD:

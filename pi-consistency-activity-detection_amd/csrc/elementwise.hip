@@ -237,6 +237,148 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+
+// ------------------------------------------------------------------------------ BatchNorm with the finalize folded into the apply kernel (round 5)
+// The finalize kernels are a handful of blocks between two streaming kernels on the step's dependency chain: 6 - 8 us alone, 20 - 26 us each
+// in the four-lane step, where they wait for a free slot beside the other lanes' whole-CU GEMM blocks (17 + 15 such launches on lane 0 alone).
+// For layers with few partial rows (the 28 x 28 layers: <= 256 per batch group) every block of the apply kernel instead reduces the partial
+// rows of ITS 64 channels itself -- 16 row lanes x 16 float4 columns, doubles, fixed order; a few tens of KB from L2 -- and goes on to its
+// rows.  Grid = (row blocks, 64-channel blocks, batch groups); the row block 0 of group 0 also writes what leaves the layer (stat / running
+// statistics; d gamma / d beta), walking the other groups' partial rows for that.
+constexpr int FA_CB = 64;        // channels per block
+// sums of the partial rows [npg][2][C] over rows, for the channels cb * 64 .. + 63: valid on threads tid < 64 (channel cb * 64 + tid)
+__device__ __forceinline__ void fa_partial_sums(const float* __restrict__ part, int npg, int C, int cb, int tid, double (*shd)[FA_CB][2], double& s, double& s2) {
+    const int c4 = tid & 15, rl = tid >> 4, c = cb * FA_CB + c4 * 4;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (c < C) {
+#pragma unroll 4
+        for (int i = rl; i < npg; i += 16) {
+            const f32x4 x = *(const f32x4*)(part + (size_t)i * 2 * C + c), y = *(const f32x4*)(part + (size_t)i * 2 * C + C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { a[e] += (double)x[e]; b[e] += (double)y[e]; }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {          // the four row lanes of a wave (lane bits 4, 5), then the four waves through LDS
+        a[e] += __shfl_xor(a[e], 16, 64); a[e] += __shfl_xor(a[e], 32, 64);
+        b[e] += __shfl_xor(b[e], 16, 64); b[e] += __shfl_xor(b[e], 32, 64);
+    }
+    __syncthreads();                       // (a previous call's readers are done with shd)
+    if ((tid & 63) < 16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { shd[tid >> 6][c4 * 4 + e][0] = a[e]; shd[tid >> 6][c4 * 4 + e][1] = b[e]; }
+    }
+    __syncthreads();
+    s = 0; s2 = 0;
+    if (tid < FA_CB) {
+        s = ((shd[0][tid][0] + shd[1][tid][0]) + shd[2][tid][0]) + shd[3][tid][0];
+        s2 = ((shd[0][tid][1] + shd[1][tid][1]) + shd[2][tid][1]) + shd[3][tid][1];
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_fin_apply_kernel(const float* __restrict__ part, int npg, int groups, int C, double count,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float mom,
+                                                           float* rmean, float* rvar, float* __restrict__ stat, const float* __restrict__ z, int ldz,
+                                                           float* __restrict__ y, int ldy, int relu, int rows_per_group, int rows_per_block) {
+    __shared__ double shd[4][FA_CB][2];
+    __shared__ __attribute__((aligned(16))) float shs[2][FA_CB];
+    const int tid = threadIdx.x, rb = blockIdx.x, cb = blockIdx.y, g = blockIdx.z;
+    const int ch = cb * FA_CB + tid;                  // this thread's channel in the per-channel sections (tid < 64)
+    double s, s2;
+    fa_partial_sums(part + (size_t)g * npg * 2 * C, npg, C, cb, tid, shd, s, s2);
+    double mean0 = 0, var0 = 0;
+    if (tid < FA_CB && ch < C) {
+        const double mean = s / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float sc = gamma[ch] * invstd, sh = beta[ch] - (float)mean * sc;
+        shs[0][tid] = sc; shs[1][tid] = sh;
+        if (rb == 0) {
+            float* st = stat + (size_t)g * 4 * C;
+            st[ch] = (float)mean; st[C + ch] = invstd; st[2 * C + ch] = sc; st[3 * C + ch] = sh;
+        }
+        mean0 = mean; var0 = var;
+    }
+    if (rb == 0 && g == 0 && rmean != nullptr) {      // block-uniform: running statistics over the batch groups IN ORDER (two forward passes)
+        float rm = 0.f, rv = 0.f;
+        if (tid < FA_CB && ch < C) { rm = rmean[ch]; rv = rvar[ch]; }
+        for (int q = 0; q < groups; ++q) {
+            double mean = mean0, var = var0;
+            if (q > 0) {
+                double t, t2;
+                fa_partial_sums(part + (size_t)q * npg * 2 * C, npg, C, cb, tid, shd, t, t2);
+                mean = t / count; var = t2 / count - mean * mean;
+                if (var < 0.0) var = 0.0;
+            }
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rm = (1.f - mom) * rm + mom * (float)mean;
+            rv = (1.f - mom) * rv + mom * (float)unb;
+        }
+        if (tid < FA_CB && ch < C) { rmean[ch] = rm; rvar[ch] = rv; }
+    }
+    __syncthreads();
+    const int c4 = tid & 15, rl = tid >> 4, c = cb * FA_CB + c4 * 4;
+    if (c >= C) return;
+    const f32x4 sc = *(const f32x4*)&shs[0][c4 * 4], sh = *(const f32x4*)&shs[1][c4 * 4];
+    const int64_t r0 = (int64_t)g * rows_per_group + (int64_t)rb * rows_per_block;
+    const int64_t r1 = min((int64_t)(g + 1) * rows_per_group, r0 + rows_per_block);
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+        const f32x4 v = *(const f32x4*)(z + r * ldz + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { const float t = v[e] * sc[e] + sh[e]; o[e] = relu ? fmaxf(t, 0.f) : t; }
+        *(f32x4*)(y + r * ldy + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_fin_apply_kernel(const float* __restrict__ part, int npg, int groups, int C, double count,
+                                                               const float* __restrict__ dy, int lddy, const float* __restrict__ z, int ldz,
+                                                               const float* __restrict__ stat, int relu, float* __restrict__ dz, int lddz,
+                                                               float* dgamma, float* dbeta, int accum, int rows_per_group, int rows_per_block) {
+    __shared__ double shd[4][FA_CB][2];
+    __shared__ __attribute__((aligned(16))) float shs[2][FA_CB];
+    const int tid = threadIdx.x, rb = blockIdx.x, cb = blockIdx.y, g = blockIdx.z;
+    const int ch = cb * FA_CB + tid;
+    double s, s2;
+    fa_partial_sums(part + (size_t)g * npg * 2 * C, npg, C, cb, tid, shd, s, s2);
+    if (tid < FA_CB && ch < C) { shs[0][tid] = (float)(s / count); shs[1][tid] = (float)(s2 / count); }
+    if (rb == 0 && g == 0) {                          // block-uniform: d beta / d gamma = the sums over every group, in group order
+        double tb = s, tg = s2;
+        for (int q = 1; q < groups; ++q) {
+            double t, t2;
+            fa_partial_sums(part + (size_t)q * npg * 2 * C, npg, C, cb, tid, shd, t, t2);
+            tb += t; tg += t2;
+        }
+        if (tid < FA_CB && ch < C) {
+            if (dbeta) dbeta[ch] = (accum ? dbeta[ch] : 0.f) + (float)tb;
+            if (dgamma) dgamma[ch] = (accum ? dgamma[ch] : 0.f) + (float)tg;
+        }
+    }
+    __syncthreads();
+    const int c4 = tid & 15, rl = tid >> 4, c = cb * FA_CB + c4 * 4;
+    if (c >= C) return;
+    const f32x4 c1 = *(const f32x4*)&shs[0][c4 * 4], c2 = *(const f32x4*)&shs[1][c4 * 4];
+    const float* st = stat + (size_t)g * 4 * C;
+    const f32x4 mean = *(const f32x4*)(st + c), inv = *(const f32x4*)(st + C + c);
+    const f32x4 sc = *(const f32x4*)(st + 2 * C + c), sh_ = *(const f32x4*)(st + 3 * C + c);
+    const int64_t r0 = (int64_t)g * rows_per_group + (int64_t)rb * rows_per_block;
+    const int64_t r1 = min((int64_t)(g + 1) * rows_per_group, r0 + rows_per_block);
+#pragma unroll 4
+    for (int64_t r = r0 + rl; r < r1; r += 16) {
+        const f32x4 d = *(const f32x4*)(dy + r * lddy + c), zz = *(const f32x4*)(z + r * ldz + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float yv = zz[e] * sc[e] + sh_[e];
+            const float dd = (relu && !(yv > 0.f)) ? 0.f : d[e];
+            o[e] = sc[e] * (dd - c1[e] - (zz[e] - mean[e]) * inv[e] * c2[e]);
+        }
+        *(f32x4*)(dz + r * lddz + c) = o;
+    }
+}
+
 // partial [nblk][2][C] -> dbias (+)=
 __global__ __launch_bounds__(FIN_T) void colsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* out, int accum) {
     __shared__ double sh[2][FIN_RL][FIN_CL];
@@ -531,6 +673,34 @@ extern "C" int pc_bn_finalize(const float* part, int nparts_per_group, int group
     return pc_bn_finalize_ws(part, nparts_per_group, groups, C, count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat, nullptr, s);
 }
 
+// Finalize + apply in ONE launch (bn_fin_apply_kernel): for layers with at most FA_MAX_NPG partial rows per batch group.  Same results as
+// pc_bn_finalize followed by pc_bn_apply (the per-channel sums are taken in double in another, equally fixed order).
+constexpr int FA_MAX_NPG = 256;
+static int fa_rows_per_block(int64_t rpg, int cblocks, int groups) {
+    // about 2048 blocks, at least 128 rows each (the partial rows a block re-reads must stay a fraction of the rows it streams), whole 16-row passes
+    int64_t rb = (rpg * cblocks * groups + 2047) / 2048;
+    if (rb < 128) rb = 128;
+    return (int)((rb + 15) / 16 * 16);
+}
+extern "C" int pc_bn_finalize_apply_ok(int nparts_per_group, int C) { return nparts_per_group >= 1 && nparts_per_group <= FA_MAX_NPG && C % 4 == 0 ? 1 : 0; }
+
+extern "C" int pc_bn_finalize_apply(const float* part, int nparts_per_group, int groups, int C, int64_t count_per_group, const float* gamma, const float* beta,
+                                    float eps, float momentum, float* running_mean, float* running_var, float* stat, const float* z, int ldz, int64_t rows,
+                                    float* y, int ldy, int relu, pc_stream s) {
+    PC_CHECK_ARG(part && gamma && beta && stat && z && y && groups >= 1 && C > 0 && C % 4 == 0 && ldz % 4 == 0 && ldy % 4 == 0 && rows % groups == 0,
+                 "pc_bn_finalize_apply: bad args (C=%d)", C);
+    PC_CHECK_ARG(pc_bn_finalize_apply_ok(nparts_per_group, C), "pc_bn_finalize_apply: %d partial rows per group (at most %d: use pc_bn_finalize + pc_bn_apply)",
+                 nparts_per_group, FA_MAX_NPG);
+    PC_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "pc_bn_finalize_apply: running_mean / running_var go together");
+    const int64_t rpg = rows / groups;
+    PC_CHECK_ARG(rows * (int64_t)(C / 4) < (1ll << 31) && rpg < (1ll << 31), "elementwise kernels index with 32 bits");
+    const int cblocks = cdiv(C, FA_CB), rpb = fa_rows_per_block(rpg, cblocks, groups);
+    hipLaunchKernelGGL(bn_fin_apply_kernel, dim3((unsigned)cdiv(rpg, rpb), cblocks, groups), dim3(256), 0, (hipStream_t)s, part, nparts_per_group, groups, C,
+                       (double)count_per_group, gamma, beta, eps, momentum, running_mean, running_var, stat, z, ldz, y, ldy, relu, (int)rpg, rpb);
+    PC_CHECK_LAUNCH("bn_fin_apply");
+    return PC_OK;
+}
+
 extern "C" int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                                float eps, int C, float* stat, pc_stream s) {
     PC_CHECK_ARG(gamma && beta && running_mean && running_var && stat, "pc_bn_eval_stat: null");
@@ -560,7 +730,13 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(dy && z && stat && dz && ws && C % 4 == 0 && C <= 1024 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 &&
                  groups >= 1 && rows % groups == 0, "pc_bn_bwd: bad args (C=%d)", C);
-    const int64_t rpg = rows / groups, rpb = red_rows_per_block(rpg);
+    const int64_t rpg = rows / groups;
+    // layers of at most 16 384 rows per group (the 28 x 28 layers): 64 partial rows per group and the finalize folded into the apply kernel
+    // (bn_bwd_fin_apply_kernel) -- two launches instead of three on the dependency chain.  PICONS_BN_FUSED=0: the three-launch form everywhere.
+    static const int fuse = getenv("PICONS_BN_FUSED") ? atoi(getenv("PICONS_BN_FUSED")) : 1;
+    const bool fused = fuse && rpg <= 16384;
+    int64_t rpb = red_rows_per_block(rpg);
+    if (fused && (rpg + 63) / 64 > rpb) rpb = (rpg + 63) / 64;
     const int npg = (int)((rpg + rpb - 1) / rpb);
     float* part = ws;
     float* coef = ws + (size_t)npg * groups * 2 * C;
@@ -573,6 +749,14 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
         hipLaunchKernelGGL(colreduce_kernel<0>, dim3(npg, groups), dim3(256), 0, s, p);
     }
     PC_CHECK_LAUNCH("bn_bwd reduce");
+    if (fused) {
+        PC_CHECK_ARG(rows * (int64_t)(C / 4) < (1ll << 31), "elementwise kernels index with 32 bits");
+        const int cblocks = cdiv(C, FA_CB), rb2 = fa_rows_per_block(rpg, cblocks, groups);
+        hipLaunchKernelGGL(bn_bwd_fin_apply_kernel, dim3((unsigned)cdiv(rpg, rb2), cblocks, groups), dim3(256), 0, s, part, npg, groups, C, (double)rpg, dy, lddy, z, ldz,
+                           stat, relu, dz, lddz, dgamma, dbeta, accum, (int)rpg, rb2);
+        PC_CHECK_LAUNCH("bn_bwd fin_apply");
+        return PC_OK;
+    }
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FIN_CL)), dim3(FIN_T), 0, s, part, npg, groups, C, (double)rpg, coef, dgamma, dbeta, accum);
     const int64_t total4 = rows * (C / 4);
     PC_CHECK_ARG(total4 < (1ll << 31), "elementwise kernels index with 32 bits: %lld float4 elements", (long long)total4);

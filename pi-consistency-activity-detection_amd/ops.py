@@ -131,6 +131,14 @@ def bn_finalize(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean=
     return stat
 
 
+def bn_finalize_apply(part, npg, groups, C_, count, gamma, beta, eps, momentum, rmean, rvar, z, ldz, rows, y, ldy, relu=True):
+    """pc_bn_finalize_apply: the statistics and the normalised output in one launch (npg <= 256 partial rows per group) -> stat."""
+    stat = torch.empty(groups, 4, C_, device=part.device, dtype=torch.float32)
+    capi.call("pc_bn_finalize_apply", ptr(part), npg, groups, C_, int(count), ptr(gamma), ptr(beta), eps, momentum, ptr(rmean), ptr(rvar), ptr(stat),
+              ptr(z), ldz, int(rows), ptr(y), ldy, int(relu), stream())
+    return stat
+
+
 def bn_apply(z, ldz, stat, C_, rows, groups, y, ldy, relu=True):
     capi.call("pc_bn_apply", ptr(z), ldz, ptr(stat), C_, int(rows), groups, ptr(y), ldy, int(relu), stream())
     return y

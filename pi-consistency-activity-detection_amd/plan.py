@@ -362,6 +362,16 @@ class Plan:
             self.final_at[nm] = len(self.lists["bwd"])
             self.final_lane[nm] = self.lane
 
+    def bn_finalize_or_defer(self, nrows, cout, z, part, gamma, beta, pre, stat):
+        """BatchNorm(train) statistics of a Unit3D from the conv's partial rows: either the finalize launch is emitted here (-> None), or --
+        few partial rows per batch group, PICONS_BN_FUSED != 0 -- the caller folds it into the apply launch (-> what that op needs)."""
+        npg = nrows // self.groups
+        if os.environ.get("PICONS_BN_FUSED", "1") != "0" and capi.lib().pc_bn_finalize_apply_ok(int(npg), int(cout)):
+            return dict(npg=npg, part=part)
+        self.emit(capi.OP_BN_FINALIZE, i=[npg, self.groups, cout], l=[z.rows // self.groups], f=[spec.BN_EPS, spec.BN_MOMENTUM],
+                  p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(npg, cout)])
+        return None
+
     def bn_fin_ws(self, npg, C):
         """Workspace of the two-stage BatchNorm finalize (pc_bn_finalize_ws; None below 512 partial rows per group)."""
         n = capi.lib().pc_bn_finalize_ws_floats(int(npg), int(self.groups), int(C))
@@ -570,6 +580,7 @@ class Plan:
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
         wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training) if wino else None
+        fin = None
         tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
         tmap_b = (1, pf[0] - 2, stride[0])                 # input gradient (mirrored taps): frame (t + pad_front - 2 + kt) / s
         if self.training and wino:
@@ -577,9 +588,7 @@ class Plan:
             part = self.alloc(nrows * 2 * cout)
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
             self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART)
-            self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
-                      f=[spec.BN_EPS, spec.BN_MOMENTUM],
-                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(nrows // self.groups, cout)])
+            fin = self.bn_finalize_or_defer(nrows, cout, z, part, gamma, beta, pre, stat)
             g_apply = self.groups
         elif wino:
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
@@ -600,9 +609,7 @@ class Plan:
             nrows = _bnpart_rows(d)
             part = self.alloc(nrows * 2 * cout)
             self.conv_op(d, x.ref, w["fwd"], z.ref, bnpart=part, x6=trunk_x6)
-            self.emit(capi.OP_BN_FINALIZE, i=[nrows // self.groups, self.groups, cout], l=[z.rows // self.groups],
-                      f=[spec.BN_EPS, spec.BN_MOMENTUM],
-                      p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(nrows // self.groups, cout)])
+            fin = self.bn_finalize_or_defer(nrows, cout, z, part, gamma, beta, pre, stat)
             g_apply = self.groups
         else:
             d = D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw, flags=capi.F_CI3 if ci3 else 0)
@@ -611,7 +618,11 @@ class Plan:
             self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
                       p=[gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
             g_apply = 1
-        self.emit(capi.OP_BN_APPLY, i=[z.ld, cout, g_apply, y.ld, 1], l=[z.rows], p=[z.ref, stat, y.ref])
+        if fin is not None:           # finalize folded into the apply kernel (few partial rows: one dispatch fewer on the chain)
+            self.emit(capi.OP_BN_FIN_APPLY, i=[fin["npg"], self.groups, cout, z.ld, y.ld, 1], l=[z.rows // self.groups, z.rows], f=[spec.BN_EPS, spec.BN_MOMENTUM],
+                      p=[fin["part"], gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, z.ref, y.ref])
+        else:
+            self.emit(capi.OP_BN_APPLY, i=[z.ld, cout, g_apply, y.ld, 1], l=[z.rows], p=[z.ref, stat, y.ref])
 
         st = {}
 

@@ -239,9 +239,9 @@ class StepEngine:
             self.aview(ref, n).zero_()
         torch.cuda.synchronize(self.dev)
 
-    def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
+    def forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None, timed_on_lanes=False):
         try:
-            return self._forward_backward(epoch, wt_ramp, reducer, timed_kind)
+            return self._forward_backward(epoch, wt_ramp, reducer, timed_kind, timed_on_lanes)
         except Exception:
             try:
                 self.reset_workspaces()
@@ -249,7 +249,7 @@ class StepEngine:
                 pass
             raise
 
-    def _forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None):
+    def _forward_backward(self, epoch, wt_ramp, reducer=None, timed_kind=None, timed_on_lanes=False):
         """prep -> forward (both passes batched) -> losses -> backward.  With a dist.GradReducer the
         backward list is replayed in segments and each gradient bucket's all-reduce is launched as soon
         as the ops that finalise it are enqueued.  timed_kind: accumulate hipEvent time of that op kind
@@ -263,8 +263,10 @@ class StepEngine:
                 ops.run_ops(arr, side=self.side)
             else:
                 # a timed step is replayed on ONE stream (FORK / JOIN are no-ops then): kernels that overlap on two lanes stretch
-                # each other's event-timed duration, and the roofline leg wants every kernel's own duration
-                ops.run_ops_timed(arr, timed_kind, side=None, defer=True)    # read after the step's own sync
+                # each other's event-timed duration, and the roofline leg wants every kernel's own duration.  timed_on_lanes: the event
+                # pairs ride in the dispatches of the ordinary four-lane step instead (durations as stretched by the co-running lanes):
+                # what bench.py's headline leg uses, so that its timed steps cost what every other step costs
+                ops.run_ops_timed(arr, timed_kind, side=self.side if timed_on_lanes else None, defer=True)    # read after the step's own sync
         run(o["prep"])
         run(o["prep_late"])        # side lanes only; joined inside the forward list (plan.late_prep)
         run(o["fwd"])
@@ -411,26 +413,27 @@ class StepEngine:
         self.kind_ms += ms
         self.kind_count += cnt
 
-    def run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True):
+    def run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True, timed_on_lanes=False):
         if self.main is not None and reducer is None:
             self.main.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.main):
-                out = self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect)
+                out = self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect, timed_on_lanes)
             torch.cuda.current_stream().wait_stream(self.main)
             return out
-        return self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect)
+        return self._run_staged(epoch, wt_ramp, lr, reducer, timed_kind, collect, timed_on_lanes)
 
-    def _run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True):
+    def _run_staged(self, epoch, wt_ramp, lr=None, reducer=None, timed_kind=None, collect=True, timed_on_lanes=False):
         """One full step on the minibatch already staged in HBM: fwd x2 + losses + bwd (+ all-reduce) +
         Adam + the packed loss read-back.  RETURNS WITH THE BACKWARD AND ADAM STILL IN FLIGHT: the only host wait is for the loss
         scalars' copy, which is final before the backward starts.  Stream-ordered consumers (the next step, torch ops on the current
         stream) need nothing; anything else calls synchronize() first.  collect=False leaves the timing events of a timed step pending (the caller
         reads them with collect_timing() later, e.g. after its timed region: reading 212 events costs ~0.4 ms of host time)."""
-        if reducer is not None and reducer.active and timed_kind is None:
+        product = timed_kind is None or timed_on_lanes          # the ordinary schedule (a single-stream timed replay is not)
+        if reducer is not None and reducer.active and product:
             self.arm_early_adam_dp(self.args.lr if lr is None else lr, reducer)
         else:
-            self.arm_early_adam(self.args.lr if lr is None else lr, on=(reducer is None or not reducer.active) and timed_kind is None)
-        self.forward_backward(epoch, wt_ramp, reducer, timed_kind)
+            self.arm_early_adam(self.args.lr if lr is None else lr, on=(reducer is None or not reducer.active) and product)
+        self.forward_backward(epoch, wt_ramp, reducer, timed_kind, timed_on_lanes)
         gscale = 1.0
         if reducer is not None:
             reducer.wait()

@@ -50,7 +50,7 @@ def test_bench_line_contract():
     assert abs(d["frac"] - d["achieved"] / d["peak"]) < 1e-9 and 0.1 < d["frac"] < 1.0 and d["kernel_ms_per_step"] < j["ms_per_step"]
     r = j["roofline_conv_x6"]                               # fp32 on the bf16 matrix cores, roof = bf16 peak / 6 products
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["peak"] - 2500.0 / 6) < 1e-6 and "conv_x6_kernel" in r["kernel"]
-    assert r["in_region_timed_steps"] >= 1 and 0.67 < r["in_region_kernel_ms_per_step"] / r["kernel_ms_per_step"] < 1.5
+    assert r["in_region_timed_steps"] >= 1 and 0.9 < r["in_region_kernel_ms_per_step"] / r["kernel_ms_per_step"] < 4.0      # in-step durations are stretched by the other lanes
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.1 < r["frac"] < 1.0
     assert r["launches_per_step"] > 30 and abs(r["avg_launch_ms"] * r["launches_per_step"] - r["kernel_ms_per_step"]) < 1e-6 * r["kernel_ms_per_step"]
     assert r["kernel_ms_per_step"] < j["ms_per_step"]                                    # event time of the conv kernels fits inside the step

@@ -380,6 +380,77 @@ def test_unit3d_bn_relu_fwd_bwd(groups):
     close(uncl(ye), ref_e, what="bn eval")
 
 
+@pytest.mark.parametrize("rows_g,C,ld,npg", [(6272, 512, 512, 98), (12544, 208, 832, 196), (1000, 40, 48, 7), (300, 64, 64, 256)])
+def test_bn_finalize_folded_into_apply_matches_the_two_launches(rows_g, C, ld, npg):
+    """pc_bn_finalize_apply (round 5): every block of the apply kernel reduces the partial rows of its own 64 channels.  Against
+    pc_bn_finalize + pc_bn_apply on the same partial rows: statistics and running statistics to the last bit or one ulp (both sum in fp64,
+    in different fixed orders), outputs to one ulp of the scale, channel slices of wider tensors untouched outside, repeated runs identical."""
+    g = torch.Generator().manual_seed(rows_g + C)
+    groups, rows = 2, 2 * rows_g
+    z = torch.randn(rows, ld, generator=g).to(DEV)
+    zs = z[:, 8:8 + C] if ld > C else z
+    # partial rows as a conv epilogue leaves them: sums / sums of squares of row blocks of each group
+    per = -(-rows_g // npg)
+    part = torch.zeros(groups * npg, 2, C, device=DEV)
+    for gi in range(groups):
+        for q in range(npg):
+            blk = zs[gi * rows_g + q * per: gi * rows_g + min(rows_g, (q + 1) * per)].double()
+            if blk.numel():
+                part[gi * npg + q, 0] = blk.sum(0).float(); part[gi * npg + q, 1] = (blk * blk).sum(0).float()
+    gamma = (torch.rand(C, generator=g) + 0.5).to(DEV); beta = torch.randn(C, generator=g).to(DEV)
+    rm0 = torch.randn(C, generator=g).to(DEV); rv0 = (torch.rand(C, generator=g) + 0.5).to(DEV)
+    rm, rv = rm0.clone(), rv0.clone()
+    st = ops.bn_finalize(part, npg, groups, C, rows_g, gamma, beta, spec.BN_EPS, spec.BN_MOMENTUM, rm, rv)
+    y = torch.full((rows, ld), 3.5, device=DEV)
+    ops.bn_apply(zs, ld, st, C, rows, groups, y[:, 8:] if ld > C else y, ld, True)
+    outs = []
+    for _ in range(2):
+        rm2, rv2 = rm0.clone(), rv0.clone()
+        y2 = torch.full((rows, ld), 3.5, device=DEV)
+        st2 = ops.bn_finalize_apply(part, npg, groups, C, rows_g, gamma, beta, spec.BN_EPS, spec.BN_MOMENTUM, rm2, rv2, zs, ld, rows, y2[:, 8:] if ld > C else y2, ld, True)
+        outs.append((st2.clone(), rm2, rv2, y2))
+    st2, rm2, rv2, y2 = outs[0]
+    assert torch.allclose(st2, st, rtol=3e-7, atol=1e-9) and torch.allclose(rm2, rm, rtol=3e-7, atol=1e-9) and torch.allclose(rv2, rv, rtol=3e-7, atol=1e-9)
+    assert (y2 - y).abs().max().item() <= 4e-7 * max(1.0, y.abs().max().item())
+    if ld > C:
+        assert torch.all(y2[:, :8] == 3.5) and torch.all(y2[:, 8 + C:] == 3.5)
+    assert all(torch.equal(a, b) for a, b in zip(outs[0], outs[1]))
+    # the mean really is the mean of the rows
+    assert torch.allclose(st2[:, 0].double().cpu(), zs.double().view(groups, rows_g, C).mean(1).cpu(), atol=2e-6)
+    assert capi.lib().pc_bn_finalize_apply_ok(257, 64) == 0 and capi.lib().pc_bn_finalize_apply_ok(256, 64) == 1
+
+
+@pytest.mark.parametrize("rows_g,C", [(6272, 512), (12544, 112), (20000, 64)])
+def test_bn_backward_both_forms_vs_autograd(rows_g, C):
+    """pc_bn_bwd at layer sizes on both sides of its switch (<= 16 384 rows per group: 64 partial rows and the finalize folded into the apply
+    kernel; above: three launches) against torch autograd of BatchNorm(train) + ReLU in float64, two batch groups."""
+    g = torch.Generator().manual_seed(C)
+    groups, rows = 2, 2 * rows_g
+    z = torch.randn(rows, C, generator=g, dtype=torch.float64) * 2 + 0.3
+    dy = torch.randn(rows, C, generator=g, dtype=torch.float64)
+    gamma = (torch.rand(C, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    zr = z.clone().requires_grad_(True)
+    ys = [torch.relu(F.batch_norm(zr[i * rows_g:(i + 1) * rows_g], None, None, gamma, beta, True, 0.0, spec.BN_EPS)) for i in range(groups)]
+    (torch.cat(ys) * dy).sum().backward()
+    zg = z.float().to(DEV)
+    stat = torch.empty(groups, 4, C, device=DEV)
+    for i in range(groups):
+        blk = z[i * rows_g:(i + 1) * rows_g]
+        mean, var = blk.mean(0), blk.var(0, unbiased=False)
+        inv = 1.0 / torch.sqrt(var + spec.BN_EPS)
+        stat[i, 0], stat[i, 1] = mean.float().to(DEV), inv.float().to(DEV)
+        stat[i, 2], stat[i, 3] = (gamma.detach() * inv).float().to(DEV), (beta.detach() - mean * gamma.detach() * inv).float().to(DEV)
+    dz = torch.empty(rows, C, device=DEV); dgam = torch.zeros(C, device=DEV); dbet = torch.zeros(C, device=DEV)
+    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dgam, dbet)
+    close(dz.cpu(), zr.grad, rtol=2e-4, atol=2e-5, what="dz")
+    close(dgam.cpu(), gamma.grad, rtol=2e-4, atol=2e-3, what="dgamma")
+    close(dbet.cpu(), beta.grad, rtol=2e-4, atol=2e-3, what="dbeta")
+    dg2 = dgam.clone(); db2 = dbet.clone()
+    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dg2, db2, accum=True)
+    assert torch.allclose(dg2, 2 * dgam, rtol=1e-6, atol=1e-6) and torch.allclose(db2, 2 * dbet, rtol=1e-6, atol=1e-6)
+
+
 @pytest.mark.parametrize("npg,C", [(6272, 64), (1568, 192), (513, 40), (100, 64)])
 def test_bn_finalize_two_stage_matches_one_stage(npg, C):
     """Layers with thousands of BatchNorm partial rows (the stem: 6272 per group) are finalized in two stages (32 slices per 16 channels

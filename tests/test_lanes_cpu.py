@@ -12,6 +12,7 @@ from picons_amd.plan import Plan
 
 # p[] slots each op kind WRITES (every other non-null slot is read); kinds are those plan.py emits into fwd / loss / bwd
 WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4, 5, 6), capi.OP_BN_APPLY: (2,), capi.OP_BN_EVAL_STAT: (4,),
+          capi.OP_BN_FIN_APPLY: (3, 4, 5, 7),
           capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_CHSCALE: (2,), capi.OP_ACT_BWD: (2, 3, 4),
           capi.OP_TO_NDHWC: (1,), capi.OP_TRANSPOSE: (1,), capi.OP_FILL: (0,), capi.OP_EM_FWD: (4, 5), capi.OP_EM_BWD: (5, 6, 7, 8, 9),
           capi.OP_CMASK_FWD: (3, 4, 5), capi.OP_CMASK_BWD: (3,), capi.OP_TAIL_COMBINE: (4, 5, 6), capi.OP_TAIL6_WEIGHTS: (1, 2),
@@ -310,7 +311,7 @@ def test_flat_layout_groups_the_stacked_units(monkeypatch):
                     o += p.pshape[pre + ".bn.weight"][0]
     # one conv / BN per group instead of three: 2 x 7 fewer convs forward
     count = lambda pl, kind: sum(1 for op in pl.lists["fwd"] if op[0] == kind)
-    assert count(q, capi.OP_CONV) - count(p, capi.OP_CONV) == 14 and count(q, capi.OP_BN_APPLY) - count(p, capi.OP_BN_APPLY) == 14
+    assert count(q, capi.OP_CONV) - count(p, capi.OP_CONV) == 14 and (count(q, capi.OP_BN_APPLY) + count(q, capi.OP_BN_FIN_APPLY)) - (count(p, capi.OP_BN_APPLY) + count(p, capi.OP_BN_FIN_APPLY)) == 14
 
 
 @pytest.mark.parametrize("lanes", [1, 2, 4])

@@ -477,15 +477,17 @@ def test_early_adam_uses_final_gradients():
             eng.adam(1e-3)
         eng.synchronize()
         assert eng.step_count == 2
-        res.append((eng.P.clone(), eng.M.clone(), eng.V.clone()))
+        res.append((eng.P.clone(), eng.M.clone(), eng.V.clone(), p0))
     # weight gradients are summed with fp32 atomics (arrival order), and EM routing amplifies the 1e-9 that leaves in the parameters after
-    # step 1 into 1e-5 .. 1e-3 of the trunk's step-2 gradients: the two schedules agree to that, not bit for bit -- parameters after two steps
-    # within 10 % of one step's move, both moments to 1e-2 in rel-L2 (the armed schedule splits the flat buffer between two Adam ops: a range
-    # that one of them doubled, skipped or stepped with the wrong count shows here at 1e-1 .. 1)
-    (Pa, Ma, Va), (Pb, Mb, Vb) = res
-    dP, dM, dV = (Pa - Pb).abs().max().item(), ((Ma - Mb).norm() / Mb.norm()).item(), ((Va - Vb).norm() / Vb.norm()).item()
-    print("early Adam vs one Adam after two steps: max |dP| %.3e (lr 1e-3), rel-L2 dM %.3e, dV %.3e" % (dP, dM, dV))
-    assert dP <= 0.1 * 1e-3 + 1e-7 and dM < 1e-2 and dV < 1e-2, (dP, dM, dV)
+    # step 1 into 1e-5 .. 1e-3 of the trunk's step-2 gradients (measured: rel-L2 1.8e-3 on the first moments, 5.9e-4 on the second; single
+    # elements whose gradient is that noise move by up to 1.5 lr): the two schedules agree to that, not bit for bit -- both moments to 1e-2 in
+    # rel-L2 and the parameters to 2 % of the distance they travelled in the two steps (the armed schedule splits the flat buffer between two
+    # Adam ops: a range that one of them doubled, skipped or stepped with the wrong count shows here at 1e-1 .. 1)
+    (Pa, Ma, Va, P0), (Pb, Mb, Vb, _) = res
+    dP = ((Pa - Pb).norm() / (Pb - P0).norm()).item()
+    dM, dV = ((Ma - Mb).norm() / Mb.norm()).item(), ((Va - Vb).norm() / Vb.norm()).item()
+    print("early Adam vs one Adam after two steps: |dP| / |P - P0| %.3e, rel-L2 dM %.3e, dV %.3e" % (dP, dM, dV))
+    assert dP < 2e-2 and dM < 1e-2 and dV < 1e-2, (dP, dM, dV)
 
 
 @pytest.mark.parametrize("mode", ["default", "reducer"])
