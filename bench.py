@@ -200,17 +200,25 @@ class StagedInputs:
         drops = [(torch.rand(n, c, generator=self.g) < 0.5).float().numpy() * 2 for c in (832, 128, 832, 128)]
         self.st.prepare(slot, lambda j, out: self.ip.get_item(*self.vids[(n * i + j) % nv], train=True, out=out, ndhwc4=True), n // 2, perm, drops)
 
-    def run(self, steps, epoch, ramp, reducer, lr, timed_kind=None, time_every=0):
-        """`steps` full steps, each on a fresh minibatch; returns (seconds, last losses, steps that carried kernel-timing events)."""
+    def run(self, steps, epoch, ramp, reducer, lr, timed_kind=None, time_every=0, warm=0, at_start=None):
+        """`warm` untimed steps flowing straight into `steps` timed ones, each on a fresh minibatch; returns (seconds, last losses, steps that
+        carried kernel-timing events).  The clock starts behind a torch.cuda.synchronize() (and at_start(): the ranks' barrier) between the last
+        warm step and the first timed one: the first timed step's minibatch was prepared under the last warm step, as every later one is under
+        its predecessor -- no host-only phase (sample decoding, first uploads: tens of ms in which the chip clocks down) sits in front of the clock."""
         eng, st = self.eng, self.st
-        self.prep(0, 0)
+        self.prep(-warm, (-warm) & 1)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out, ntimed = None, 0
-        for i in range(steps):
+        for i in range(-warm, steps):
             slot = i & 1
+            if i == 0:
+                torch.cuda.synchronize()
+                if at_start is not None:
+                    at_start()
+                t0 = time.perf_counter()
             st.commit(slot)                   # the main stream waits for the slot; the clip conversion reads it in place
-            tk = timed_kind if (timed_kind is not None and time_every and i % time_every == 0) else None
+            tk = timed_kind if (i >= 0 and timed_kind is not None and time_every and i % time_every == 0) else None
             ntimed += tk is not None
             # a timed step of THIS leg is the ordinary four-lane step with event pairs riding in the dominant kernel's dispatches
             # (timed_on_lanes): it costs what every other step costs; the kernels' own durations come from the single-stream legs
@@ -246,14 +254,21 @@ class DictInputs:
             self.mbs.append(({k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in lab.items()},
                              {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in unl.items()}, perm, drops))
 
-    def run(self, steps, epoch, ramp, reducer, lr):
+    def run(self, steps, epoch, ramp, reducer, lr, warm=0, at_start=None):
+        """As StagedInputs.run: `warm` untimed steps flow straight into the timed ones."""
         eng, st = self.eng, self.st
-        st.prepare(0, *self.mbs[0])
+        nm = len(self.mbs)
+        st.prepare((-warm) & 1, *self.mbs[(-warm) % nm])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         out, host_wait = None, 0.0
-        for i in range(steps):
+        for i in range(-warm, steps):
             slot = i & 1
+            if i == 0:
+                torch.cuda.synchronize()
+                if at_start is not None:
+                    at_start()
+                t0, host_wait = time.perf_counter(), 0.0
             st.commit(slot)
             if reducer is not None and reducer.active:
                 eng.arm_early_adam_dp(lr, reducer)
@@ -266,7 +281,7 @@ class DictInputs:
                 gscale = reducer.gscale
             eng.adam(lr, gscale)
             st.release(slot)
-            st.prepare(slot ^ 1, *self.mbs[(i + 1) % len(self.mbs)])      # the host's 180 MB gather + the uploads run under the step enqueued above
+            st.prepare(slot ^ 1, *self.mbs[(i + 1) % nm])      # the host's 180 MB gather + the uploads run under the step enqueued above
             tw = time.perf_counter()
             out = eng.read_scalars()
             host_wait += time.perf_counter() - tw
@@ -380,13 +395,14 @@ def main():
     timed_steps = 0
     if staged_ok:
         si = StagedInputs(eng, a.bs, ncls, rank)
-        si.run(min(3, a.steps), a.epoch, ramp, reducer, args.lr)                      # warm-up (pinned buffers, first uploads)
-        if world > 1:
-            torch.distributed.barrier()
-        if reducer is not None:
-            torch.cuda.synchronize()
-            reducer.stats()                    # reset: the diagnostics below cover the headline leg only
-        sec, last, timed_steps = si.run(a.steps, a.epoch, ramp, reducer, args.lr, timed_kind=main_kind, time_every=max(1, a.time_every))
+
+        def headline_start():              # between the last warm step and the first timed one, behind torch.cuda.synchronize()
+            if world > 1:
+                torch.distributed.barrier()
+            if reducer is not None:
+                reducer.stats()            # reset: the diagnostics below cover the headline leg only
+        sec, last, timed_steps = si.run(a.steps, a.epoch, ramp, reducer, args.lr, timed_kind=main_kind, time_every=max(1, a.time_every), warm=3,
+                                        at_start=headline_start)
         if world > 1:
             torch.distributed.barrier()
         ms_total = pdist.barrier_max_ms(sec * 1e3, device=dev)
@@ -458,10 +474,7 @@ def main():
     dict_leg = None
     if staged_ok and not a.no_extra_legs:
         di = DictInputs(eng, a.bs, ncls, rank)
-        di.run(3, a.epoch, ramp, reducer, args.lr)
-        if world > 1:
-            torch.distributed.barrier()
-        sec, last_d, host_wait = di.run(n_leg, a.epoch, ramp, reducer, args.lr)
+        sec, last_d, host_wait = di.run(n_leg, a.epoch, ramp, reducer, args.lr, warm=3, at_start=(torch.distributed.barrier if world > 1 else None))
         ms_d = pdist.barrier_max_ms(sec * 1e3, device=dev)
         dict_leg = {"value": world * a.bs * n_leg / (ms_d / 1e3), "unit": "clips/s", "ms_per_step": ms_d / n_leg, "steps": n_leg, "loss_total": last_d["total"],
                     "host_wait_ms_per_step": host_wait * 1e3 / n_leg,
@@ -511,17 +524,18 @@ def main():
     step_exec = conv_exec + x6_exec + wino_exec + wg_exec
     # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run, so this is OFFLINE data from the named file
-    traffic, traffic_src = None, None
-    tkey = "conv_x6_hbm_bytes_per_launch" if split_on else "conv_gemm_hbm_bytes_per_launch"
-    for tag in ("r04", "r03", "r02", "r01"):
+    traffic_of, traffic_src = {}, None
+    for tag in ("r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", tag + "_traffic.json")
-        if traffic is None and os.path.exists(tp) and a.bs == 8:
+        if not traffic_of and os.path.exists(tp) and a.bs == 8:
             try:
-                traffic = json.load(open(tp))[tkey]
+                tj = json.load(open(tp))
+                traffic_of = {"x6": tj.get("conv_x6_hbm_bytes_per_launch"), "f32": tj.get("conv_gemm_hbm_bytes_per_launch"),
+                              "wino": next((v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items() if "wino_conv_kernel" in k), None)}
                 traffic_src = "profiles/%s_traffic.json (offline rocprofv3 --pmc passes, not this run)" % tag
             except Exception:
-                traffic = None
-
+                traffic_of = {}
+    traffic = traffic_of.get("x6" if split_on else "f32")
     def roof(kernel, exec_f, issued_f, valid_f, leg, peak, extra=None):
         kms, count, steps_t, why = leg if leg is not None else (0.0, 0, 0, "leg not run")
         if why is not None or not count or not steps_t:
@@ -550,7 +564,7 @@ def main():
                                           "as stretched by the kernels running beside them on the other lanes); the fractions above come from the single-stream replays"})
         roof_f32conv = roof("conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA gather-GEMM: the launches that stay on v_mfma_f32_32x32x2_f32 -- the RGB stem, "
                             "channel counts that are not multiples of 32, launches too small to gain)", conv_exec, tot(fe, "mfma"), tot(fe, "valid"), legs.get("f32c"),
-                            PEAK_FP32_MFMA_TFLOPS)
+                            PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic_of.get("f32"), "traffic_source": traffic_src})
         if roof_x6.get("achieved"):
             roof_x6["frac_of_fp32_mfma_peak"] = roof_x6["achieved"] / PEAK_FP32_MFMA_TFLOPS
     elif main_kind is not None:
@@ -560,7 +574,8 @@ def main():
         fzd = sum(pl.flops_reference_counted_wino()[n] for n in lists)
         roof_wino = roof("wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
                          legs.get("wino"), PEAK_FP32_MFMA_TFLOPS,
-                         {"flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)"})
+                         {"flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)",
+                          "traffic": traffic_of.get("wino"), "traffic_source": traffic_src})
         if roof_wino.get("kernel_ms_per_step"):
             roof_wino["direct_equivalent_tflops"] = fzd / (roof_wino["kernel_ms_per_step"] * 1e-3) / 1e12      # the 3x3x3 formulation's FLOPs over the same time
     # `roofline` = the GEMM family with the LARGEST single-stream kernel time per step (the dominant kernel); the others keep their own blocks

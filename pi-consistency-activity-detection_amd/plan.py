@@ -935,6 +935,7 @@ class Plan:
         if self.skip_lane:       # the decoder's concat buffers exist before the trunk so the skip convs can write into them early
             cat56 = self.tensor(N, (2, 2 * s28e, 2 * s28e), 128, "cat56")
             cat112 = self.tensor(N, (4, 4 * s28e, 4 * s28e), 128, "cat112")
+        pending_skip, skip_after = [], os.environ.get("PICONS_SKIP_FWD_AFTER", "")
         for ent in spec.TRUNK:
             name = "conv1." + ent[0]
             if ent[0] == "Mixed_3b" and self.late_prep:
@@ -949,11 +950,17 @@ class Plan:
             if ent[0] == "Conv3d_2c_3x3":
                 out56 = x
                 if self.skip_lane:
-                    self._skip_conv("conv56", out56, cat56)
+                    pending_skip.append(("conv56", out56, cat56))
             if ent[0] == "Conv3d_1a_7x7":
                 out112 = x
                 if self.skip_lane:
-                    self._skip_conv("conv112", out112, cat112)
+                    pending_skip.append(("conv112", out112, cat112))
+            # the skip convs' forward: right behind their input (default), or held until the trunk entry PICONS_SKIP_FWD_AFTER has been emitted
+            # (A/B switch: whole-CU Winograd blocks of conv112 / conv56 beside the chain's own big layers, or beside its small 28 x 28 ones)
+            if pending_skip and (not skip_after or ent[0] == skip_after or ent is spec.TRUNK[-1]):
+                for nm_, t_, c_ in pending_skip:
+                    self._skip_conv(nm_, t_, c_)
+                pending_skip = []
             if ent[0] == "MaxPool3d_3a_3x3" and self.skip_lane:
                 # first trunk op whose backward touches a gradient the skip lane writes (d out56; d out112 comes later still)
                 inner = self.tape.pop()
