@@ -72,3 +72,10 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
+
+// Barrier that must also publish the LDS-DMA (buffer_load ... lds) tiles the block's waves have issued: every wave's own transfers have landed
+// (vmcnt(0)) before it arrives.  __syncthreads() alone is NOT a contract for that: hipcc (ROCm 7.2) adds the vmcnt(0) only when its waitcnt pass
+// knows of a pending LDS-DMA, and in round 5 it lost that knowledge across a loop back edge (conv_x6.hip: a barrier of the K loop was emitted
+// with lgkmcnt(0) alone and waves read tiles that had not landed).  The wait is written as inline asm, which the pass cannot drop.
+#define PC_SYNC_DMA() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
+

@@ -400,12 +400,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_glds_kernel(const ConvK p) {
     };
     if constexpr (ST == 2) {
         if (nchunks > 0) fetch(0);
-        __syncthreads();
+        PC_SYNC_DMA();
         for (int c = 0; c < nchunks; ++c) {
             const int buf = c & 1;
             if (!(VAR & 2) && c + 1 < nchunks) fetch(buf ^ 1);
             mma_chunk(buf, c);
-            __syncthreads();      // drains the LDS-DMA of chunk c+1 (vmcnt(0)) and fences the reads of chunk c
+            PC_SYNC_DMA();        // the LDS-DMA of chunk c+1 has landed (vmcnt(0), written out: common.h) and the reads of chunk c are fenced
         }
     } else {
         // ring: chunks c .. c+ST-2 in flight while chunk c is multiplied.  Each thread issues AR + BR DMA pieces per chunk, in order,
@@ -856,7 +856,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     ptab_fill(c_begin + 1);
     __syncthreads();
     gload(c_begin, 0);
-    __syncthreads();
+    PC_SYNC_DMA();
     const int ml = wm * (BM / 2) + (lane & 31), nl = wn * (BN / 2) + (lane & 31), kh = lane >> 5;
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (ABL >= 1 && ABL <= 3) ? 0 : ((c - c_begin) & 1);
@@ -921,7 +921,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (ABL < 3) __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+        if (ABL < 3) PC_SYNC_DMA();        // the LDS-DMA of chunk c+1 has landed and the reads of chunk c are fenced
     }
     if constexpr (X6 && HILO) {
 #pragma unroll
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     for (int j = 0; j < TN; ++j) { const int col = wn * (BN / WNW) + 32 * j; kwj[j] = col / CSB; csj[j] = col % CSB + (lane & 31); }
     const int ml = wm * (BM / WMW) + (lane & 31), kh = lane >> 5;
     bool live = gload(std::integral_constant<int, 0>{});
-    __syncthreads();
+    PC_SYNC_DMA();
     auto chunk = [&](auto slot, int c) {
         constexpr int buf = decltype(slot)::value;
         const bool next_live = c + 1 < c_end ? gload(std::integral_constant<int, buf ^ 1>{}) : false;
@@ -1102,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+        PC_SYNC_DMA();        // the LDS-DMA of chunk c+1 has landed and the reads of chunk c are fenced
         live = next_live;
     };
     for (int c = c_begin; c < c_end; c += 2) {
@@ -1244,7 +1244,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_x6_kernel(const Wg3K p) {
 #undef WG_MF
     };
     bool live = gload(std::integral_constant<int, 0>{});
-    __syncthreads();
+    PC_SYNC_DMA();
     auto chunk = [&](auto slot, int c) {
         constexpr int buf = decltype(slot)::value;
         const bool next_live = c + 1 < c_end ? gload(std::integral_constant<int, buf ^ 1>{}) : false;
@@ -1259,7 +1259,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_x6_kernel(const Wg3K p) {
                 mma_step(pa[s & 1], pb[s & 1]);
             }
         }
-        __syncthreads();      // drains the LDS-DMA of chunk c+1 and fences the reads of chunk c
+        PC_SYNC_DMA();        // the LDS-DMA of chunk c+1 has landed and the reads of chunk c are fenced
         live = next_live;
     };
     for (int c = c_begin; c < c_end; c += 2) {
@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
         }
     }
     gload(std::integral_constant<int, 0>{});
-    __syncthreads();
+    PC_SYNC_DMA();
     auto chunk = [&](auto slot, int c) {
         constexpr int buf = decltype(slot)::value;
         if (c + 1 < c_end) gload(std::integral_constant<int, buf ^ 1>{});
@@ -1408,7 +1408,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
 #pragma unroll
             for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf[j], acc[j], 0, 0, 0);
         }
-        __syncthreads();
+        PC_SYNC_DMA();
     };
     for (int c = c_begin; c < c_end; c += 2) {
         chunk(std::integral_constant<int, 0>{}, c);

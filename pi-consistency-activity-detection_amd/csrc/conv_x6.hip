@@ -13,7 +13,9 @@
 //     with one MFMA and its share of the side work per slot, pinned (sched_barrier binds only the machine scheduler: empty volatile asm on
 //     the inputs and outputs of a split unit keeps the IR passes from hoisting or sinking the pure ALU work);
 //   * LDS reads run one step ahead of the MFMAs, so the two-buffer ring is as deep as a three-buffer one: the barrier sits at the head of
-//     the odd phases (chunk c + 1 landed, every wave has read chunk c), behind it goes the DMA of chunk c + 2 into chunk c's buffer.
+//     the odd phases (chunk c + 1 landed, every wave has read chunk c), behind it goes the DMA of chunk c + 2 -- BOTH operands since round 5
+//     (the weight planes used to follow half a chunk later, which left them half a chunk to land: the waves of these kernels spent
+//     37 - 43 % of their cycles parked at that barrier) -- into chunk c's buffers.
 //   * TAIL SPLIT.  A launch of T tiles on S resident-block slots runs floor(T / S) full rounds and then a last round with T mod S blocks: the
 //     320-row spectral planes in 128 x 64 tiles are 1107 = 2 x 512 + 83 blocks of 234 K chunks each -- the chip is 16 % full for a third of the
 //     kernel.  With a workspace the last T mod S tiles (or all tiles of a launch that does not fill one round) are multiplied by `ksplit` blocks each,
@@ -183,7 +185,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
     const int c_lo = any_tap ? __builtin_ctz(bw) : 0, c_hi = any_tap ? 31 - __builtin_clz(bw) : -1;
     const int nb_ = b_hi - b_lo + 1, nc_ = c_hi - c_lo + 1;
     const int nchunks_tile = (a_hi - a_lo + 1) * nb_ * nc_ * (p.Ci / BK);
-    // the A stream and the B stream of a chunk are issued half a chunk apart: each walks the (tap, channel chunk) sequence on its own
+    // the A stream and the B stream each walk the (tap, channel chunk) sequence on their own (the prologue issues them chunk by chunk)
     struct Walk { int a, b, c, ci; };
     Walk wa = {a_lo, b_lo, c_lo, 0}, wb = wa;
     auto advance = [&](Walk& w) {
@@ -265,10 +267,12 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
         constexpr int s = PH & 1, buf = PH >> 1, cur = PH & 1;
         constexpr int s1 = s ^ 1, b1 = s ? (buf ^ 1) : buf;     // step / buffer of t + 1
         if constexpr (s == 1) {
-            __syncthreads();                                    // chunk (t + 1) / 2 has landed; every wave has read chunk (t - 1) / 2
-            if ((t + 3) / 2 < nchunks) fetchA(buf);
-        } else {
-            if (t >= 2 && (t + 2) / 2 < nchunks) fetchB(buf ^ 1);
+            // The wait is written out: with both fetches behind this barrier the only LDS-DMA in flight here comes from the PREVIOUS trip of the
+            // loop, and hipcc (ROCm 7.2) then emits the barrier of __syncthreads() with lgkmcnt(0) alone -- its loop-carried bookkeeping loses the
+            // pending LDS-DMA writes -- so a wave could read a tile that had not landed (caught by the tail-split test on a cold launch: 1 - 10 k
+            // wrong elements in 126 of 150 launches).  Inline asm is invisible to that pass (PC_SYNC_DMA, common.h).
+            PC_SYNC_DMA();                                      // chunk (t + 1) / 2 has landed; every wave has read chunk (t - 1) / 2
+            if ((t + 3) / 2 < nchunks) { fetchA(buf); fetchB(buf); }       // both operands of chunk (t + 3) / 2: a whole chunk ahead of their first read
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!wave_live) return;                                 // a wave whose 32 rows lie behind the group's last row only fetches and keeps the barriers
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void conv_x6_kernel(const ConvX6 p
     using P2 = std::integral_constant<int, 2>; using P3 = std::integral_constant<int, 3>;
     if (nchunks > 0) { fetchA(0); fetchB(0); }
     if (nchunks > 1) { fetchA(1); fetchB(1); }
-    __syncthreads();
+    PC_SYNC_DMA();
     if (nchunks > 0 && wave_live) {
         rdA(0, 0, 0); rdA(1, 0, 0);
 #pragma unroll

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         for (int j = 0; j < 8; ++j) glds16b<!(VAR & 2)>(dma_rsrc(ug + j * 256), uoff, ul + j * 256);
         advance(uq, uc8);                         // -> chunk 1
     }
-    __syncthreads();
+    PC_SYNC_DMA();
     if (nchunks > 0) {
         rsrc = Rs + rbase;
         vb = Vs + voff;
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         WINO_GROUP(12, a0, b0, a1, b1)  WINO_GROUP(13, a1, b1, a0, b0)  WINO_GROUP(14, a0, b0, a1, b1)  WINO_GROUP(15, a1, b1, a0, b0)
 #undef WINO_STEP
 #undef WINO_GROUP
-        __syncthreads();
+        PC_SYNC_DMA();
     }
 
     if (VAR & 32) stamp[2] = __builtin_amdgcn_s_memtime();
