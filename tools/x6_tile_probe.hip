@@ -545,15 +545,23 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tile_pipe2(const float* 
     };
     constexpr int NRD = 2 * TM + 3 * TN;                                 // LDS reads per step
     static_assert(NRD <= NM, "one read per slot");
+    unsigned long long w_vm = 0, w_bar = 0;
     auto phase = [&](auto ph, int t) {
         constexpr int PH = decltype(ph)::value;
         constexpr int s = PH & 1, buf = PH >> 1, cur = PH & 1;
         constexpr int s1 = s ^ 1, b1 = s ? (buf ^ 1) : buf;
         if constexpr (s == 1) {
-            if constexpr (!(ABL & 4)) __syncthreads();
-            if (!(ABL & 2) && (t + 3) / 2 < nchunks) fetchA((t + 3) / 2, buf);
+            if constexpr (ABL & 16) {          // where does a wave wait: for its own LDS-DMA (vmcnt) or for the other waves (barrier)?
+                const unsigned long long q0 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const unsigned long long q1 = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                const unsigned long long q2 = __builtin_amdgcn_s_memtime();
+                w_vm += q1 - q0; w_bar += q2 - q1;
+            } else if constexpr (!(ABL & 4)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+            if (!(ABL & 2) && (t + 3) / 2 < nchunks) { fetchA((t + 3) / 2, buf); if constexpr (ABL & 8) fetchB((t + 3) / 2, buf); }
         } else {
-            if (!(ABL & 2) && t >= 2 && (t + 2) / 2 < nchunks) fetchB((t + 2) / 2, buf ^ 1);
+            if constexpr (!(ABL & 8)) if (!(ABL & 2) && t >= 2 && (t + 2) / 2 < nchunks) fetchB((t + 2) / 2, buf ^ 1);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -594,6 +602,7 @@ __global__ __launch_bounds__(64 * WM * WN, 1) void gemm_tile_pipe2(const float* 
     }
     __syncthreads();
     if (STAMPS && tid == 0) { g_stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - st0; g_stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - rt0; }
+    if ((ABL & 16) && tid == 0) { g_stamps[2 * 65536 + 2 * blockIdx.x] = w_vm; g_stamps[2 * 65536 + 2 * blockIdx.x + 1] = w_bar; }
     float* T = (float*)smem;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -664,6 +673,15 @@ static void run(const char* tag, const float* dA, const float* dW, const uint16_
     printf("%-28s mode %d  %8.4f ms  %6.1f TFLOP/s   err/sum|ab|: kernel %.3e (max %.2e)  fp32 fmaf chain %.3e", tag, MODE, ms,
            2.0 * M * N * K / ms / 1e9, e_emul / scale, e_max, e_f32 / scale);
     if (STAMPS) printf("   clock %.2f GHz, %.0f cycles / chunk / block", clk, cyc_chunk);
+    if (STAMPS && (ABL & 16)) {
+        std::vector<unsigned long long> hw(2 * (size_t)grid);
+        unsigned long long* dptr; CK(hipMemcpyFromSymbol(&dptr, HIP_SYMBOL(g_stamps), sizeof(dptr)));
+        CK(hipMemcpy(hw.data(), dptr + 2 * 65536, hw.size() * 8, hipMemcpyDeviceToHost));
+        std::vector<double> a, b;
+        for (int q = 0; q < grid; ++q) { a.push_back((double)hw[2 * q] / (K / BK)); b.push_back((double)hw[2 * q + 1] / (K / BK)); }
+        std::sort(a.begin(), a.end()); std::sort(b.begin(), b.end());
+        printf("   wave 0 per chunk: %.0f cycles waiting for its LDS-DMA, %.0f at the barrier", a[a.size() / 2], b[b.size() / 2]);
+    }
     printf("\n");
 }
 
@@ -679,7 +697,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dA, hA.size() * 4 + 4096)); CK(hipMalloc(&dW, hW.size() * 4 + 4096)); CK(hipMalloc(&dC, hC.size() * 4)); CK(hipMalloc(&dWp, hW.size() * 6 + 4096));
     CK(hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemcpy(dW, hW.data(), hW.size() * 4, hipMemcpyHostToDevice));
-    { unsigned long long* ds; CK(hipMalloc(&ds, 16 * 65536 * 8)); CK(hipMemset(ds, 0, 16 * 65536 * 8)); CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ds, sizeof(ds))); }
+    { unsigned long long* ds; CK(hipMalloc(&ds, 16 * 65536 * 8)); CK(hipMemset(ds, 0, 16 * 65536 * 8));   /* [0, 2 x 65536): loop stamps; [2 x 65536, ..): wait stamps */ CK(hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), &ds, sizeof(ds))); }
     const int64_t nW = (int64_t)N * K;
     split_planes<<<(nW / 2 + 255) / 256, 256>>>(dW, dWp, nW);
     CK(hipDeviceSynchronize());
@@ -703,6 +721,12 @@ int main(int argc, char** argv) {
     run<5, 256, 128, 8, 1, 2>("  abl: no DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<5, 256, 128, 4, 2>("256x128 pipe, B planes, 4x2", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<5, 128, 64, 4, 1>("128x64 pipe, B planes, 4x1", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 128, 64, 4, 1, 8>("  early B fetch", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 128, 64, 4, 1, 16>("  wait stamps", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 128, 64, 4, 1, 24>("  early B + wait stamps", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 256, 128, 8, 1, 8>("256x128 early B fetch", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 256, 128, 8, 1, 24>("  early B + wait stamps", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
+    run<5, 256, 128, 8, 1, 16>("256x128 wait stamps", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<1, 128, 128, 2, 2, 1>("  abl: no split VALU", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<1, 128, 128, 2, 2, 2>("  abl: no DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
     run<1, 128, 128, 2, 2, 3>("  abl: no split, no DMA", dA, dW, dWp, dC, M, N, K, hC, hA, hW);
