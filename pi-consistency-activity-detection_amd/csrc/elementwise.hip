@@ -239,6 +239,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
 
 
 // ------------------------------------------------------------------------------ BatchNorm with the finalize folded into the apply kernel (round 5)
+// OPTIONAL (PICONS_BN_FUSED=1; off by default: measured no gain on the step, +0.1 ms of single-stream kernel time -- DESIGN.md 6, round 5).
 // The finalize kernels are a handful of blocks between two streaming kernels on the step's dependency chain: 6 - 8 us alone, 20 - 26 us each
 // in the four-lane step, where they wait for a free slot beside the other lanes' whole-CU GEMM blocks (17 + 15 such launches on lane 0 alone).
 // For layers with few partial rows (the 28 x 28 layers: <= 256 per batch group) every block of the apply kernel instead reduces the partial
@@ -731,12 +732,14 @@ extern "C" int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, con
     PC_CHECK_ARG(dy && z && stat && dz && ws && C % 4 == 0 && C <= 1024 && lddy % 4 == 0 && ldz % 4 == 0 && lddz % 4 == 0 &&
                  groups >= 1 && rows % groups == 0, "pc_bn_bwd: bad args (C=%d)", C);
     const int64_t rpg = rows / groups;
-    // layers of at most 16 384 rows per group (the 28 x 28 layers): 64 partial rows per group and the finalize folded into the apply kernel
-    // (bn_bwd_fin_apply_kernel) -- two launches instead of three on the dependency chain.  PICONS_BN_FUSED=0: the three-launch form everywhere.
-    static const int fuse = getenv("PICONS_BN_FUSED") ? atoi(getenv("PICONS_BN_FUSED")) : 1;
-    const bool fused = fuse && rpg <= 16384;
+    // PICONS_BN_FUSED=1 (read per call: a test switch): layers of at most 16 384 rows per group (the 28 x 28 layers) take at most 192 partial rows
+    // per group and the finalize folded into the apply kernel (bn_bwd_fin_apply_kernel) -- two launches instead of three on the dependency chain.
+    // Built for VERDICT r4 #4b and measured (profiles/r05_switch_ab.txt): the step does not move (19.25 against 19.25 ms) and the family's
+    // single-stream time goes UP (1.43 -> 1.54 ms: every block of the apply kernel repeats the reduction over the partial rows), so it is OFF.
+    const char* fenv = getenv("PICONS_BN_FUSED");
+    const bool fused = fenv && atoi(fenv) && rpg <= 16384;
     int64_t rpb = red_rows_per_block(rpg);
-    if (fused && (rpg + 63) / 64 > rpb) rpb = (rpg + 63) / 64;
+    if (fused && (rpg + 191) / 192 > rpb) rpb = (rpg + 191) / 192;
     const int npg = (int)((rpg + rpb - 1) / rpb);
     float* part = ws;
     float* coef = ws + (size_t)npg * groups * 2 * C;

@@ -364,9 +364,9 @@ class Plan:
 
     def bn_finalize_or_defer(self, nrows, cout, z, part, gamma, beta, pre, stat):
         """BatchNorm(train) statistics of a Unit3D from the conv's partial rows: either the finalize launch is emitted here (-> None), or --
-        few partial rows per batch group, PICONS_BN_FUSED != 0 -- the caller folds it into the apply launch (-> what that op needs)."""
+        few partial rows per batch group AND PICONS_BN_FUSED=1 (off by default: no gain measured) -- the caller folds it into the apply launch (-> what that op needs)."""
         npg = nrows // self.groups
-        if os.environ.get("PICONS_BN_FUSED", "1") != "0" and capi.lib().pc_bn_finalize_apply_ok(int(npg), int(cout)):
+        if os.environ.get("PICONS_BN_FUSED", "0") != "0" and capi.lib().pc_bn_finalize_apply_ok(int(npg), int(cout)):
             return dict(npg=npg, part=part)
         self.emit(capi.OP_BN_FINALIZE, i=[npg, self.groups, cout], l=[z.rows // self.groups], f=[spec.BN_EPS, spec.BN_MOMENTUM],
                   p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(npg, cout)])

@@ -420,10 +420,12 @@ def test_bn_finalize_folded_into_apply_matches_the_two_launches(rows_g, C, ld, n
     assert capi.lib().pc_bn_finalize_apply_ok(257, 64) == 0 and capi.lib().pc_bn_finalize_apply_ok(256, 64) == 1
 
 
+@pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("rows_g,C", [(6272, 512), (12544, 112), (20000, 64)])
-def test_bn_backward_both_forms_vs_autograd(rows_g, C):
-    """pc_bn_bwd at layer sizes on both sides of its switch (<= 16 384 rows per group: 64 partial rows and the finalize folded into the apply
-    kernel; above: three launches) against torch autograd of BatchNorm(train) + ReLU in float64, two batch groups."""
+def test_bn_backward_both_forms_vs_autograd(rows_g, C, fused, monkeypatch):
+    """pc_bn_bwd in its three-launch form (default) and with the finalize folded into the apply kernel (PICONS_BN_FUSED=1, read per call; layers of
+    <= 16 384 rows per group) against torch autograd of BatchNorm(train) + ReLU in float64, two batch groups."""
+    monkeypatch.setenv("PICONS_BN_FUSED", fused)
     g = torch.Generator().manual_seed(C)
     groups, rows = 2, 2 * rows_g
     z = torch.randn(rows, C, generator=g, dtype=torch.float64) * 2 + 0.3

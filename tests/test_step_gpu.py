@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from oracle import step as ostep
-from picons_amd import spec, step as pstep, synthetic
+from picons_amd import capi, spec, step as pstep, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -379,6 +379,33 @@ def test_stacked_1x1_units_match_separate_units(monkeypatch):
     assert (num / den) ** 0.5 < 2e-4
 
 
+def test_batchnorm_finalize_folded_into_apply_matches_default(monkeypatch):
+    """PICONS_BN_FUSED=1 (round 5; off by default -- no gain measured): the 28 x 28 layers' BatchNorm statistics are taken in the prologue of the
+    apply kernels, forward (PC_OP_BN_FIN_APPLY in the plan) and backward (pc_bn_bwd's two-launch form).  Against the default engine on the same
+    minibatch: same outputs, scalars, running statistics and gradients (the per-channel sums are taken in fp64 in another fixed order)."""
+    args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
+    lab, unl, perm, drops = synthetic.make_step_inputs(2, step=2, hw=112)
+    res = []
+    for fused in ("0", "1"):
+        monkeypatch.setenv("PICONS_BN_FUSED", fused)
+        eng = pstep.StepEngine(args, bs=2, hw=112)
+        nfa = sum(1 for op in eng.plan.lists["fwd"] if op[0] == capi.OP_BN_FIN_APPLY)
+        assert (nfa > 10) if fused == "1" else (nfa == 0)
+        eng.stage(lab, unl, perm, drops)
+        eng.forward_backward(1, 0.01)
+        torch.cuda.synchronize()
+        res.append((eng.read_scalars(), [t.clone() for t in eng.outputs()], eng.state_dict(), eng.G.clone()))
+    (s0, o0, sd0, g0), (s1, o1, sd1, g1) = res
+    for a, b in zip(o0, o1):
+        assert (a - b).abs().max().item() < 5e-5
+    for k in s0:
+        assert abs(s0[k] - s1[k]) <= 1e-5 * max(1.0, abs(s0[k])), (k, s0[k], s1[k])
+    for k in sd0:
+        if "running_" in k:
+            assert torch.allclose(sd0[k], sd1[k], rtol=1e-6, atol=1e-7), k
+    assert ((g0 - g1).norm() / g0.norm()).item() < 2e-4
+
+
 def test_step_is_deterministic_run_to_run():
     """SURVEY 5 determinism check (catches races in the reductions): the same step twice from the same state.  No forward
     kernel uses float atomics, so outputs, logits, loss scalars and BN running statistics must be BIT-identical, and so must
@@ -556,3 +583,8 @@ def test_training_trajectory_vs_reference(tmp_path, mode):
     for tag in ("adam_m_norms", "adam_v_norms"):
         assert v[tag]["worst_excess"] <= 0.0, (tag, v[tag])
         assert v[tag]["median_rel"] <= max(3 * v[tag]["ref32_median_rel"], 0.02), (tag, v[tag])
+        # the stem's three tensors are the closing Adam op's whole range, and their moments are well conditioned (measured: 0.4 - 8 % from the fp64
+        # run, the reference's fp32 run 1.4 - 8 %): a factor 1.25 (or 3x the reference's own log-distance) -- a doubled update doubles them
+        assert len(v[tag]["stem"]) == 3
+        for name, lg, lr32 in v[tag]["stem"]:
+            assert lg <= max(3 * lr32, float(np.log(1.25))), (tag, name, lg, lr32)
