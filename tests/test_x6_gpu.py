@@ -289,3 +289,31 @@ def test_x6_tail_split_stress_beside_a_memory_bound_stream(Ci, Co, k, thw, N, it
     assert differ == 0, "%d of %d tail-split launches differ from the first" % (differ, iters)
     nctr = n_ws % (128 * 64)                                       # the counters sit behind whole 128 x 64 slices
     assert nctr > 0 and torch.all(ws[-nctr:] == 0), "tile counters must be left at zero"
+
+
+@pytest.mark.parametrize("Ci,Co,k,thw,N", [(64, 128, (3, 3, 3), (4, 28, 28), 32), (832, 544, (1, 9, 1), (1, 28, 1), 80)])
+def test_x6_launches_from_an_idle_chip_are_bit_identical(Ci, Co, k, thw, N):
+    """Round 5 regression: with the weight planes fetched a whole chunk ahead, hipcc dropped the vmcnt(0) of the K loop's barrier and a wave could
+    read an LDS tile before its LDS-DMA had landed -- only when the transfers were slow, i.e. on a launch that starts from an idle chip with cold
+    caches (126 of 150 such launches had 1 - 10 k wrong elements; back-to-back launches never did).  The barrier now carries the wait as inline asm
+    (PC_SYNC_DMA, csrc/common.h); this test keeps the launch pattern that exposed it: host pause, ONE launch, compare."""
+    import time
+    g = torch.Generator().manual_seed(29)
+    x = torch.relu(torch.randn(N, Ci, *thw, generator=g))
+    w = torch.randn(Co, Ci, *k, generator=g) / np.sqrt(Ci * np.prod(k))
+    pads = [spec.same_pad(thw[i], k[i], 1) for i in range(3)]
+    d = desc.conv_fwd(N, thw, Ci, Ci, Co, Co, k, (1, 1, 1), [p[0] for p in pads], thw, act=capi.ACT_RELU, flags=capi.F_BIAS)
+    xg, wk = cl(x), w_oki(w)
+    wp = ops.split_planes(wk)
+    bias = torch.randn(Co, generator=g).to(DEV)
+    junk = torch.empty(96 << 20, device=DEV)                          # 384 MB: flushes L2 and the Infinity Cache between launches
+    first = ops.conv_fwd_x6(d, xg, wp, torch.empty(N, *thw, Co, device=DEV), bias=bias).clone()
+    out = torch.empty_like(first)
+    differ = 0
+    for it in range(40):
+        junk.fill_(float(it))
+        torch.cuda.synchronize()
+        time.sleep(0.002)
+        ops.conv_fwd_x6(d, xg, wp, out, bias=bias)
+        differ += int(not torch.equal(out, first))
+    assert differ == 0, "%d of 40 launches from an idle chip differ from the first" % differ
