@@ -148,10 +148,16 @@ typedef struct pc_wino_desc {
     int32_t ta, tc, tden;           /* tap kt of output frame t reads input frame (t*ta + kt + tc) / tden when that is an integer in
                                      * [0, Ti): forward with temporal stride s and front padding p: (s, -p, 1); input gradient of that
                                      * layer (weights mirrored): (1, p - (KT-1), s).  Stride 1, padding KT/2: (1, -(KT/2), 1) both ways */
+    int32_t m;                      /* output tile edge: 2 (or 0) = F(2x2, 3x3); 4 = F(4x4, 3x3): 4x fewer multiply-accumulates than the direct
+                                     * form for ~4x the rounding error of an fp32 accumulation chain; H, W multiples of 4, Ci % 4 == 0, and U
+                                     * from pc_wino4_weights (pc_wino4_u_floats floats) */
 } pc_wino_desc;
 int64_t pc_wino_u_floats(int O, int I, int KT);
 int pc_wino_weights(const float* w, int64_t sO, int64_t sT, int64_t sI, int O, int I, int KT, int flip, float* U, pc_stream s);
 int pc_wino_conv(const pc_wino_desc* d, const float* in, const float* U, const float* bias, float* out, float* bnpart, pc_stream s);
+/* transform-domain weights of the m = 4 form (same addressing of w as pc_wino_weights) */
+int64_t pc_wino4_u_floats(int O, int I, int KT);
+int pc_wino4_weights(const float* w, int64_t sO, int64_t sT, int64_t sI, int O, int I, int KT, int flip, float* U, pc_stream s);
 int pc_wino_bnpart_rows(const pc_wino_desc* d);
 /* host-only work accounting (see pc_conv_work): out[0] issued, out[1] executed multiply-accumulates, out[2] blocks */
 int pc_wino_work(const pc_wino_desc* d, double* out);
@@ -499,8 +505,8 @@ enum {
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued so far on lane i[1] (0 by default) */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */
     PC_OP_WGRAD_MULTI,              /* p[0] = HOST pointer to pc_wgrad_job[i[0]] (kept alive by the owner of the list): pc_conv_wgrad_multi */
-    PC_OP_WINO_CONV,                /* i[0..11] = pc_wino_desc; p = in, U, bias, out, bnpart */
-    PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip; l = sO, sT, sI; p = w, U */
+    PC_OP_WINO_CONV,                /* i[0..15] = pc_wino_desc; p = in, U, bias, out, bnpart */
+    PC_OP_WINO_WEIGHTS,             /* i = O, I, KT, flip, m (4: pc_wino4_weights); l = sO, sT, sI; p = w, U */
     PC_OP_CONV_X6,                  /* i = pc_conv_desc (flags with PC_F_X6); l[0] = plane stride, l[1] = workspace floats; p = in, wplanes, bias, cscale, out, bnpart, ws (0: none) */
     PC_OP_SPLIT_PLANES,             /* l = n, plane stride; p = src, planes */
     PC_OP_SPLIT_PLANES_MULTI,       /* p[0] = HOST pointer to pc_split_job[i[0]] (kept alive by the owner of the list) */

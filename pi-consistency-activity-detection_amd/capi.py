@@ -36,7 +36,7 @@ AXIS_FIELDS = ["R", "I", "O", "C", "in_split", "out_split", "act", "act_c0", "ac
 
 
 class WinoDesc(C.Structure):
-    _fields_ = [(n, i32) for n in ("N", "T", "H", "W", "Ci", "ldi", "Co", "ldo", "KT", "act", "flags", "Ti", "ta", "tc", "tden")]
+    _fields_ = [(n, i32) for n in ("N", "T", "H", "W", "Ci", "ldi", "Co", "ldo", "KT", "act", "flags", "Ti", "ta", "tc", "tden", "m")]
 
 
 class AxisDesc(C.Structure):
@@ -96,6 +96,8 @@ _SIGS = {
     "pc_wino_u_floats": (i64, [i32, i32, i32]),
     "pc_wino_weights": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "pc_wino_conv": (i32, [C.POINTER(WinoDesc), vp, vp, vp, vp, vp, vp]),
+    "pc_wino4_u_floats": (i64, [i32, i32, i32]),
+    "pc_wino4_weights": (i32, [vp, i64, i64, i64, i32, i32, i32, i32, vp, vp]),
     "pc_wino_bnpart_rows": (i32, [C.POINTER(WinoDesc)]),
     "pc_wino_work": (i32, [C.POINTER(WinoDesc), C.POINTER(C.c_double)]),
     "pc_bn_finalize": (i32, [vp, i32, i32, i32, i64, vp, vp, f32, f32, vp, vp, vp, vp]),

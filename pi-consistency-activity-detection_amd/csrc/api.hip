@@ -155,6 +155,7 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_wino_conv(&d, P(const float*, 0), P(const float*, 1), P(const float*, 2), P(float*, 3), P(float*, 4), s);
         }
         case PC_OP_WINO_WEIGHTS:
+            if (op.i[4] == 4) return pc_wino4_weights(P(const float*, 0), op.l[0], op.l[1], op.l[2], op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
             return pc_wino_weights(P(const float*, 0), op.l[0], op.l[1], op.l[2], op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         default:
             pc_set_error("pc_run_ops: unknown op kind %d", op.kind);

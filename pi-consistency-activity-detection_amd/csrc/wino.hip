@@ -444,6 +444,12 @@ int fill(const pc_wino_desc* d, WinoK& k) {
 
 }  // namespace
 
+// pc_wino_desc.m == 4: the F(4x4, 3x3) kernel (wino4.hip)
+int pc_wino4_bnpart_rows_impl(const pc_wino_desc* d);
+int pc_wino4_work_impl(const pc_wino_desc* d, double* out);
+int pc_wino4_conv_impl(const pc_wino_desc* d, const float* in, const float* U, const float* bias, float* out, float* bnpart, pc_stream s);
+#define WINO_M_CHECK(d) PC_CHECK_ARG(!(d) || (d)->m == 0 || (d)->m == 2 || (d)->m == 4, "pc_wino: m must be 2 (or 0) or 4, got %d", (d)->m)
+
 extern "C" int64_t pc_wino_u_floats(int O, int I, int KT) {
     if (O < 1 || I < 8 || I % 8 || (KT != 1 && KT != 3)) return -1;
     return (int64_t)KT * cdiv(O, WC) * (I / WK) * PLANE;
@@ -460,6 +466,8 @@ extern "C" int pc_wino_weights(const float* w, int64_t sO, int64_t sT, int64_t s
 }
 
 extern "C" int pc_wino_bnpart_rows(const pc_wino_desc* d) {
+    if (d && d->m == 4) return pc_wino4_bnpart_rows_impl(d);
+    if (d && d->m != 0 && d->m != 2) return -1;
     WinoK k;
     if (fill(d, k) != PC_OK) return -1;
     return k.N * k.T * k.nbh * k.nbw * 2;
@@ -467,6 +475,8 @@ extern "C" int pc_wino_bnpart_rows(const pc_wino_desc* d) {
 
 // Host-only: multiply-accumulates the launch issues to the matrix cores / performs on real outputs (see pc_conv_work)
 extern "C" int pc_wino_work(const pc_wino_desc* d, double* out) {
+    WINO_M_CHECK(d);
+    if (d && d->m == 4) return pc_wino4_work_impl(d, out);
     WinoK k;
     const int rc = fill(d, k);
     if (rc != PC_OK) return rc;
@@ -482,6 +492,8 @@ extern "C" int pc_wino_work(const pc_wino_desc* d, double* out) {
 }
 
 extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float* U, const float* bias, float* out, float* bnpart, pc_stream s) {
+    WINO_M_CHECK(d);
+    if (d && d->m == 4) return pc_wino4_conv_impl(d, in, U, bias, out, bnpart, s);
     WinoK k;
     const int rc = fill(d, k);
     if (rc != PC_OK) return rc;

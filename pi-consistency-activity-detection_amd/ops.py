@@ -72,21 +72,24 @@ def conv_fwd_x6(d, x, wplanes, out, bias=None, cscale=None, bnpart=None, ws=None
     return out
 
 
-def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0, Ti=None, ta=1, tc=None, tden=1):
-    """pc_wino_desc; defaults = temporal stride 1 with padding KT // 2 (see include/picons.h for (ta, tc, tden))."""
+def wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT=3, act=0, flags=0, Ti=None, ta=1, tc=None, tden=1, m=2):
+    """pc_wino_desc; defaults = temporal stride 1 with padding KT // 2 (see include/picons.h for (ta, tc, tden)); m = 2: F(2x2, 3x3),
+    4: F(4x4, 3x3) (U from wino_weights(..., m=4))."""
     st = capi.WinoDesc()
+    st.m = m
     st.N, st.T, st.H, st.W, st.Ci, st.ldi, st.Co, st.ldo, st.KT, st.act, st.flags = N, T, H, W, Ci, ldi, Co, ldo, KT, act, flags
     st.Ti, st.ta, st.tc, st.tden = (T if Ti is None else Ti), ta, (-(KT // 2) if tc is None else tc), tden
     return st
 
 
-def wino_weights(w, O, I, KT=3, flip=False, strides=None, out=None):
+def wino_weights(w, O, I, KT=3, flip=False, strides=None, out=None, m=2):
     """Transform-domain weights of pc_wino_conv from a weight tensor addressed as w[o*sO + tap*sT + i*sI] (default: contiguous
     OIDHW, i.e. (O, I, KT, 3, 3))."""
     sO, sT, sI = strides if strides is not None else (I * KT * 9, 1, KT * 9)
-    n = capi.lib().pc_wino_u_floats(O, I, KT)
+    fam = "pc_wino4" if m == 4 else "pc_wino"
+    n = getattr(capi.lib(), fam + "_u_floats")(O, I, KT)
     U = out if out is not None else torch.empty(n, device=w.device, dtype=torch.float32)
-    capi.call("pc_wino_weights", ptr(w), int(sO), int(sT), int(sI), O, I, KT, int(flip), ptr(U), stream())
+    capi.call(fam + "_weights", ptr(w), int(sO), int(sT), int(sI), O, I, KT, int(flip), ptr(U), stream())
     return U
 
 

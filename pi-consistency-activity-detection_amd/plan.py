@@ -394,11 +394,23 @@ class Plan:
         return (T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(os.environ.get("PICONS_WINO_CMIN", "32")) and cout >= 64
                 and cout % 8 == 0 and x.ld % 4 == 0)
 
-    def wino_weights(self, wname, O, I, need_tr):
+    @staticmethod
+    def wino_m(x):
+        """Output tile edge of a Winograd layer: 4 -- F(4x4, 3x3), csrc/wino4.hip: 1.78x fewer MFMAs than F(2x2, 3x3), measured 1.27 - 1.44x
+        faster on the 224 x 224 and 56 x 56 layers (tools/bench_wino4.py) -- where H, W are multiples of 4 and a frame has at least
+        PICONS_WINO4_MIN_TILES (196 = 56 x 56) tiles; the 28 x 28 layers have too few whole-CU blocks for it (0.77x) and stay on
+        F(2x2, 3x3).  PICONS_WINO4=0: F(2x2, 3x3) everywhere."""
+        _T, H, W = x.thw
+        if os.environ.get("PICONS_WINO4", "1") == "0" or H % 4 or W % 4:
+            return 2
+        return 4 if (H // 4) * (W // 4) >= int(os.environ.get("PICONS_WINO4_MIN_TILES", "196")) else 2
+
+    def wino_weights(self, wname, O, I, need_tr, m=2):
         """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
         gradient, from its transpose with mirrored taps: strides + flip, no intermediate layout)."""
-        nU = capi.lib().pc_wino_u_floats(O, I, 3)
-        if nU <= 0 or (need_tr and capi.lib().pc_wino_u_floats(I, O, 3) <= 0):
+        u_floats = capi.lib().pc_wino4_u_floats if m == 4 else capi.lib().pc_wino_u_floats
+        nU = u_floats(O, I, 3)
+        if nU <= 0 or (need_tr and u_floats(I, O, 3) <= 0):
             raise ValueError("Winograd form of %s: %d -> %d channels is not a shape the kernel takes" % (wname, I, O))
         u = dict(fwd=self.alloc(nU))
         src = self.P(wname)
@@ -406,26 +418,28 @@ class Plan:
         if self.late_prep and wname.startswith("conv1.Conv3d_2c_3x3"):
             self.prep_target = "prep"          # needed before the late-prep list has run
         pl = self.next_prep_lane()
-        self.emit(capi.OP_WINO_WEIGHTS, i=[O, I, 3, 0], l=[I * 27, 1, 27], p=[src, u["fwd"]], lst=self.prep_target, lane=pl)
+        self.emit(capi.OP_WINO_WEIGHTS, i=[O, I, 3, 0, m], l=[I * 27, 1, 27], p=[src, u["fwd"]], lst=self.prep_target, lane=pl)
         if need_tr:
-            u["tr"] = self.alloc(capi.lib().pc_wino_u_floats(I, O, 3))
-            self.emit(capi.OP_WINO_WEIGHTS, i=[I, O, 3, 1], l=[27, 1, I * 27], p=[src, u["tr"]], lst=self.prep_target, lane=pl)
+            u["tr"] = self.alloc(u_floats(I, O, 3))
+            self.emit(capi.OP_WINO_WEIGHTS, i=[I, O, 3, 1, m], l=[27, 1, I * 27], p=[src, u["tr"]], lst=self.prep_target, lane=pl)
         self.prep_target = saved_target
         if wname in self.kw:               # finalize() lays a skip conv's weights out on the skip lane, in front of the conv
             self.kw[wname]["wino_fwd"], self.kw[wname]["wino_tr"] = u["fwd"], u.get("tr")
+        u["m"] = m
         return u
 
     @staticmethod
-    def _wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act=0, flags=0):
+    def _wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act=0, flags=0, m=2):
         d = capi.WinoDesc()
+        d.m = m
         d.N, d.T, d.H, d.W, d.Ci, d.ldi, d.Co, d.ldo, d.KT, d.act, d.flags = N, othw[0], othw[1], othw[2], Ci, ldi, Co, ldo, 3, act, flags
         d.Ti, d.ta, d.tc, d.tden = Ti, tmap[0], tmap[1], tmap[2]
         return d
 
-    def wino_op(self, x_ref, N, othw, Ti, Ci, ldi, Co, ldo, tmap, U, out_ref, bias=None, bnpart=None, act=0, flags=0):
+    def wino_op(self, x_ref, N, othw, Ti, Ci, ldi, Co, ldo, tmap, U, out_ref, bias=None, bnpart=None, act=0, flags=0, m=2):
         """One pc_wino_conv launch: output frames / positions othw, Ti input frames, tmap = (ta, tc, tden) of pc_wino_desc."""
         import ctypes as C
-        d = self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act, flags)
+        d = self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act, flags, m)
         out = (C.c_double * 3)()
         capi.check(capi.lib().pc_wino_work(C.byref(d), out))
         for key, v in (("wino_mfma", out[0]), ("wino_executed", out[1])):
@@ -434,9 +448,9 @@ class Plan:
         self.op_work[id(il)] = dict(issued=out[0], executed=out[1], valid=out[1], blocks=int(out[2]), wino=True)
         return d
 
-    def wino_bnpart_rows(self, N, othw, Ti, Ci, ldi, Co, ldo, tmap):
+    def wino_bnpart_rows(self, N, othw, Ti, Ci, ldi, Co, ldo, tmap, m=2):
         import ctypes as C
-        return capi.lib().pc_wino_bnpart_rows(C.byref(self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap)))
+        return capi.lib().pc_wino_bnpart_rows(C.byref(self._wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, m=m)))
 
     def wino_flops_executed(self):
         """Per list: FLOPs of the Winograd launches -- `mfma` issued to the matrix cores (whole 64 x 64 blocks), `executed` on real tiles
@@ -579,20 +593,21 @@ class Plan:
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
-        wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training) if wino else None
+        wm = self.wino_m(x) if wino else 2
+        wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training, wm) if wino else None
         fin = None
         tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
         tmap_b = (1, pf[0] - 2, stride[0])                 # input gradient (mirrored taps): frame (t + pad_front - 2 + kt) / s
         if self.training and wino:
-            nrows = self.wino_bnpart_rows(x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f)
+            nrows = self.wino_bnpart_rows(x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wm)
             part = self.alloc(nrows * 2 * cout)
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
-            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART)
+            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, bnpart=part, flags=capi.F_BNPART, m=wm)
             fin = self.bn_finalize_or_defer(nrows, cout, z, part, gamma, beta, pre, stat)
             g_apply = self.groups
         elif wino:
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
-            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref)
+            self.wino_op(x.ref, x.N, othw, x.thw[0], Ci, x.ld, cout, z.ld, tmap_f, wu["fwd"], z.ref, m=wm)
             self.emit(capi.OP_BN_EVAL_STAT, i=[cout], f=[spec.BN_EPS],
                       p=[gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat])
             g_apply = 1
@@ -645,7 +660,7 @@ class Plan:
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd, wino)
                 if wino:      # the input gradient of a stride-1 same-padded conv is the same correlation with mirrored, transposed weights
-                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
+                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0, m=wm)
                 else:
                     for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
                         self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)
@@ -759,10 +774,11 @@ class Plan:
         w = self.prep_conv_weight([name + ".weight"], [cout], x.C, k, need_dx, layouts=not wino)
         if wino:
             othw = tuple(x.thw)
-            wu = self.wino_weights(name + ".weight", cout, x.C, need_dx and self.training)
+            wm = self.wino_m(x)
+            wu = self.wino_weights(name + ".weight", cout, x.C, need_dx and self.training, wm)
             F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
             self.alg_flops_wino[self.cur] = self.alg_flops_wino.get(self.cur, 0) + F_fwd
-            self.wino_op(x.ref, x.N, othw, x.thw[0], x.C, x.ld, cout, out.ld, (1, -1, 1), wu["fwd"], out.ref, bias=self.P(name + ".bias"), act=act, flags=capi.F_BIAS)
+            self.wino_op(x.ref, x.N, othw, x.thw[0], x.C, x.ld, cout, out.ld, (1, -1, 1), wu["fwd"], out.ref, bias=self.P(name + ".bias"), act=act, flags=capi.F_BIAS, m=wm)
         else:
             othw = self.conv_bias_act(name + ".weight", x, cout, k, pad, act, out, bias_ref=self.P(name + ".bias"))
             F_fwd = _conv_flops(D.conv_fwd(x.N, x.thw, x.C, x.ld, cout, out.ld, k, (1, 1, 1), pad, othw))
@@ -780,7 +796,7 @@ class Plan:
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd, wino)
                 if wino:
-                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, x.C, dx.ld, (1, -1, 1), wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0)
+                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, x.C, dx.ld, (1, -1, 1), wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0, m=wm)
                 else:
                     for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, x.C, dx.ld, k, (1, 1, 1), pad, flags=capi.F_ACCUM if acc else 0, ldw=cout):
                         self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)

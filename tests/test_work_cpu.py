@@ -102,7 +102,18 @@ def test_winograd_layers_in_the_plan_and_their_accounting(monkeypatch):
     fz = p.wino_flops_executed()
     ex = sum(v["executed"] for v in fz.values()); mf = sum(v["mfma"] for v in fz.values())
     ref = sum(p.flops_reference_counted_wino().values())
-    assert 0 < ex <= mf and 1.9 < ref / ex < 4.0            # 2.25x fewer than the direct form (more where temporal taps fall outside: 6.75x at one frame)
+    # 2.25x fewer than the direct form with F(2x2, 3x3) (more where temporal taps fall outside: 6.75x at one frame), 4x with F(4x4, 3x3), which
+    # the 112 x 112 and 56 x 56 layers run in (Plan.wino_m)
+    assert 0 < ex <= mf and 3.0 < ref / ex < 6.0
+    m_of = {tuple(op[1][:4]): op[1][15] for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_CONV}
+    assert {hw[2] for hw, m in m_of.items() if m == 4} == {112, 56} and {hw[2] for hw, m in m_of.items() if m != 4} == {28}
+    assert sorted(op[1][4] for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_WEIGHTS).count(4) == 6
+    monkeypatch.setenv("PICONS_WINO4", "0")
+    q4 = build()
+    fz2 = q4.wino_flops_executed()
+    assert 1.9 < ref / sum(v["executed"] for v in fz2.values()) < 4.0
+    assert all(op[1][15] in (0, 2) for n in q4.lists for op in q4.lists[n] if op[0] == capi.OP_WINO_CONV)
+    monkeypatch.delenv("PICONS_WINO4")
     monkeypatch.setenv("PICONS_WINO_T1", "0")
     assert count(build(), capi.OP_WINO_CONV) == 12
     monkeypatch.delenv("PICONS_WINO_T1")
@@ -113,6 +124,15 @@ def test_winograd_layers_in_the_plan_and_their_accounting(monkeypatch):
     assert out[2] == 3136 and out[0] == out[1] == 16 * 10 * 16.0 * 56 * 56 * 64 * 64
     assert capi.lib().pc_wino_u_floats(64, 64, 3) == 3 * 1 * 8 * 8192 and capi.lib().pc_wino_u_floats(96, 64, 3) == 3 * 2 * 8 * 8192
     assert capi.lib().pc_wino_bnpart_rows(C.byref(d)) == 16 * 4 * 49 * 2
+    # the F(4x4, 3x3) form of the same layer: 28 blocks of 28 (of 32) tiles x 64 channels per frame, 36 transform positions
+    d4 = ops.wino_desc(16, 4, 112, 112, 64, 64, 64, 64, 3, m=4)
+    capi.check(capi.lib().pc_wino_work(C.byref(d4), out))
+    assert out[2] == 16 * 4 * 28 and out[1] == 16 * 10 * 36.0 * 28 * 28 * 64 * 64 and out[0] == out[1] * 32 / 28
+    assert capi.lib().pc_wino4_u_floats(64, 64, 3) == 3 * 1 * 16 * 9216 and capi.lib().pc_wino_bnpart_rows(C.byref(d4)) == 16 * 4 * 28 * 2
+    bad4 = ops.wino_desc(2, 2, 14, 16, 64, 64, 64, 64, 3, m=4)
+    assert capi.lib().pc_wino_work(C.byref(bad4), out) != 0 and b"multiples of 4" in capi.lib().pc_last_error()
+    bad4.m = 3
+    assert capi.lib().pc_wino_work(C.byref(bad4), out) != 0 and b"m must be" in capi.lib().pc_last_error()
     # odd sizes and thin channel counts are refused by the host checks (no GPU call)
     bad = ops.wino_desc(2, 2, 15, 16, 64, 64, 64, 64, 3)
     assert capi.lib().pc_wino_work(C.byref(bad), out) != 0 and b"even" in capi.lib().pc_last_error()

@@ -95,8 +95,10 @@ res["adam_step_ref"] = [int(S["adam_step"].min()), int(S["adam_step"].max())]
 norms = {n: float(sd[n].double().norm()) for n in names}
 # every parameter tensor's norm after the last step: distance from the fp64 run beyond 3x the reference's own fp32 distance, relative to max(norm, 1)
 # (biases start at zero: after three steps their norm IS the handful of +-lr moves, sign noise included)
-res["param_norm_excess"] = max((abs(norms[n] - float(r64)) - 3 * abs(float(r32) - float(r64))) / max(float(r64), 1.0)
-                               for n, r32, r64 in zip(names, S["param_norms"], S["f64::param_norms"]))
+excess = sorted(((abs(norms[n] - float(r64)) - 3 * abs(float(r32) - float(r64))) / max(float(r64), 1.0), n, abs(norms[n] - float(r64)), abs(float(r32) - float(r64)), float(r64))
+                for n, r32, r64 in zip(names, S["param_norms"], S["f64::param_norms"]))[::-1]
+res["param_norm_excess"] = excess[0][0]
+res["param_norm_excess_top"] = [dict(excess=e, name=n, d_vs_f64=a, ref32_d_vs_f64=b, norm=c) for e, n, a, b, c in excess[:6]]
 res["step_count"] = eng.step_count
 json.dump(res, open(out_path, "w"), indent=1)
 if red is not None:

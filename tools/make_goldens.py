@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Generate tests/golden/*.npz by running THE REFERENCE ITSELF on CPU (authoring container only).
 
-    python tools/make_goldens.py [--only stages|masks|steps|traj]
+    python tools/make_goldens.py [--only stages|masks|steps|steps_f64|traj] [--steps tag,tag]
 
 Fixtures are data only (inputs/expected outputs); nothing of the reference's source travels.
 Each file records torch version and thread count (results differ across thread counts,
@@ -172,7 +172,7 @@ def gen_masks():
 
 
 # ----------------------------------------------------------------------------- full steps
-def gen_steps(only_tags=None):
+def gen_steps(only_tags=None, add_f64=False):
     import importlib
     from models.capsules_ucf101 import CapsNet, ConvCaps
     import torch.nn as nn
@@ -269,6 +269,19 @@ def gen_steps(only_tags=None):
 
     for case in cases:
         t0 = time.time()
+        if add_f64:
+            # `--only steps_f64 --steps tags` (round 5): an fp64 run of the reference added to an EXISTING fixture, whose fp32 contents stay as
+            # they are -- the anchor the element-wise gradient bars of the bs = 2 fixtures are judged against
+            old = np.load(os.path.join(OUT, case[0] + ".npz"))
+            d = {k: old[k] for k in old.files if not k.startswith("_")}
+            d64 = run_reference(case, True)
+            ref_import.install_shims(double=False)
+            for k, v in d64.items():
+                if k.startswith(("grad::", "gsample::")) or k in ("predicted_action", "total", "loc", "cls", "cons", "grad_norms"):
+                    d["f64::" + k] = v
+            d["seconds_f64"] = np.array(time.time() - t0)
+            save(case[0] + ".npz", d)
+            continue
         d = run_reference(case, False)
         if case[8]:
             d64 = run_reference(case, True)
@@ -425,6 +438,8 @@ if __name__ == "__main__":
         gen_masks()
     if a.only in (None, "steps"):
         gen_steps(a.steps.split(",") if a.steps else None)
+    if a.only == "steps_f64":
+        gen_steps(a.steps.split(","), add_f64=True)
     if a.only == "traj_spread":
         gen_trajectory(spread_only=True)
     if a.only == "traj_adam":

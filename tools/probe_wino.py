@@ -11,6 +11,10 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 SHAPES = [("conv112 64->64 @4x112x112", (4, 112, 112), 64, 64), ("192->64 @2x56x56", (2, 56, 56), 192, 64), ("64->192 @2x56x56", (2, 56, 56), 64, 192)]
+M = int(os.environ.get("PROBE_M", "2"))             # 4: csrc/wino4.hip (F(4x4, 3x3)) on the shapes it takes
+if M == 4:
+    SHAPES = [("64->64 @4x224x224 (N=4)", (4, 224, 224), 64, 64), ("192->64 @2x56x56", (2, 56, 56), 192, 64), ("64->192 @2x56x56", (2, 56, 56), 64, 192),
+              ("96->128 @2x28x28", (2, 28, 28), 96, 128), ("128->192 @2x28x28", (2, 28, 28), 128, 192)]
 NAMES = {0: "product", 1: "no patch loads", 2: "no U DMA", 3: "no loads, no DMA", 4: "no transform stores", 7: "MFMA + LDS reads only", 8: "no output stores",
          15: "MFMA loop + inverse only", 32: "stamps"}
 
@@ -20,13 +24,14 @@ def child(var):
     import torch
     import picons_amd  # noqa
     from picons_amd import ops
-    N, R = 16, 10
+    R = 10
     for name, thw, Ci, Co in SHAPES:
+        N = 4 if thw[1] == 224 else 16
         x = torch.randn(N, *thw, Ci, device="cuda").clamp_min(0)
         w = torch.randn(Co, Ci, 3, 3, 3, device="cuda") * (1.0 / np.sqrt(27 * Ci))
         out = torch.empty(N, *thw, Co, device="cuda")
-        U = ops.wino_weights(w, Co, Ci, 3)
-        wd = ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3)
+        U = ops.wino_weights(w, Co, Ci, 3, m=M)
+        wd = ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3, m=M)
         dbg = torch.zeros(1 << 16, dtype=torch.int64, device="cuda")
         fn = lambda: ops.wino_conv(wd, x, U, out, bnpart=dbg)
         for _ in range(2):
@@ -51,5 +56,5 @@ if __name__ == "__main__":
     if len(sys.argv) > 1:
         child(int(sys.argv[1]))
     else:
-        for v in (0, 1, 2, 3, 4, 7, 8, 15, 32):
+        for v in [int(q) for q in os.environ.get("PROBE_VARS", "0,1,2,3,4,7,8,15,32").split(",")]:
             subprocess.run([sys.executable, os.path.abspath(__file__), str(v)], env=dict(os.environ, PICONS_WINO_VARIANT=str(v)))
