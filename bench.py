@@ -531,7 +531,8 @@ def main():
             try:
                 tj = json.load(open(tp))
                 traffic_of = {"x6": tj.get("conv_x6_hbm_bytes_per_launch"), "f32": tj.get("conv_gemm_hbm_bytes_per_launch"),
-                              "wino": next((v["hbm_bytes_per_launch"] for k, v in tj.get("kernels", {}).items() if "wino_conv_kernel" in k), None)}
+                              "wino": (lambda ws: (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ws) / max(sum(v["launches"] for v in ws), 1)) if ws else None)(
+                                  [v for k, v in tj.get("kernels", {}).items() if "wino_conv_kernel" in k or "wino4_conv_kernel" in k])}
                 traffic_src = "profiles/%s_traffic.json (offline rocprofv3 --pmc passes, not this run)" % tag
             except Exception:
                 traffic_of = {}
@@ -572,7 +573,7 @@ def main():
                             legs.get("main"), PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic, "traffic_source": traffic_src})
     if main_kind is not None:
         fzd = sum(pl.flops_reference_counted_wino()[n] for n in lists)
-        roof_wino = roof("wino_conv_kernel (Winograd F(2x2,3x3) conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
+        roof_wino = roof("wino4_conv_kernel + wino_conv_kernel (Winograd F(4x4,3x3) on the 112x112 / 56x56 layers, F(2x2,3x3) on the 28x28 ones: conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
                          legs.get("wino"), PEAK_FP32_MFMA_TFLOPS,
                          {"flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)",
                           "traffic": traffic_of.get("wino"), "traffic_source": traffic_src})

@@ -123,13 +123,13 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, long long sO, 
 // R runs two chunks ahead, U one; one barrier per chunk.  The two roles are two copies of the K loop (a branch inside the loop would split it
 // into blocks and degrade every s_waitcnt); the barrier counts arrivals, not program counters.
 // VAR (PICONS_DIAG builds; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no U DMA, 4 = no transform stores, 8 = no output stores,
-// 32 = s_memtime stamps of prologue / K loop / epilogue per block into bnpart (4 x u64 per block).
+// 32 = s_memtime stamps of prologue / K loop / epilogue per block into bnpart (4 x u64 per block), 64 = the product kernel with stamps around
+// the epilogue's three phases as well (8 x u64 per block: prologue, loop, row/column stage + send, finalise, stores, chunks).
 template <int VAR>
 __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Rs = smem;                        // [2][RPLANE]
     float* Vs = smem + 2 * RPLANE;           // [2][VPLANE]
-    float* Us = smem + 2 * RPLANE + 2 * VPLANE;      // [2][UPLANE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int nh = wave >> 1, wn = wave & 1;
@@ -142,11 +142,11 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     const int PW = 4 * p.BTW + 2, PH = 4 * p.BTH + 2;
     const int h0 = 4 * bh * p.BTH - 1, w0 = 4 * bw * p.BTW - 1;          // image position of patch position (0, 0)
 
-    // raw-patch DMA role (waves 0-2): piece i of this wave is piece wave + 3 i of the image; lane -> slot q = 64 piece + lane
-    unsigned roff[4];
+    // raw-patch DMA role (wave 3): all RPIECES pieces of the image; lane -> slot q = 64 piece + lane
+    unsigned roff[RPIECES];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = ((wave % 3) + 3 * i) * 64 + lane;
+    for (int i = 0; i < RPIECES; ++i) {
+        const int q = i * 64 + lane;
         const int pr = q / p.rpitch, rem = q - pr * p.rpitch;
         const int cm = rem / p.rq, idx = rem - cm * p.rq;
         const int pc = 4 * idx + cm;
@@ -154,7 +154,9 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
         const bool ok = pr < PH && cm < 4 && pc < PW && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         roff[i] = ok ? (unsigned)(((h * p.W + w) * p.ldi) * 4) : DMA_OOB;
     }
-    const unsigned uoff = lane * 16;   // U pieces are contiguous images
+    // weight fragments: straight from global memory (L2) into registers -- lane (k half, channel) of pair pp reads 16 bytes at
+    // ((pp' * 2 + k half) * 64 + channel) * 16, pp' = 9 nh + pp: the layout the MFMA wants, so U never passes through LDS
+    const unsigned uoff = (unsigned)(((nh * 18 + (lane >> 5)) * XC + wn * 32 + (lane & 31)) * 16);
 
     // transform role (waves 0-2): thread = (tile lane % 32, B^T row xi); waves 0 / 1 / 2 hold xi = (1, 2) / (3, 4) / (0, 5)
     const int ttile = lane & 31;
@@ -215,14 +217,18 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
 
     const float* rnext = nullptr;
     const float* ug = nullptr;
-    float* ul = nullptr;
     const float* rsrc = nullptr;
     float* vb = nullptr;
     f32x4 dA[4], dB[4], Tc[6], tq, eA, eB, eC, eD, w0v, w1v;
-    auto issue_r = [&](const float* base, int rb) {           // raw patch -> R[rb] (prologue; waves 0-2)
+    f32x4 bq0[9], bq1[9];                                       // weight fragments of the chunk in flight / of the next one
+    auto issue_r = [&](const float* base, int rb) {           // raw patch -> R[rb] (prologue; wave 3)
         const dma_rsrc_t rs = dma_rsrc(base);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) glds16b<!(VAR & 1)>(rs, roff[i], Rs + rb * RPLANE + ((wave % 3) + 3 * i) * 256);
+        for (int i = 0; i < RPIECES; ++i) glds16b<!(VAR & 1)>(rs, roff[i], Rs + rb * RPLANE + i * 256);
+    };
+    auto load_b = [&](const float* base, int pp) -> f32x4 {
+        if (VAR & 2) return (f32x4){0.f, 0.f, 0.f, 0.f};
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dma_rsrc(base), uoff, pp * (2 * XC * 16), 0));
     };
     auto readcol = [&](f32x4* d, int c) {
 #pragma unroll
@@ -236,15 +242,17 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
             *(f32x2*)(vb + vo[nu] + XT * 4) = (f32x2){v[2], v[3]};
         }
     };
-    // Side work of one K chunk, one piece per MFMA gap (step s = 4 * group + slot, 9 groups of 4 MFMAs = one position pair each).
+    // Side work of one K chunk, one piece per MFMA gap (step s = 4 * group + slot, 9 groups of 4 MFMAs = one position pair each).  Every wave
+    // fetches its nine weight fragments of chunk c + 1 in the first nine gaps (a chunk for them to arrive).
     // ROLE 0 (transform): patch columns are read in the order (1, 2, 3, 4, 0, 5), one per group, into two alternating register sets; the row
     // stage of a column runs one group later (its reads were issued in front of that group's fragments, so the group's own lgkmcnt wait covers
-    // them), the column stage as soon as its inputs exist.  ROLE 1 (wave 3): one U piece per gap.
-    auto side = [&](auto ROLE, auto S, int buf) {
-        constexpr int role = decltype(ROLE)::value, s_ = decltype(S)::value;
+    // them), the column stage as soon as its inputs exist.  ROLE 1 (wave 3): the raw-patch pieces of chunk c + 2, one per gap behind the fragments.
+    auto side = [&](auto ROLE, auto S, auto PHASE) {
+        constexpr int role = decltype(ROLE)::value, s_ = decltype(S)::value, buf = decltype(PHASE)::value;
         constexpr int g = s_ >> 2, e = s_ & 3;
+        if constexpr (s_ < 9) (buf ? bq0 : bq1)[s_] = load_b(ug, s_);
         if constexpr (role == 1) {
-            glds16b<!(VAR & 2)>(dma_rsrc(ug + s_ * 256), uoff, ul + s_ * 256);           // U piece s of chunk c + 1
+            if constexpr (s_ >= 9 && s_ < 9 + RPIECES) glds16b<!(VAR & 1)>(dma_rsrc(rnext), roff[s_ - 9], Rs + buf * RPLANE + (s_ - 9) * 256);
         } else {
             constexpr int cols[6] = {1, 2, 3, 4, 0, 5};
             if constexpr (e == 0 && g < 6) readcol((g & 1) ? dB : dA, cols[g]);
@@ -262,9 +270,6 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
             if constexpr (g == 7 && e == 1) w0v = fma4(bc(P0), Tc[0], fma4(bc(-PS), Tc[2], Tc[4]));
             if constexpr (g == 7 && e == 2) w1v = fma4(bc(P0), Tc[1], fma4(bc(-PS), Tc[3], Tc[5]));
             if constexpr (g == 8 && e == 0) { vstore(0, w0v); vstore(5, w1v); }
-            // R pieces of chunk c + 2 (this wave's four)
-            if constexpr (g == 0 && e >= 1) glds16b<!(VAR & 1)>(dma_rsrc(rnext), roff[e - 1], Rs + buf * RPLANE + ((wave % 3) + 3 * (e - 1)) * 256);
-            if constexpr (g == 8 && e == 1) glds16b<!(VAR & 1)>(dma_rsrc(rnext), roff[3], Rs + buf * RPLANE + ((wave % 3) + 9) * 256);
         }
     };
     // 18 accumulators = 288 registers: 16 of them fill the 256 AGPRs, two live in VGPRs.  The MFMAs are inline asm with the register class
@@ -275,24 +280,23 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     for (int i = 0; i < 18; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-    unsigned long long stamp[4] = {0, 0, 0, 0};
-    if (VAR & 32) stamp[0] = __builtin_amdgcn_s_memtime();
+    unsigned long long stamp[6] = {0, 0, 0, 0, 0, 0};
+    if (VAR & (32 | 64)) stamp[0] = __builtin_amdgcn_s_memtime();
 
     const int kh = lane >> 5;
-    const int aoff = ((nh * 18 + kh) * XT + (lane & 31)) * 4, boff = ((nh * 18 + kh) * XC + wn * 32 + (lane & 31)) * 4;
-    // prologue: R(0), R(1), U(0) in flight; V(0) from R(0)
+    const int aoff = ((nh * 18 + kh) * XT + (lane & 31)) * 4;
+    // prologue: R(0), R(1) in flight (wave 3), every wave's weight fragments of chunk 0; V(0) from R(0)
     if (nchunks > 0) {
-        if (wave < 3) {
+        if (wave == 3) {
             issue_r(r_base(rq_, rc4), 0);
             advance(rq_, rc4);
             issue_r(r_base(rq_, rc4), 1);
             advance(rq_, rc4);                       // -> chunk 2
-        } else {
-            ug = u_base(uq, uc4);
-#pragma unroll
-            for (int j = 0; j < 36; ++j) glds16b<!(VAR & 2)>(dma_rsrc(ug + j * 256), uoff, Us + j * 256);
-            advance(uq, uc4);                        // -> chunk 1
         }
+        ug = u_base(uq, uc4);
+#pragma unroll
+        for (int j = 0; j < 9; ++j) bq0[j] = load_b(ug, j);
+        advance(uq, uc4);                            // -> chunk 1
     }
     PC_SYNC_DMA();
     if (nchunks > 0 && wave < 3) {
@@ -313,53 +317,57 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
         vstore(5, fma4(bc(P0), Tc[1], fma4(bc(-PS), Tc[3], Tc[5])));
     }
     __syncthreads();
-    if (VAR & 32) stamp[1] = __builtin_amdgcn_s_memtime();
-    auto k_loop = [&](auto ROLE) {
-        constexpr int role = decltype(ROLE)::value;
-        for (int c = 0; c < nchunks; ++c) {
-            const int buf = c & 1;
-            // during chunk c: U(c+1) -> U[buf^1], R(c+2) -> R[buf] (held chunk c, transformed one iteration ago), V(c+1) from R[buf^1]
-            if constexpr (role == 1) {
-                ug = u_base(uq, uc4);
-                ul = Us + (buf ^ 1) * UPLANE;
-                advance(uq, uc4);
-            } else {
-                rsrc = Rs + (buf ^ 1) * RPLANE;
-                vb = Vs + (buf ^ 1) * VPLANE;
-                rnext = r_base(rq_, rc4);
-                advance(rq_, rc4);
-            }
-            const float* va = Vs + buf * VPLANE + aoff;
-            const float* ub = Us + buf * UPLANE + boff;
-            f32x4 a0 = *(const f32x4*)va, b0 = *(const f32x4*)ub, a1, b1;
-#define W4_STEP(PP, E, A, B)                                                                                                   \
-            if constexpr (2 * (PP) + ((E) >> 1) < 16)                                                                          \
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[2 * (PP) + ((E) >> 1)]) : "v"(A[E]), "v"(B[E])); \
-            else                                                                                                               \
-                asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[2 * (PP) + ((E) >> 1)]) : "v"(A[E]), "v"(B[E])); \
+    if (VAR & (32 | 64)) stamp[1] = __builtin_amdgcn_s_memtime();
+    // One K chunk; PHASE = chunk parity (the loop is unrolled by two, so every LDS buffer and fragment set is a compile-time choice; nchunks is
+    // even: Ci % 8 == 0).  During chunk c: weight fragments of c+1 -> the other register set, R(c+2) -> R[buf] (held chunk c, transformed one
+    // iteration ago), V(c+1) from R[buf^1].
+    auto chunk = [&](auto ROLE, auto PHASE) {
+        constexpr int role = decltype(ROLE)::value, buf = decltype(PHASE)::value;
+        ug = u_base(uq, uc4);
+        advance(uq, uc4);
+        if constexpr (role == 1) {
+            rnext = r_base(rq_, rc4);
+            advance(rq_, rc4);
+        } else {
+            rsrc = Rs + (buf ^ 1) * RPLANE;
+            vb = Vs + (buf ^ 1) * VPLANE;
+        }
+        const float* va = Vs + buf * VPLANE + aoff;
+        f32x4* bq = buf ? bq1 : bq0;
+        f32x4 a0 = *(const f32x4*)va, a1;
+#define W4_STEP(PP, E, A)                                                                                                      \
+        if constexpr (2 * (PP) + ((E) >> 1) < 16)                                                                              \
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc[2 * (PP) + ((E) >> 1)]) : "v"(A[E]), "v"(bq[PP][E])); \
+        else                                                                                                                   \
+            asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(acc[2 * (PP) + ((E) >> 1)]) : "v"(A[E]), "v"(bq[PP][E])); \
+        __builtin_amdgcn_sched_barrier(0);                                                                                     \
+        side(ROLE, std::integral_constant<int, 4 * (PP) + (E)>{}, PHASE);                                                      \
+        __builtin_amdgcn_sched_barrier(0);
+#define W4_GROUP(PP, A, AN)                                                                                                    \
+        {                                                                                                                      \
+            W4_STEP(PP, 0, A)                                                                                                  \
+            if ((PP) + 1 < 9) AN = *(const f32x4*)(va + ((PP) + 1) * (2 * XT * 4));                                            \
             __builtin_amdgcn_sched_barrier(0);                                                                                 \
-            side(ROLE, std::integral_constant<int, 4 * (PP) + (E)>{}, buf);                                                    \
-            __builtin_amdgcn_sched_barrier(0);
-#define W4_GROUP(PP, A, B, AN, BN)                                                                                             \
-            {                                                                                                                  \
-                W4_STEP(PP, 0, A, B)                                                                                           \
-                if ((PP) + 1 < 9) { AN = *(const f32x4*)(va + ((PP) + 1) * (2 * XT * 4)); BN = *(const f32x4*)(ub + ((PP) + 1) * (2 * XC * 4)); } \
-                __builtin_amdgcn_sched_barrier(0);                                                                             \
-                W4_STEP(PP, 1, A, B) W4_STEP(PP, 2, A, B) W4_STEP(PP, 3, A, B)                                                 \
-            }
-            W4_GROUP(0, a0, b0, a1, b1)   W4_GROUP(1, a1, b1, a0, b0)   W4_GROUP(2, a0, b0, a1, b1)
-            W4_GROUP(3, a1, b1, a0, b0)   W4_GROUP(4, a0, b0, a1, b1)   W4_GROUP(5, a1, b1, a0, b0)
-            W4_GROUP(6, a0, b0, a1, b1)   W4_GROUP(7, a1, b1, a0, b0)   W4_GROUP(8, a0, b0, a1, b1)
+            W4_STEP(PP, 1, A) W4_STEP(PP, 2, A) W4_STEP(PP, 3, A)                                                              \
+        }
+        W4_GROUP(0, a0, a1)   W4_GROUP(1, a1, a0)   W4_GROUP(2, a0, a1)
+        W4_GROUP(3, a1, a0)   W4_GROUP(4, a0, a1)   W4_GROUP(5, a1, a0)
+        W4_GROUP(6, a0, a1)   W4_GROUP(7, a1, a0)   W4_GROUP(8, a0, a1)
 #undef W4_STEP
 #undef W4_GROUP
-            PC_SYNC_DMA();
+        PC_SYNC_DMA();
+    };
+    auto k_loop = [&](auto ROLE) {
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(ROLE, std::integral_constant<int, 0>{});
+            chunk(ROLE, std::integral_constant<int, 1>{});
         }
     };
     if (wave == 3) k_loop(std::integral_constant<int, 1>{});
     else k_loop(std::integral_constant<int, 0>{});
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results (inline asm: the compiler does not count their latency)
 
-    if (VAR & 32) stamp[2] = __builtin_amdgcn_s_memtime();
+    if (VAR & (32 | 64)) stamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: Y = A^T M A per (tile, channel).  Accumulator register r is tile (r&3) + 8*(r>>2) + 4*(lane>>5), the lane's column is the
     // output channel.  The row stage (over xi) is local; the column stage sums over nu, half of which the partner wave (same tiles and channels,
     // other nu half) holds: each wave sends its partial sums of the two output columns the partner finalises through LDS (the operand images
@@ -415,6 +423,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
             }
         }
     });
+    if (VAR & 64) stamp[3] = __builtin_amdgcn_s_memtime();
     __syncthreads();
     float* obase = p.out + ((size_t)n * p.T + t) * plane_out + co;
     auto finalise = [&](auto VEC) {
@@ -453,6 +462,7 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     };
     if (vec_ok) finalise(std::true_type{});
     else finalise(std::false_type{});
+    if (VAR & 64) stamp[4] = __builtin_amdgcn_s_memtime();
     if (vec_ok) {
         __syncthreads();
         const int c4 = tid & 15, co0 = ct * XC + c4 * 4;
@@ -470,6 +480,14 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
                 if (accum) v += *(const f32x4*)o;
                 *(f32x4*)o = v;
             }
+        }
+    }
+    if (VAR & 64) {
+        stamp[5] = __builtin_amdgcn_s_memtime();
+        if (tid == 0 && (p.flags & PC_F_BNPART) == 0 && p.bnpart) {
+            unsigned long long* dbg = (unsigned long long*)p.bnpart + (size_t)blockIdx.x * 8;
+            dbg[0] = stamp[1] - stamp[0]; dbg[1] = stamp[2] - stamp[1]; dbg[2] = stamp[3] - stamp[2]; dbg[3] = stamp[4] - stamp[3]; dbg[4] = stamp[5] - stamp[4];
+            dbg[5] = (unsigned long long)nchunks; dbg[6] = 0; dbg[7] = 0;
         }
     }
     if (VAR & 32) {
@@ -534,8 +552,8 @@ void choose_pitch(int bth, int btw, int& rpitch, int& rq) {
 int fill(const pc_wino_desc* d, Wino4K& k) {
     PC_CHECK_ARG(d, "pc_wino: null descriptor");
     PC_CHECK_ARG(d->N >= 1 && d->T >= 1 && d->H >= 4 && d->W >= 4 && d->H % 4 == 0 && d->W % 4 == 0, "pc_wino (m = 4): H, W must be multiples of 4 (H=%d W=%d)", d->H, d->W);
-    PC_CHECK_ARG(d->Ci >= 4 && d->Ci % 4 == 0 && d->ldi % 4 == 0 && d->ldi >= d->Ci && d->Co >= 1 && d->ldo >= d->Co,
-                 "pc_wino (m = 4): Ci %% 4, ldi %% 4, ldi >= Ci, ldo >= Co (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
+    PC_CHECK_ARG(d->Ci >= 8 && d->Ci % 8 == 0 && d->ldi % 4 == 0 && d->ldi >= d->Ci && d->Co >= 1 && d->ldo >= d->Co,
+                 "pc_wino (m = 4): Ci %% 8, ldi %% 4, ldi >= Ci, ldo >= Co (Ci=%d ldi=%d Co=%d ldo=%d)", d->Ci, d->ldi, d->Co, d->ldo);
     PC_CHECK_ARG(d->KT == 1 || d->KT == 3, "pc_wino: KT must be 1 or 3");
     PC_CHECK_ARG((int64_t)d->N * (d->T > d->Ti ? d->T : d->Ti) * d->H * d->W * (int64_t)(d->ldi > d->ldo ? d->ldi : d->ldo) < (1ll << 40), "pc_wino: tensor too large");
     PC_CHECK_ARG((int64_t)d->H * d->W * d->ldi * 4 < 0xff000000ll, "pc_wino: plane too large (the LDS-DMA lane offsets are 32-bit byte offsets inside one frame)");
@@ -556,13 +574,13 @@ int fill(const pc_wino_desc* d, Wino4K& k) {
 }  // namespace
 
 extern "C" int64_t pc_wino4_u_floats(int O, int I, int KT) {
-    if (O < 1 || I < 4 || I % 4 || (KT != 1 && KT != 3)) return -1;
+    if (O < 1 || I < 8 || I % 8 || (KT != 1 && KT != 3)) return -1;
     return (int64_t)KT * cdiv(O, XC) * (I / XK) * UPLANE;
 }
 
 extern "C" int pc_wino4_weights(const float* w, int64_t sO, int64_t sT, int64_t sI, int O, int I, int KT, int flip, float* U, pc_stream s) {
     PC_CHECK_ARG(w && U, "pc_wino4_weights: null pointer");
-    PC_CHECK_ARG(O >= 1 && I >= 4 && I % 4 == 0 && (KT == 1 || KT == 3), "pc_wino4_weights: O=%d I=%d KT=%d", O, I, KT);
+    PC_CHECK_ARG(O >= 1 && I >= 8 && I % 8 == 0 && (KT == 1 || KT == 3), "pc_wino4_weights: O=%d I=%d KT=%d", O, I, KT);
     const int nct = cdiv(O, XC), nc4 = I / XK;
     const long long total = (long long)KT * nct * 64 * I;
     hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)s, w, (long long)sO, (long long)sT, (long long)sI, O, I, KT, flip, U, nct, nc4);
@@ -607,7 +625,8 @@ int pc_wino4_conv_impl(const pc_wino_desc* d, const float* in, const float* U, c
     static const int var = getenv("PICONS_WINO_VARIANT") ? atoi(getenv("PICONS_WINO_VARIANT")) : 0;
     PC_CHECK_ARG(var != 32 || bnpart, "pc_wino_conv: variant 32 writes its stamps through bnpart");
 #endif
-    const size_t lds = (size_t)(2 * RPLANE + 2 * VPLANE + 2 * UPLANE) * sizeof(float);
+    const size_t lds = (size_t)(16 * XT * XC) * sizeof(float);        // the epilogue's staging image (the K loop's R and V images are 60 KiB of it)
+    static_assert(2 * RPLANE + 2 * VPLANE <= 16 * XT * XC, "the operand images must fit the staging image");
     const dim3 grid((unsigned)((int64_t)k.N * k.T * k.nbh * k.nbw * k.nct));
 #define WINO_LAUNCH(V)                                                                                                            \
     {                                                                                                                             \
@@ -625,6 +644,7 @@ int pc_wino4_conv_impl(const pc_wino_desc* d, const float* in, const float* U, c
         case 8: WINO_LAUNCH(8) break;
         case 15: WINO_LAUNCH(15) break;
         case 32: WINO_LAUNCH(32) break;
+        case 64: WINO_LAUNCH(64) break;
         default: WINO_LAUNCH(0) break;
     }
 #else

@@ -1,5 +1,5 @@
 #!/bin/bash
-# F(4x4, 3x3) in the step: kernel tests, step tests, A/B of the bench line (PICONS_WINO4=0 / default), interleaved
+# F(4x4, 3x3) in the step: kernel tests, A/B of the bench line (PICONS_WINO4=0 / default / 28x28 layers too), interleaved, then the whole GPU tier
 set -u
 R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/r05_w4s
@@ -10,6 +10,7 @@ B="python3 bench.py --no-cpu-baseline --no-extra-legs --no-kernel-timing"
 for i in 1 2; do
   PICONS_WINO4=0 timeout 300 $B > $O/bench_w4off_$i.json 2>> $O/bench.err
   timeout 300 $B > $O/bench_w4on_$i.json 2>> $O/bench.err
+  PICONS_WINO4_MIN_TILES=49 timeout 300 $B > $O/bench_w4all_$i.json 2>> $O/bench.err
 done
 python3 - <<'PY'
 import json, glob
@@ -20,4 +21,4 @@ for f in sorted(glob.glob("gpurun_out/r05_w4s/bench_*.json")):
         print(f, "failed", e)
 PY
 timeout 600 python3 tools/bench_wino4.py 10 > $O/bench_wino4.txt 2>&1; cat $O/bench_wino4.txt
-timeout 2400 python3 -m pytest tests/test_step_gpu.py -q > $O/pytest_step.log 2>&1; echo "pytest step rc=$?"; tail -12 $O/pytest_step.log
+bash tools/gpu/r05_tests.sh

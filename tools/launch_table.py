@@ -46,7 +46,7 @@ def main():
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if any(k in r["Kernel_Name"] for k in ("conv_gemm", "conv_x6_kernel", "wgrad_kernel", "wgrad3_kernel", "wgrad4_kernel", "wgrad_x6_kernel", "wgrad3_x6_kernel", "wino_conv_kernel"))]
+    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if any(k in r["Kernel_Name"] for k in ("conv_gemm", "conv_x6_kernel", "wgrad_kernel", "wgrad3_kernel", "wgrad4_kernel", "wgrad_x6_kernel", "wgrad3_x6_kernel", "wino_conv_kernel", "wino4_conv_kernel"))]
     def n_kernels(op):
         """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (pc_wgrad_work's launch count)."""
         return p.op_work[id(op[1])]["launches"] if op[0] == capi.OP_WGRAD else 1
@@ -66,7 +66,9 @@ def main():
             if "wino" not in kn:
                 raise SystemExit("order mismatch: winograd op paired with " + kn)
             N_, T_, H_, W_, Ci_, _l, Co_ = op[1][:7]
-            what = "wino  M=%-7d Co=%-5d Ci=%-4d taps=3x(4x4 transform domain)" % (N_ * T_ * H_ * W_, Co_, Ci_)
+            if (op[1][15] == 4) != ("wino4" in kn):
+                raise SystemExit("order mismatch: winograd op with m = %d paired with %s" % (op[1][15], kn))
+            what = "wino  M=%-7d Co=%-5d Ci=%-4d taps=3x(%s transform domain)" % (N_ * T_ * H_ * W_, Co_, Ci_, "6x6" if op[1][15] == 4 else "4x4")
         elif op[0] in (capi.OP_CONV, capi.OP_CONV_X6):
             if (op[0] == capi.OP_CONV_X6) != ("conv_x6" in kn):
                 raise SystemExit("order mismatch: %s op paired with %s" % ("bf16-split" if op[0] == capi.OP_CONV_X6 else "fp32", kn))

@@ -16,7 +16,7 @@ if M == 4:
     SHAPES = [("64->64 @4x224x224 (N=4)", (4, 224, 224), 64, 64), ("192->64 @2x56x56", (2, 56, 56), 192, 64), ("64->192 @2x56x56", (2, 56, 56), 64, 192),
               ("96->128 @2x28x28", (2, 28, 28), 96, 128), ("128->192 @2x28x28", (2, 28, 28), 128, 192)]
 NAMES = {0: "product", 1: "no patch loads", 2: "no U DMA", 3: "no loads, no DMA", 4: "no transform stores", 7: "MFMA + LDS reads only", 8: "no output stores",
-         15: "MFMA loop + inverse only", 32: "stamps"}
+         15: "MFMA loop + inverse only", 32: "stamps", 64: "product + epilogue stamps"}
 
 
 def child(var):
@@ -43,6 +43,12 @@ def child(var):
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / R
         line = "var %2d %-26s %-28s %7.3f ms" % (var, NAMES.get(var, "?"), name, dt * 1e3)
+        if var == 64:
+            d = dbg.cpu().numpy().reshape(-1, 8)
+            d = d[d[:, 5] > 0]
+            med = lambda a: float(np.median(a))
+            line += "   blocks %d  prologue %.0f  loop %.0f (%.0f / chunk)  epilogue: transform + send %.0f  barrier + finalise %.0f  barrier + stores %.0f cycles" % (
+                len(d), med(d[:, 0]), med(d[:, 1]), med(d[:, 1] / d[:, 5]), med(d[:, 2]), med(d[:, 3]), med(d[:, 4]))
         if var == 32:
             d = dbg.cpu().numpy().reshape(-1, 4)
             d = d[d[:, 3] > 0]

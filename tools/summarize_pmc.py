@@ -102,7 +102,7 @@ def main():
         fams = {"conv_gemm": p.conv_flops_executed(), "conv_x6": p.x6_flops_executed(), "wino_conv": p.wino_flops_executed(), "wgrad": p.wgrad_flops_executed()}
         host = {k: sum(v["mfma"] for v in f.values()) for k, f in fams.items()}
         execd = {k: sum(v["executed"] for v in f.values()) for k, f in fams.items()}
-        fam = lambda k: next((f for f in ("wino_conv", "conv_gemm", "conv_x6", "wgrad") if k.startswith(f)), None)
+        fam = lambda k: "wino_conv" if k.startswith("wino4_conv") else next((f for f in ("wino_conv", "conv_gemm", "conv_x6", "wgrad") if k.startswith(f)), None)
         # one MOPS count = 512 FLOPs of the counter's own dtype; a bf16-split kernel issues six bf16 products per fp32 product, so its
         # fp32-EQUIVALENT FLOPs (what the host books) are the bf16 count / 6.  The wgrad family holds kernels of both kinds.
         cnt = collections.defaultdict(float)
