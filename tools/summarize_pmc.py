@@ -119,7 +119,10 @@ def main():
                 f.write("%-12s %16.2f %16.2f %10.4f %16.2f %10.4f\n" % (k, c / 1e9, host[k] / 1e9, host[k] / max(c, 1.0), execd[k] / 1e9, execd[k] / max(c, 1.0)))
                 if c > 0:
                     assert abs(host[k] / c - 1.0) < 0.03, "host-issued FLOPs of %s disagree with the MFMA counter: %.4f" % (k, host[k] / c)
-                    assert execd[k] <= c * 1.0001 and execd[k] >= 0.85 * c, "executed FLOPs of %s outside [0.85, 1] x counter" % k
+                    # executed / issued: whole-tile padding only -- the Winograd family pads most (28 of 32 tile slots per block in F(4x4,3x3)
+                    # at 112 x 112 / 56 x 56, 49 of 64 in F(2x2,3x3) at 28 x 28, channel counts that are not multiples of 64)
+                    lo = 0.75 if k == "wino_conv" else 0.85
+                    assert execd[k] <= c * 1.0001 and execd[k] >= lo * c, "executed FLOPs of %s outside [%.2f, 1] x counter" % (k, lo)
         print(open(os.path.join(ROOT, "profiles", a.tag + "_mfma_counter_check.txt")).read())
     if a.sq:
         names = ["SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
