@@ -1,5 +1,6 @@
 #!/bin/bash
 # F(4x4,3x3) on the two-frame 28 x 28 layers (Mixed_3b / 3c) only: numerics tests that failed with all 28 x 28 layers in it, and the step
+# (PICONS_WINO4_MIN_T was a one-off switch of Plan.wino_m for this run -- layers with fewer frames stayed in F(2x2,3x3) -- and is not in the tree)
 set -u
 R=${GRAFT_REPO_ROOT:?}
 O=$R/gpurun_out/r05_w4m3
