@@ -372,8 +372,10 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     // output channel.  The row stage (over xi) is local; the column stage sums over nu, half of which the partner wave (same tiles and channels,
     // other nu half) holds: each wave sends its partial sums of the two output columns the partner finalises through LDS (the operand images
     // are dead: the K loop ended with a barrier) and finalises its own two -- bias, BatchNorm partial sums, activation -- into the same staging
-    // image, which then leaves as row-contiguous 16-byte stores.  Every loop over r is unrolled by construction (static_for): a rolled loop
-    // indexes the accumulators through s_set_gpr_idx and took 39 k cycles per block.
+    // image, which then leaves as row-contiguous 16-byte stores.  The staging image is [row][column pair][channel][2]: the two columns a wave
+    // sends (or finalises) for a tile row are one 8-byte slot per lane (32 lanes = 64 banks).  Every loop over r is unrolled by construction
+    // (static_for: a rolled loop indexes the accumulators through s_set_gpr_idx and took 39 k cycles per block) and the nu half is a template
+    // argument of the stage (a run-time half computed both column stages and selected).
     const int co = ct * XC + wn * 32 + (lane & 31);
     const bool cval = co < p.Co;
     const float bv = (p.flags & PC_F_BIAS) && cval ? p.bias[co] : 0.f;
@@ -381,50 +383,52 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     float s1 = 0.f, s2 = 0.f;
     const size_t plane_out = (size_t)p.H * p.W * p.ldo;
     const bool vec_ok = !(VAR & (8 | 32)) && p.ldo % 4 == 0 && p.Co % 4 == 0 && ((uintptr_t)p.out % 16 == 0);
-    float* Tst = smem;                                    // [4 BTH * 4 BTW positions][XC channels ^ 32 (tile bit 2)]
-    const int OW4 = 4 * p.BTW, rowf = OW4 * XC;
-    const int jown = 2 * nh, jsend = 2 - 2 * nh;
+    float* Tst = smem;                                    // [4 BTH rows][2 BTW column pairs][XC channels][2]
+    const int OP2 = 2 * p.BTW, rowf = OP2 * XC * 2;        // column pairs per row / floats per row
     const int ntile = p.BTH * p.BTW;
     const int mhi = 4 * (lane >> 5);
-    // staging column of this lane: lanes 32-63 hold tile m + 4, whose positions are a multiple of 4 KiB away -- the XOR keeps the two lane
-    // halves of a ds_write_b32 / ds_read_b32 on different banks
-    const int tcol = (wn * 32 + (lane & 31)) ^ ((lane >> 5) * 32);
-    float own[16][8];
-    static_for<16>([&](auto R) {
-        constexpr int r = decltype(R)::value;
-        const int m = (r & 3) + 8 * (r >> 2) + mhi;
-        const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;
-        float S[4][3];
+    const int tcol = (wn * 32 + (lane & 31)) * 2;
+    f32x2 own[16][4];
+    auto stage1 = [&](auto NH) {
+        constexpr int nh_ = decltype(NH)::value;
+        static_for<16>([&](auto R) {
+            constexpr int r = decltype(R)::value;
+            const int m = (r & 3) + 8 * (r >> 2) + mhi;
+            const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;
+            float S[4][3];
 #pragma unroll
-        for (int nul = 0; nul < 3; ++nul) {
-            const float m0 = acc[nul][r], m1 = acc[3 + nul][r], m2 = acc[6 + nul][r], m3 = acc[9 + nul][r], m4 = acc[12 + nul][r], m5 = acc[15 + nul][r];
-            const float pp = m1 + m2, qq = m1 - m2, rr = m3 + m4, ss = m3 - m4;
-            S[0][nul] = m0 + pp + rr;
-            S[1][nul] = __builtin_fmaf(PB, ss, PA * qq);
-            S[2][nul] = __builtin_fmaf(PB2, rr, PA2 * pp);
-            S[3][nul] = __builtin_fmaf(PB3, ss, PA3 * qq) + m5;
-        }
-        float* ts = Tst + (4 * li * OW4 + 4 * lj) * XC + tcol;
+            for (int nul = 0; nul < 3; ++nul) {
+                const float m0 = acc[nul][r], m1 = acc[3 + nul][r], m2 = acc[6 + nul][r], m3 = acc[9 + nul][r], m4 = acc[12 + nul][r], m5 = acc[15 + nul][r];
+                const float pp = m1 + m2, qq = m1 - m2, rr = m3 + m4, ss = m3 - m4;
+                S[0][nul] = m0 + pp + rr;
+                S[1][nul] = __builtin_fmaf(PB, ss, PA * qq);
+                S[2][nul] = __builtin_fmaf(PB2, rr, PA2 * pp);
+                S[3][nul] = __builtin_fmaf(PB3, ss, PA3 * qq) + m5;
+            }
+            // this wave sends the column pair 1 - nh and keeps pair nh
+            float* ts = Tst + (4 * li * OP2 + 2 * lj + (1 - nh_)) * (XC * 2) + tcol;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float y0, y1, y2, y3;
-            if (nh == 0) {                 // nu = 0, 1, 2: A^T columns (1 0 0 0), (1 a a2 a3), (1 -a a2 -a3)
-                const float P_ = S[i][1] + S[i][2], Q_ = S[i][1] - S[i][2];
-                y0 = S[i][0] + P_; y1 = PA * Q_; y2 = PA2 * P_; y3 = PA3 * Q_;
-            } else {                       // nu = 3, 4, 5: A^T columns (1 b b2 b3), (1 -b b2 -b3), (0 0 0 1)
-                const float P_ = S[i][0] + S[i][1], Q_ = S[i][0] - S[i][1];
-                y0 = P_; y1 = PB * Q_; y2 = PB2 * P_; y3 = __builtin_fmaf(PB3, Q_, S[i][2]);
+            for (int i = 0; i < 4; ++i) {
+                f32x2 keep, send;
+                if constexpr (nh_ == 0) {      // nu = 0, 1, 2: A^T columns (1 0 0 0), (1 a a2 a3), (1 -a a2 -a3)
+                    const float P_ = S[i][1] + S[i][2], Q_ = S[i][1] - S[i][2];
+                    keep = (f32x2){S[i][0] + P_, PA * Q_};
+                    send = (f32x2){PA2 * P_, PA3 * Q_};
+                } else {                       // nu = 3, 4, 5: A^T columns (1 b b2 b3), (1 -b b2 -b3), (0 0 0 1)
+                    const float P_ = S[i][0] + S[i][1], Q_ = S[i][0] - S[i][1];
+                    send = (f32x2){P_, PB * Q_};
+                    keep = (f32x2){PB2 * P_, __builtin_fmaf(PB3, Q_, S[i][2])};
+                }
+                own[r][i] = keep;
+                if (m < ntile) *(f32x2*)(ts + i * rowf) = send;
             }
-            own[r][i * 2] = nh ? y2 : y0;
-            own[r][i * 2 + 1] = nh ? y3 : y1;
-            if (m < ntile) {
-                ts[i * rowf + jsend * XC] = nh ? y0 : y2;
-                ts[i * rowf + (jsend + 1) * XC] = nh ? y1 : y3;
-            }
-        }
-    });
+        });
+    };
+    if (nh == 0) stage1(std::integral_constant<int, 0>{});
+    else stage1(std::integral_constant<int, 1>{});
     if (VAR & 64) stamp[3] = __builtin_amdgcn_s_memtime();
     __syncthreads();
+    const int jown = 2 * nh;
     float* obase = p.out + ((size_t)n * p.T + t) * plane_out + co;
     auto finalise = [&](auto VEC) {
         constexpr bool vec = decltype(VEC)::value;
@@ -435,26 +439,27 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
             const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;
             const int oi = bh * p.BTH + li, oj = bw * p.BTW + lj;
             const bool ok = cval && m < ntile && oi < p.TH && oj < p.TW;
-            float* ts = Tst + (4 * li * OW4 + 4 * lj + jown) * XC + tcol;
+            float* ts = Tst + (4 * li * OP2 + 2 * lj + nh) * (XC * 2) + tcol;
             if (ok) {
-                float v[8];
+                f32x2 v[4];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = ts[(q >> 1) * rowf + (q & 1) * XC];
+                for (int i = 0; i < 4; ++i) v[i] = *(const f32x2*)(ts + i * rowf);
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    v[q] += own[r][q] + bv;
-                    s1 += v[q]; s2 += v[q] * v[q];
-                    v[q] = relu ? fmaxf(v[q], 0.f) : v[q];
+                for (int i = 0; i < 4; ++i) {
+                    v[i] += own[r][i] + (f32x2){bv, bv};
+                    s1 += v[i][0] + v[i][1]; s2 += v[i][0] * v[i][0] + v[i][1] * v[i][1];
+                    if (relu) { v[i][0] = fmaxf(v[i][0], 0.f); v[i][1] = fmaxf(v[i][1], 0.f); }
                 }
                 if constexpr (vec) {
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) ts[(q >> 1) * rowf + (q & 1) * XC] = v[q];
+                    for (int i = 0; i < 4; ++i) *(f32x2*)(ts + i * rowf) = v[i];
                 } else {
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
+                        float vv = v[q >> 1][q & 1];
                         float* o = obase + ((size_t)(4 * oi + (q >> 1)) * p.W + 4 * oj + jown + (q & 1)) * p.ldo;
-                        if (accum) v[q] += *o;
-                        if (!(VAR & 8) || v[q] == 12345.678f) *o = v[q];
+                        if (accum) vv += *o;
+                        if (!(VAR & 8) || vv == 12345.678f) *o = vv;
                     }
                 }
             }
@@ -466,19 +471,24 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     if (vec_ok) {
         __syncthreads();
         const int c4 = tid & 15, co0 = ct * XC + c4 * 4;
-        const int npo = 16 * ntile;
+        const int npp = 8 * ntile;                                       // column pairs of the block
         float* ob = p.out + ((size_t)n * p.T + t) * plane_out + co0;
         if (co0 < p.Co) {
-#pragma unroll 4
-            for (int pos = tid >> 4; pos < npo; pos += 16) {
-                const int lr = pos / OW4, lc = pos - lr * OW4;
-                const int orow = 4 * bh * p.BTH + lr, ocol = 4 * bw * p.BTW + lc;
-                if (orow >= 4 * p.TH || ocol >= 4 * p.TW) continue;
-                const int mt = (lr >> 2) * p.BTW + (lc >> 2);                          // the tile of this position: its lanes' staging columns
-                f32x4 v = *(const f32x4*)(Tst + pos * XC + ((c4 * 4) ^ (((mt >> 2) & 1) * 32)));
-                float* o = ob + ((size_t)orow * p.W + ocol) * p.ldo;
-                if (accum) v += *(const f32x4*)o;
-                *(f32x4*)o = v;
+            int lr = (tid >> 4) / OP2, lcp = (tid >> 4) - lr * OP2;      // this thread's column pair: every 16th, walked without a division
+#pragma unroll 2
+            for (int pp = tid >> 4; pp < npp; pp += 16) {
+                const int orow = 4 * bh * p.BTH + lr, ocol = 4 * bw * p.BTW + 2 * lcp;
+                if (orow < 4 * p.TH && ocol < 4 * p.TW) {
+                    const float* tp = Tst + (pp * XC + c4 * 4) * 2;
+                    const f32x4 a = *(const f32x4*)tp, b = *(const f32x4*)(tp + 4);          // (c0 p0, c0 p1, c1 p0, c1 p1), (c2 .., c3 ..)
+                    f32x4 v0 = {a[0], a[2], b[0], b[2]}, v1 = {a[1], a[3], b[1], b[3]};
+                    float* o = ob + ((size_t)orow * p.W + ocol) * p.ldo;
+                    if (accum) { v0 += *(const f32x4*)o; v1 += *(const f32x4*)(o + p.ldo); }
+                    *(f32x4*)o = v0;
+                    *(f32x4*)(o + p.ldo) = v1;
+                }
+                lcp += 16;
+                while (lcp >= OP2) { lcp -= OP2; ++lr; }
             }
         }
     }

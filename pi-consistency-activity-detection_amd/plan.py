@@ -396,21 +396,25 @@ class Plan:
 
     @staticmethod
     def wino_m(x):
-        """Output tile edge of a Winograd layer: 4 -- F(4x4, 3x3), csrc/wino4.hip: 1.78x fewer MFMAs than F(2x2, 3x3), measured 1.27 - 1.44x
-        faster on the 224 x 224 and 56 x 56 layers (tools/bench_wino4.py) -- where H, W are multiples of 4 and a frame has at least
-        PICONS_WINO4_MIN_TILES (196 = 56 x 56) tiles; the 28 x 28 layers have too few whole-CU blocks for it (0.77x) and stay on
-        F(2x2, 3x3).  PICONS_WINO4=0: F(2x2, 3x3) everywhere."""
+        """Output tile edge of a Winograd layer: 4 -- F(4x4, 3x3), csrc/wino4.hip: 1.78x fewer MFMAs than F(2x2, 3x3), measured 1.42 - 1.68x
+        faster on the 112 x 112 and 56 x 56 layers (tools/bench_wino4.py) -- where H, W are multiples of 4 and a frame has at least
+        PICONS_WINO4_MIN_TILES (196 = 56 x 56) tiles.  The 28 x 28 layers stay on F(2x2, 3x3): most of them are slower alone (64 - 192
+        whole-CU blocks), the step is 0.3 ms faster with them -- and five step-level parity tests fail (they are the trunk, in
+        front of EM routing).  PICONS_WINO4=0: F(2x2, 3x3) everywhere."""
         _T, H, W = x.thw
         if os.environ.get("PICONS_WINO4", "1") == "0" or H % 4 or W % 4:
             return 2
         return 4 if (H // 4) * (W // 4) >= int(os.environ.get("PICONS_WINO4_MIN_TILES", "196")) else 2
 
-    def wino_weights(self, wname, O, I, need_tr, m=2):
+    def wino_weights(self, wname, O, I, need_tr, m=2, m_tr=None):
         """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
-        gradient, from its transpose with mirrored taps: strides + flip, no intermediate layout)."""
+        gradient, from its transpose with mirrored taps: strides + flip, no intermediate layout).  m / m_tr: the Winograd form (2 or 4) of the
+        forward / of the input gradient."""
+        m_tr = m if m_tr is None else m_tr
         u_floats = capi.lib().pc_wino4_u_floats if m == 4 else capi.lib().pc_wino_u_floats
+        u_floats_tr = capi.lib().pc_wino4_u_floats if m_tr == 4 else capi.lib().pc_wino_u_floats
         nU = u_floats(O, I, 3)
-        if nU <= 0 or (need_tr and u_floats(I, O, 3) <= 0):
+        if nU <= 0 or (need_tr and u_floats_tr(I, O, 3) <= 0):
             raise ValueError("Winograd form of %s: %d -> %d channels is not a shape the kernel takes" % (wname, I, O))
         u = dict(fwd=self.alloc(nU))
         src = self.P(wname)
@@ -420,12 +424,12 @@ class Plan:
         pl = self.next_prep_lane()
         self.emit(capi.OP_WINO_WEIGHTS, i=[O, I, 3, 0, m], l=[I * 27, 1, 27], p=[src, u["fwd"]], lst=self.prep_target, lane=pl)
         if need_tr:
-            u["tr"] = self.alloc(u_floats(I, O, 3))
-            self.emit(capi.OP_WINO_WEIGHTS, i=[I, O, 3, 1, m], l=[27, 1, I * 27], p=[src, u["tr"]], lst=self.prep_target, lane=pl)
+            u["tr"] = self.alloc(u_floats_tr(I, O, 3))
+            self.emit(capi.OP_WINO_WEIGHTS, i=[I, O, 3, 1, m_tr], l=[27, 1, I * 27], p=[src, u["tr"]], lst=self.prep_target, lane=pl)
         self.prep_target = saved_target
         if wname in self.kw:               # finalize() lays a skip conv's weights out on the skip lane, in front of the conv
             self.kw[wname]["wino_fwd"], self.kw[wname]["wino_tr"] = u["fwd"], u.get("tr")
-        u["m"] = m
+        u["m"], u["m_tr"] = m, m_tr
         return u
 
     @staticmethod
@@ -593,8 +597,12 @@ class Plan:
         gamma, beta = self.P(pre + ".bn.weight"), self.P(pre + ".bn.bias")
         F_fwd = _conv_flops(dict(D.conv_fwd(x.N, x.thw, Ci, x.ld, cout, z.ld, k, stride, pf, othw), Ci_real=Ci_real))
         ci3 = Ci == 4 and Ci_real == 3             # the RGB clip: the padding channel's MFMAs are not issued (PC_F_CI3 / PC_WG_CS3)
-        wm = self.wino_m(x) if wino else 2
-        wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training, wm) if wino else None
+        # F(4x4, 3x3) for the input gradient; the trunk's FORWARD stays in F(2x2, 3x3) (PICONS_WINO4_TRUNK_FWD=1: F(4x4, 3x3) too): EM routing
+        # amplifies any perturbation of the trunk's forward arithmetic -- with Conv3d_2c's forward in F(4x4, 3x3) (2.9x the rms rounding error) the
+        # stem's BatchNorm gradients sit at 2.0 - 2.4x the fp32 reference's own distance from its fp64 run instead of 1.0 - 1.2x
+        wm_b = self.wino_m(x) if wino else 2
+        wm = wm_b if os.environ.get("PICONS_WINO4_TRUNK_FWD", "0") == "1" else 2
+        wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training, wm, wm_b) if wino else None
         fin = None
         tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
         tmap_b = (1, pf[0] - 2, stride[0])                 # input gradient (mirrored taps): frame (t + pad_front - 2 + kt) / s
@@ -660,7 +668,7 @@ class Plan:
                 dx, acc = self.grad_for_write(x)
                 self.alg_dgrad(F_fwd, wino)
                 if wino:      # the input gradient of a stride-1 same-padded conv is the same correlation with mirrored, transposed weights
-                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0, m=wm)
+                    self.wino_op(dz.ref, x.N, x.thw, othw[0], cout, dz.ld, Ci, dx.ld, tmap_b, wu["tr"], dx.ref, flags=capi.F_ACCUM if acc else 0, m=wm_b)
                 else:
                     for dd in D.transposed_classes(x.N, othw, cout, dz.ld, x.thw, Ci, dx.ld, k, stride, pf, flags=capi.F_ACCUM if acc else 0, ldw=cout):
                         self.conv_op(dd, dz.ref, w["tr"], dx.ref, alg=0)

@@ -163,24 +163,23 @@ def test_step_vs_reference_golden_full_size(golden_dir, tag):
     # path and the fp32 reference are 1.2-1.4 % (whole-gradient rel-L2) from an fp64 run (gpurun_out/step_grad_err_*_bs8.txt) --
     # the tight per-tensor bar at that size is the fp64-anchored one of test_step_bs8_full_size_vs_oracle
     #
-    # Round 5: the bs = 2 fixtures also hold an fp64 run of the reference (tools/make_goldens.py --only steps_f64).  On these tensors the
-    # reference's own fp32 run is 0.6 - 1.8 % (max-relative) from it -- the same size as the 2 % bar above -- so the bar that decides is the
-    # anchored one: no further from the fp64 run than 2x the fp32 reference's own distance (floor 1 %), the rule of
-    # test_step_reference_init_vs_reference_fp64; the comparison with the fp32 run stays as a 4 % sanity bound.  (With the 112 x 112 and
-    # 56 x 56 Winograd layers in F(4x4, 3x3) the stem's BatchNorm gradients are 1.5 - 1.9x the fp32 reference's distance, 1.0 - 1.5x in
-    # F(2x2, 3x3): tools/probe_grad_margin.py.)
+    # Round 5: the bs = 2 fixtures also hold an fp64 run of the reference (tools/make_goldens.py --only steps_f64; their fp32 contents are
+    # unchanged).  On these tensors the reference's own fp32 run is 0.6 - 1.8 % (max-relative) from it -- the size of the 2 % bar above -- so a
+    # second, anchored bar stands beside it: no further from the fp64 run than 3x the fp32 reference's own distance (floor 1 %), the rule of
+    # test_training_trajectory_vs_reference (measured: at most 1.95x, `Conv3d_1a_7x7.bn.weight` of step_gv_pseudo).  Both bars caught the one launch that may not run in Winograd F(4x4, 3x3): with Conv3d_2c's
+    # FORWARD in it the stem's BatchNorm gradients went from 1.0 - 1.2x to 2.0 - 2.5x the fp32 reference's distance and over the 2 % bar (EM routing amplifies any perturbation of the
+    # trunk's forward); with that launch in F(2x2, 3x3) and the other five in F(4x4, 3x3) every number below is what it was before
+    # (tools/probe_grad_margin.py, profiles/r05_wino4_grad_margin.txt).
     gtol = 2e-2 if bs == 2 else 5e-2
     anchored = any(k.startswith("f64::grad::") for k in S.files)
     for k in S.files:
         if k.startswith("grad::"):
             ref, g = S[k], eng.grad(k[6:]).cpu().numpy()
+            assert np.abs(g - ref).max() <= gtol * np.abs(ref).max() + 1e-8, k
             if anchored:
                 g64 = S["f64::" + k]
                 e_hip, e_ref = np.abs(g - g64).max() / np.abs(g64).max(), np.abs(ref - g64).max() / np.abs(g64).max()
-                assert e_hip <= max(2 * e_ref, 1e-2) + 1e-8 / np.abs(g64).max(), (k, e_hip, e_ref)
-                assert np.abs(g - ref).max() <= 2 * gtol * np.abs(ref).max() + 1e-8, k
-            else:
-                assert np.abs(g - ref).max() <= gtol * np.abs(ref).max() + 1e-8, k
+                assert e_hip <= max(3 * e_ref, 1e-2) + 1e-8 / np.abs(g64).max(), (k, e_hip, e_ref)
         if k.startswith("gsample::"):        # strided samples of the big 224-only / PrimaryCaps gradients
             ref = S[k]
             g = eng.grad(k[9:]).reshape(-1)[::GSAMPLE_STRIDE[k[9:]]].cpu().numpy()
@@ -583,12 +582,10 @@ def test_training_trajectory_vs_reference(tmp_path, mode):
         assert d["mean_vs_f64"] <= max(3 * d["ref32_mean_vs_f64"], 1e-3 * d["moved"]) and d["max_vs_f64"] <= 2.5 * 3 * 1e-4, (k, d)
         assert d["frac_over_lr"] <= max(3 * d["ref32_frac_over_lr"], 0.01), (k, d)
     # every parameter tensor's norm: distance from the fp64 run beyond 3x the fp32 reference's own, relative to max(norm, 1).  The tensors at the
-    # top are BatchNorm biases of the trunk (norm ~ 1, a few hundred elements, each moved by +-lr = 1e-4 per step): ONE element whose step-3 sign
-    # differs moves the norm by up to 1e-4, and which tensor tops the list changes with every change of rounding anywhere (7.1e-5 on
-    # Mixed_4e.b1b.bn.bias with the Winograd layers in F(2x2, 3x3), 1.19e-4 on Mixed_4e.b1a.bn.bias with the 112 x 112 / 56 x 56 ones in
-    # F(4x4, 3x3): gpurun_out/trajectory_*.json, param_norm_excess_top).  The bar is two such moves; a wrong or skipped update of a tensor moves
-    # its norm by n_elements^(1/2) x lr and more.
-    assert v["param_norm_excess"] <= 2e-4, v.get("param_norm_excess_top")
+    # top are BatchNorm biases of the trunk (norm ~ 1, a few hundred elements, each moved by +-lr = 1e-4 per step): one element whose step-3
+    # sign differs moves the norm by up to 1e-4 (measured 7.1e-5; 1.19e-4 with Conv3d_2c's forward in Winograd F(4x4, 3x3), which is one of
+    # the reasons that launch stays in F(2x2, 3x3): gpurun_out/trajectory_*.json, param_norm_excess_top)
+    assert v["param_norm_excess"] <= 1e-4, v.get("param_norm_excess_top")
     # Adam's moments after step 3 (round 5): what guards the optimiser's state machine.  Element-wise, the well-conditioned tensors (decoder,
     # capsule head: 2e-6 .. 1e-2 from the fp64 run) pin the early-Adam range to the reference; the trunk's moments are noise from step 2 on in
     # ANY fp32 arithmetic (the reference's own fp32 run is 40 - 70 % from its fp64 run there, EM routing amplifies rounding), so for every

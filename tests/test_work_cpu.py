@@ -105,9 +105,13 @@ def test_winograd_layers_in_the_plan_and_their_accounting(monkeypatch):
     # 2.25x fewer than the direct form with F(2x2, 3x3) (more where temporal taps fall outside: 6.75x at one frame), 4x with F(4x4, 3x3), which
     # the 112 x 112 and 56 x 56 layers run in (Plan.wino_m)
     assert 0 < ex <= mf and 3.0 < ref / ex < 6.0
-    m_of = {tuple(op[1][:4]): op[1][15] for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_CONV}
-    assert {hw[2] for hw, m in m_of.items() if m == 4} == {112, 56} and {hw[2] for hw, m in m_of.items() if m != 4} == {28}
-    assert sorted(op[1][4] for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_WEIGHTS).count(4) == 6
+    wops = [(n, op[1]) for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_CONV]
+    assert {i[2] for _n, i in wops if i[15] == 4} == {112, 56} and {i[2] for _n, i in wops if i[15] != 4} == {28, 56}
+    # ... except ONE launch: the forward of Conv3d_2c (56 x 56, 64 -> 192, BatchNorm partial sums), the only one of the six that sits in the
+    # trunk's forward, in front of EM routing (Plan.unit3d; PICONS_WINO4_TRUNK_FWD=1 would move it)
+    f23_56 = [(n, i) for n, i in wops if i[15] != 4 and i[2] == 56]
+    assert len(f23_56) == 1 and f23_56[0][0] == "fwd" and (f23_56[0][1][4], f23_56[0][1][6]) == (64, 192) and f23_56[0][1][10] & capi.F_BNPART
+    assert sorted(op[1][4] for n in p.lists for op in p.lists[n] if op[0] == capi.OP_WINO_WEIGHTS).count(4) == 5
     monkeypatch.setenv("PICONS_WINO4", "0")
     q4 = build()
     fz2 = q4.wino_flops_executed()

@@ -82,13 +82,8 @@ for tag, buf in (("adam_m_norms", eng.M), ("adam_v_norms", eng.V)):
     # primary_caps.a.bias, whose exact gradient nearly cancels; the bar is a factor 5)
     lg = np.abs(np.log(np.maximum(got, 1e-300) / np.maximum(r64, 1e-300)))
     lr32 = np.abs(np.log(np.maximum(r32, 1e-300) / np.maximum(r64, 1e-300)))
-    # (round 5, second measurement: x6.2 for the second moment of primary_caps.a.bias once the 112 x 112 / 56 x 56 Winograd layers run in
-    # F(4x4, 3x3) -- its exact gradient is 8e-8 out of terms of 1e-5, so its moments are the rounding noise of whatever arithmetic produced
-    # them; the two PrimaryCaps activation parameters get a factor 10, as they get the noise-sized bar in
-    # test_step_vs_reference_golden_full_size.  What this bar can see on such a tensor is a moment that was never written or written twice
-    # with the wrong scale; a skipped step is seen on the well-conditioned tensors, element-wise)
-    fac = np.array([10.0 if n.startswith("primary_caps.a.") else 5.0 for n in names])
-    ex = lg - np.maximum(3 * lr32, np.log(fac))
+    # (round 5: x6.2 with Conv3d_2c's forward in Winograd F(4x4, 3x3) -- one of the reasons that launch stays in F(2x2, 3x3))
+    ex = lg - np.maximum(3 * lr32, np.log(5.0))
     i = int(np.argmax(ex))
     order = np.argsort(-lg)[:5]
     res[tag] = dict(worst_excess=float(ex[i]), worst=names[i], worst_log_ratio=float(lg[i]), worst_ref32_log_ratio=float(lr32[i]),
