@@ -1,8 +1,9 @@
 // Winograd F(4x4, 3x3) over (h, w) for the largest stride-1, pad-1 3x3x3 convolutions of the step and their input gradients (the decoder's
-// skip convs at 224 x 224 and 56 x 56, capsules_ucf101.py:382-384,497,501; Conv3d_2c at 56 x 56, pytorch_i3d.py:236-238; the 28 x 28
-// Inception branches): 4x fewer multiply-accumulates than the direct form, 1.78x fewer than F(2x2, 3x3) (wino.hip), for a rounding error
-// about 4x that of an fp32 accumulation chain (tests/test_wino_gpu.py holds the bar).  Same structure as wino.hip -- ONE fused kernel, the
-// transform-domain tensors never exist in HBM -- with the roles laid out for 36 transform positions instead of 16:
+// skip convs conv112 / conv56, capsules_ucf101.py:382-384,497,501, both ways; the input gradient of Conv3d_2c at 56 x 56, pytorch_i3d.py:236-238
+// -- its FORWARD and the 28 x 28 Inception branches stay in F(2x2, 3x3): they are the trunk's forward, in front of EM routing):
+// 4x fewer multiply-accumulates than the direct form, 1.78x fewer than F(2x2, 3x3) (wino.hip), for about 3x wino.hip's rounding error
+// (tests/test_wino4_gpu.py holds the same 2e-5 bar; tests/test_wino4_cpu.py restates the algebra below in fp64).  Same structure as wino.hip --
+// ONE fused kernel, the transform-domain tensors never exist in HBM -- with the roles laid out for 36 transform positions instead of 16:
 //
 //   Y = A^T [ sum_ci sum_kt (G g_kt G^T) .* (B^T d_kt B) ] A       per 4x4 output tile, d = 6x6 input patch at (4i-1, 4j-1)
 // Interpolation points (0, +a, -a, +b, -b, inf) with a = 1/sqrt(2), b = sqrt(2) instead of the textbook (0, +-1, +-2, inf): the same operation
@@ -52,9 +53,9 @@ constexpr float PA2 = PA * PA, PB2 = PB * PB, PA3 = PA2 * PA, PB3 = PB2 * PB, P0
 constexpr int XT = 32;            // tiles per block (rows of the transform-domain GEMMs)
 constexpr int XC = 64;            // output channels per block
 constexpr int XK = 4;             // input channels per K chunk
-// LDS operand images.  Transform position (xi, nu) has index P = 18 (nu / 3) + 3 xi + nu % 3: wave (nh, wn) owns the 18 positions of its nu half
-// nh for all 32 tiles x its 32 channels.  Two consecutive positions share a 16-byte slot, so one ds_read_b128 is the fragment of four MFMAs:
-//   V[P / 2][k half][tile 32][P % 2][2]      U[P / 2][k half][co 64][P % 2][2]      channel k of the chunk = 2 (k half) + e
+// Operand images (V in LDS, U in global memory).  Transform position (xi, nu) has index P = 18 (nu / 3) + 3 xi + nu % 3: wave (nh, wn) owns the 18
+// positions of its nu half nh for all 32 tiles x its 32 channels.  Two consecutive positions share a 16-byte slot, so one 16-byte read per lane is
+// the fragment of four MFMAs:   V[P / 2][k half][tile 32][P % 2][2]      U[P / 2][k half][co 64][P % 2][2]      channel k of the chunk = 2 (k half) + e
 constexpr int VPLANE = 18 * 2 * XT * 4;
 constexpr int UPLANE = 18 * 2 * XC * 4;
 constexpr int RPIECES = 12;       // 1 KiB LDS-DMA pieces of one raw patch image (64 positions x 4 channels each): up to 768 positions
@@ -115,14 +116,19 @@ __global__ void wino4_weights_kernel(const float* __restrict__ w, long long sO, 
 // waves, one per SIMD, as 2 (nu halves) x 2 (channel halves): a wave holds the 18 accumulators of its half of the transform positions for all
 // 32 tiles x 32 channels (288 registers) and the two nu halves meet in the epilogue.  K chunk = 4 input channels of one temporal tap.
 //   R  the raw (4 BTH + 2) x (4 BTW + 2) input patch of the block, [position][4 channels]: 16 B per position, zeros for padding, fetched once
-//      per block by LDS-DMA; position (r, c) sits at r * rpitch + (c & 3) * rq + c / 4, so the 32 tiles of a ds_read_b128 read consecutive
-//      slots (rpitch chosen on the host so that tiles of different tile rows do not meet either),
+//      per block by LDS-DMA, all twelve 1 KiB pieces from wave 3, which does no transform; position (r, c) sits at
+//      r * rpitch + (c & 3) * rq + c / 4, so the 32 tiles of a ds_read_b128 read consecutive slots (rpitch chosen on the host so that tiles of
+//      different tile rows do not meet either),
 //   V  the transformed patch B^T d B, written by waves 0-2: thread = (tile, B^T row xi): 24 ds_read_b128 of R, the row stage as four multiply-adds
-//      per column with per-lane coefficients, the column stage in its factored form, 12 ds_write_b64,
-//   U  the transformed weights, contiguous in HBM by construction: 36 KiB per chunk, all of it issued by wave 3, which does no transform.
-// R runs two chunks ahead, U one; one barrier per chunk.  The two roles are two copies of the K loop (a branch inside the loop would split it
-// into blocks and degrade every s_waitcnt); the barrier counts arrivals, not program counters.
-// VAR (PICONS_DIAG builds; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no U DMA, 4 = no transform stores, 8 = no output stores,
+//      per column with per-lane coefficients, the column stage in its factored form, 6 ds_write2st64_b64,
+//   U  the transformed weights never pass through LDS: every wave reads its own nine fragments of the next chunk (16 bytes per lane, the layout
+//      wino4_weights_kernel writes is the MFMA's own) straight from global memory into registers, in the chunk's first nine MFMA gaps.  (The
+//      first version sent U through LDS with 36 LDS-DMA pieces per chunk from wave 3: 3900 - 4030 cycles per chunk against 3120 - 3230 now,
+//      profiles/r05_wino4_probe.txt.)
+// R runs two chunks ahead, U one; one barrier per chunk; the loop is unrolled by two so that every LDS buffer and register set is a compile-time
+// choice.  The two roles are two copies of the K loop (a branch inside the loop would split it into blocks and degrade every s_waitcnt); the
+// barrier counts arrivals, not program counters.
+// VAR (PICONS_DIAG builds; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no weight loads, 4 = no transform stores, 8 = no output stores,
 // 32 = s_memtime stamps of prologue / K loop / epilogue per block into bnpart (4 x u64 per block), 64 = the product kernel with stamps around
 // the epilogue's three phases as well (8 x u64 per block: prologue, loop, row/column stage + send, finalise, stores, chunks).
 template <int VAR>
