@@ -573,7 +573,7 @@ def main():
                             legs.get("main"), PEAK_FP32_MFMA_TFLOPS, {"traffic": traffic, "traffic_source": traffic_src})
     if main_kind is not None:
         fzd = sum(pl.flops_reference_counted_wino()[n] for n in lists)
-        roof_wino = roof("wino4_conv_kernel + wino_conv_kernel (Winograd F(4x4,3x3) on the 112x112 / 56x56 layers, F(2x2,3x3) on the 28x28 ones: conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
+        roof_wino = roof("wino4_conv_kernel + wino_conv_kernel (Winograd F(4x4,3x3) on five 112x112 / 56x56 launches, F(2x2,3x3) on the 28x28 layers and the trunk forward at 56x56: conv / input gradient, fp32 MFMA in the transform domain)", wino_exec, tot(fz, "mfma"), wino_exec,
                          legs.get("wino"), PEAK_FP32_MFMA_TFLOPS,
                          {"flops_counted": "executed transform-domain FLOPs on real tiles / channels (pc_wino_work)",
                           "traffic": traffic_of.get("wino"), "traffic_source": traffic_src})
