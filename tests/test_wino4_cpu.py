@@ -117,3 +117,28 @@ def test_the_chosen_points_round_better_than_the_textbook_ones():
     ours = np.mean([err([0.0, PA, -PA, PB, -PB], s) for s in range(3)], axis=0)
     text = np.mean([err([0.0, 1.0, -1.0, 2.0, -2.0], s) for s in range(3)], axis=0)
     assert ours[0] < 0.75 * text[0] and ours[1] < 0.6 * text[1], (ours, text)
+
+
+def test_host_side_block_choice_covers_every_frame_size_it_accepts():
+    """pc_wino_work with m = 4 (host only, no GPU call): for every H, W that are multiples of 4 up to 256 the kernel's host side finds a block
+    rectangle whose raw-patch image fits its twelve LDS-DMA pieces, the issued multiply-accumulates are the blocks' 32 x 64 tiles x 36 positions,
+    the executed ones the real tiles and channels, and issued / executed is the tile-slot padding (>= 1, and < 2 from 28 x 28 on)."""
+    import ctypes as C
+    from picons_amd import capi, ops
+    out = (C.c_double * 3)()
+    for H in range(4, 260, 4):
+        for W in sorted({4, 8, 12, 28, 56, 112, 132, 224, 256, H}):
+            d = ops.wino_desc(2, 3, H, W, 24, 24, 64, 64, 3, m=4)
+            assert capi.lib().pc_wino_work(C.byref(d), out) == 0, (H, W, capi.lib().pc_last_error())
+            taps = 2 * (2 + 3 + 2)                                        # N = 2 samples, T = 3 frames: 2 + 3 + 2 valid temporal taps each
+            executed = taps * 36.0 * (H // 4) * (W // 4) * 64 * 24
+            assert out[1] == executed and out[0] >= executed and out[0] % (36.0 * 32 * 64 * 24) == 0, (H, W, out[0], out[1])
+            if H >= 28 and W >= 28:
+                assert out[0] / executed < 2.0, (H, W, out[0] / executed)
+            # two BatchNorm partial rows per spatial block; out[2] counts blocks = spatial blocks x nct (64 channels: nct = 1)
+            assert out[2] > 0 and capi.lib().pc_wino_bnpart_rows(C.byref(d)) == 2 * out[2]
+    for bad in ((6, 8), (8, 10), (2, 4)):
+        d = ops.wino_desc(1, 1, bad[0], bad[1], 8, 8, 8, 8, 3, m=4)
+        assert capi.lib().pc_wino_work(C.byref(d), out) != 0
+    d = ops.wino_desc(1, 1, 8, 8, 12, 12, 8, 8, 3, m=4)                   # Ci % 8
+    assert capi.lib().pc_wino_work(C.byref(d), out) != 0 and b"Ci" in capi.lib().pc_last_error()
