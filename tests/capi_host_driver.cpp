@@ -91,6 +91,33 @@ int main() {
     // evaluation metrics / misc entry points with null pointers
     EXPECT(pc_seg_frame_counts(nullptr, nullptr, 1, 50176, nullptr, nullptr) == PC_E_ARG);
     EXPECT(pc_transpose_multi(nullptr, 3, nullptr) == PC_E_ARG);
+
+    // Winograd kernels, both forms: block / pitch choice and work accounting are host arithmetic (choose_block, choose_pitch: the loops over lane
+    // groups and candidate pitches run here under the sanitizers for every frame size), argument checks stop in front of any launch
+    {
+        double w3[3];
+        for (int m = 2; m <= 4; m += 2)
+            for (int H = 4; H <= 256; H += 4)
+                for (int W = 4; W <= 256; W += (W < 64 ? 4 : 36)) {
+                    pc_wino_desc d{};
+                    d.N = 2; d.T = 3; d.H = H; d.W = W; d.Ci = 24; d.ldi = 24; d.Co = 72; d.ldo = 72; d.KT = 3; d.Ti = 3; d.ta = 1; d.tc = -1; d.tden = 1; d.m = m;
+                    EXPECT(pc_wino_work(&d, w3) == PC_OK && w3[0] >= w3[1] && w3[1] > 0 && w3[2] > 0);
+                    EXPECT(pc_wino_bnpart_rows(&d) > 0);
+                    EXPECT(pc_wino_conv(&d, nullptr, fp, nullptr, fp, nullptr, nullptr) == PC_E_ARG);
+                }
+        pc_wino_desc d{};
+        d.N = 1; d.T = 1; d.H = 14; d.W = 14; d.Ci = 8; d.ldi = 8; d.Co = 8; d.ldo = 8; d.KT = 3; d.Ti = 1; d.ta = 1; d.tc = -1; d.tden = 1;
+        d.m = 4;
+        EXPECT(pc_wino_work(&d, w3) == PC_E_ARG && std::strstr(pc_last_error(), "multiples of 4") != nullptr && pc_wino_bnpart_rows(&d) == -1);
+        d.m = 3;
+        EXPECT(pc_wino_work(&d, w3) == PC_E_ARG && std::strstr(pc_last_error(), "m must be") != nullptr && pc_wino_bnpart_rows(&d) == -1);
+        d.m = 2; d.H = 15;
+        EXPECT(pc_wino_work(&d, w3) == PC_E_ARG && pc_wino_work(nullptr, w3) == PC_E_ARG);
+        EXPECT(pc_wino_u_floats(64, 64, 3) == 3 * 8 * 8192 && pc_wino4_u_floats(64, 64, 3) == 3 * 16 * 9216);
+        EXPECT(pc_wino_u_floats(64, 12, 3) == -1 && pc_wino4_u_floats(64, 12, 3) == -1 && pc_wino4_u_floats(64, 64, 2) == -1);
+        EXPECT(pc_wino_weights(nullptr, 1, 1, 1, 64, 64, 3, 0, fp, nullptr) == PC_E_ARG && pc_wino4_weights(fp, 1, 1, 1, 64, 64, 3, 0, nullptr, nullptr) == PC_E_ARG);
+        EXPECT(pc_wino4_weights(fp, 1, 1, 1, 64, 12, 3, 0, fp, nullptr) == PC_E_ARG);
+    }
     if (fails) { std::printf("%d host-side checks failed\n", fails); return 1; }
     std::printf("capi host driver: all checks passed\n");
     return 0;
