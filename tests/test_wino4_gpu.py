@@ -154,3 +154,27 @@ def test_wino4_refuses_shapes_it_cannot_tile():
     d.m = 3
     with pytest.raises(Exception):
         ops.wino_conv(d, torch.zeros(1, 1, 14, 14, 8, device="cuda"), torch.zeros(1 << 16, device="cuda"), torch.zeros(1, 1, 14, 14, 8, device="cuda"))
+
+
+def test_wino4_launches_from_an_idle_chip_are_bit_identical():
+    """The launch pattern that exposed a missing wait in conv_x6.hip this round (tests/test_x6_gpu.py): host pause, caches flushed, ONE launch.
+    This kernel's weight fragments come straight from global memory a chunk ahead and its raw patch by LDS-DMA two chunks ahead; slow transfers
+    (cold caches, idle clocks) are when a missing wait shows."""
+    import time
+    g = torch.Generator(device="cuda").manual_seed(9)
+    N, thw, Ci, Co = 4, (2, 56, 56), 64, 192
+    x = torch.randn(N, *thw, Ci, device="cuda", generator=g).clamp_min(0)
+    w = torch.randn(Co, Ci, 3, 3, 3, device="cuda", generator=g) * (1.0 / np.sqrt(27 * Ci))
+    U = ops.wino_weights(w, Co, Ci, 3, m=4)
+    d = ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3, m=4)
+    first = ops.wino_conv(d, x, U, torch.empty(N, *thw, Co, device="cuda")).clone()
+    junk = torch.empty(96 << 20, device="cuda")
+    out = torch.empty_like(first)
+    differ = 0
+    for it in range(30):
+        junk.fill_(float(it))
+        torch.cuda.synchronize()
+        time.sleep(0.002)
+        ops.wino_conv(d, x, U, out)
+        differ += int(not torch.equal(out, first))
+    assert differ == 0, "%d of 30 launches from an idle chip differ from the first" % differ
