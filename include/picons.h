@@ -149,7 +149,7 @@ typedef struct pc_wino_desc {
                                      * [0, Ti): forward with temporal stride s and front padding p: (s, -p, 1); input gradient of that
                                      * layer (weights mirrored): (1, p - (KT-1), s).  Stride 1, padding KT/2: (1, -(KT/2), 1) both ways */
     int32_t m;                      /* output tile edge: 2 (or 0) = F(2x2, 3x3); 4 = F(4x4, 3x3): 4x fewer multiply-accumulates than the direct
-                                     * form for ~4x the rounding error of an fp32 accumulation chain; H, W multiples of 4, Ci % 4 == 0, and U
+                                     * form for ~3x the rounding error of F(2x2, 3x3); H, W multiples of 4, Ci % 8 == 0, and U
                                      * from pc_wino4_weights (pc_wino4_u_floats floats) */
 } pc_wino_desc;
 int64_t pc_wino_u_floats(int O, int I, int KT);
