@@ -469,6 +469,10 @@ def main():
         legs["wino"] = leg_summary(kind_leg(capi.OP_WINO_CONV))
         if split_on:
             legs["f32c"] = leg_summary(kind_leg(capi.OP_CONV))
+        # the weight gradients (round 6; the largest family of the step): the launches on the bf16 matrix cores and the fp32-MFMA ones apart
+        # (pc_run_ops_timed's sub-filter: kind | 1 << 16 / kind | 2 << 16), event pairs in their own dispatches as for the conv kernels
+        legs["wgx6"] = leg_summary(kind_leg(capi.OP_WGRAD | (1 << 16)))
+        legs["wgf32"] = leg_summary(kind_leg(capi.OP_WGRAD | (2 << 16)))
 
     # ---- the reference's own minibatch contract inside the timed region: float64 host dicts -> pinned double buffer -> copy stream
     dict_leg = None
@@ -525,12 +529,16 @@ def main():
     # HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
     # their own runs, tools/summarize_pmc.py); counters cannot be read from inside a run, so this is OFFLINE data from the named file
     traffic_of, traffic_src = {}, None
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", tag + "_traffic.json")
         if not traffic_of and os.path.exists(tp) and a.bs == 8:
             try:
                 tj = json.load(open(tp))
+                fam_avg = lambda pred: (lambda ws: (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ws) / max(sum(v["launches"] for v in ws), 1)) if ws else None)(
+                    [v for k, v in tj.get("kernels", {}).items() if pred(k)])
                 traffic_of = {"x6": tj.get("conv_x6_hbm_bytes_per_launch"), "f32": tj.get("conv_gemm_hbm_bytes_per_launch"),
+                              "wgx6": fam_avg(lambda k: "wgrad3_x6_kernel" in k or "wgrad_x6_kernel" in k),
+                              "wgf32": fam_avg(lambda k: ("wgrad4_kernel" in k or "wgrad3_kernel" in k or "wgrad_kernel" in k) and "_x6" not in k),
                               "wino": (lambda ws: (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ws) / max(sum(v["launches"] for v in ws), 1)) if ws else None)(
                                   [v for k, v in tj.get("kernels", {}).items() if "wino_conv_kernel" in k or "wino4_conv_kernel" in k])}
                 traffic_src = "profiles/%s_traffic.json (offline rocprofv3 --pmc passes, not this run)" % tag
@@ -579,11 +587,22 @@ def main():
                           "traffic": traffic_of.get("wino"), "traffic_source": traffic_src})
         if roof_wino.get("kernel_ms_per_step"):
             roof_wino["direct_equivalent_tflops"] = fzd / (roof_wino["kernel_ms_per_step"] * 1e-3) / 1e12      # the 3x3x3 formulation's FLOPs over the same time
-    # `roofline` = the GEMM family with the LARGEST single-stream kernel time per step (the dominant kernel); the others keep their own blocks
-    fam = [r for r in (roof_x6, roof_f32conv, roof_wino) if r is not None and r.get("kernel_ms_per_step")]
+    roof_wgx6 = roof_wgf32 = None
+    if main_kind is not None:
+        wx, wf = pl.wgrad_flops_by_family()
+        roof_wgx6 = roof("wgrad3_x6_kernel + wgrad_x6_kernel (weight gradients of the 3x3x3 / 1x1x1 / transposed layers on the bf16 matrix cores: both operands split into "
+                         "3 bf16 terms in registers, 6 products, hi / lo fp32 accumulators; K slices summed in slice order by the gradient re-layout, no atomics)",
+                         wx["executed"], wx["mfma"], wx["valid"], legs.get("wgx6"), PEAK_BF16_MFMA_TFLOPS / 6.0,
+                         {"flops_counted": "executed: real rows x real columns x the positions each K slice walks (pc_wgrad_work)",
+                          "peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate", "traffic": traffic_of.get("wgx6"), "traffic_source": traffic_src})
+        roof_wgf32 = roof("wgrad4_kernel + wgrad3_kernel<.., 9> + wgrad_kernel (fp32 MFMA weight gradients: the RGB stem, the 9-tap spectral PrimaryCaps / upsample1 planes, "
+                          "the tail's per-sample classes)", wf["executed"], wf["mfma"], wf["valid"], legs.get("wgf32"), PEAK_FP32_MFMA_TFLOPS,
+                          {"flops_counted": "executed (pc_wgrad_work)", "traffic": traffic_of.get("wgf32"), "traffic_source": traffic_src})
+    # `roofline` = the GEMM family with the LARGEST single-stream kernel time per step (the dominant kernel) among ALL FIVE families; the others keep their own blocks
+    fam = [r for r in (roof_x6, roof_f32conv, roof_wino, roof_wgx6, roof_wgf32) if r is not None and r.get("kernel_ms_per_step")]
     roofline = max(fam, key=lambda r: r["kernel_ms_per_step"]) if fam else None
     if roofline is not None:
-        roofline = dict(roofline, dominant_by="largest single-stream kernel time per step among the conv families (%s)"
+        roofline = dict(roofline, dominant_by="largest single-stream kernel time per step among the five GEMM families (%s)"
                         % ", ".join("%s %.2f ms" % (r["kernel"].split(" ")[0], r["kernel_ms_per_step"]) for r in fam))
     ms_for_step = resident["ms_per_step"] if resident else ms_step
     roof_step = {"executed_gflop_per_step": step_exec / 1e9, "achieved": step_exec / (ms_step * 1e-3) / 1e12, "peak": PEAK_FP32_MFMA_TFLOPS,
@@ -620,6 +639,8 @@ def main():
         "roofline_conv_x6": roof_x6,
         "roofline_fp32_conv": roof_f32conv,
         "roofline_winograd": roof_wino,
+        "roofline_wgrad_x6": roof_wgx6,
+        "roofline_wgrad_fp32": roof_wgf32,
         "roofline_step": roof_step,
         "ranks_observed": ranks_observed,
         "busy_steps_outside_timed_regions": busy_steps,

@@ -52,6 +52,11 @@ typedef void* pc_stream;            /* hipStream_t */
 #define PC_F_X6      128            /* the launch multiplies on the bf16 matrix cores: fp32 operands as exact sums of three bf16 values, six
                                      * products, fp32 accumulate (pc_conv_fwd_x6; the caller holds the weights as bf16 planes) */
 
+/* ABI version of this header: bumped whenever a struct in it grows or an op's operands change (101: pc_wino_desc.m, PC_OP_BN_FIN_APPLY,
+ * pc_wgrad_desc.ws_slices, pc_transpose_job.nslices / slice_stride, pc_wgrad_slices).  Descriptors must be zero-initialised by the caller:
+ * fields added later read as "old behaviour" when 0.  pc_version() returns the value the library was built with; the Python host
+ * (capi.lib()) refuses a library whose version differs from the header it mirrors. */
+#define PC_VERSION 101
 int         pc_version(void);
 const char* pc_last_error(void);
 
@@ -181,12 +186,23 @@ typedef struct pc_wgrad_desc {
     int32_t Td, Hd, Wd, doff[3];    /* Td > 0: D is not dense but the sub-lattice (Tq,Hq,Wq) starting at doff of a
                                      * [N][Td][Hd][Wd][ldd] tensor (with nbatch > 1: per problem, N = 1 each) */
     int32_t flags;                  /* PC_WG_CS3: Cs == 4 whose 4th channel is padding -- g[..][3] may be left untouched */
-    int32_t reserved;
+    int32_t ws_slices;              /* 0: K slices are combined with fp32 atomics in g (arrival order).  n > 0: g is a WORKSPACE of n images of the
+                                     * gradient, each Cd*KT*KH*KW*Cs floats (nbatch > 1: gbstride*nbatch) -- slice k leaves its partial sums in image k
+                                     * with plain stores, n >= pc_wgrad_slices(d); the consumer adds the images in slice order
+                                     * (pc_transpose_job.nslices), so the gradient is bit-identical from run to run.  The workspace must be
+                                     * zero before its FIRST use (trimmed taps and empty slices are never written) and needs no fill after. */
 } pc_wgrad_desc;
 #define PC_WG_CS3    1
 #define PC_WG_X6     2              /* the row-segment kernel (3 taps along w, padding 1) multiplies on the bf16 matrix cores: both operands split
                                      * into three bf16 terms in registers, six products, fp32 accumulate (as pc_conv_fwd_x6); other routes ignore it */
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
+/* K slices the launch(es) of pc_conv_wgrad make for this problem (host-only, no GPU call; ws_slices is ignored): the number of workspace
+ * images a caller that sets ws_slices has to provide.  -1 on a bad descriptor. */
+int pc_wgrad_slices(const pc_wgrad_desc* d);
+/* Folds the K-slice images of a workspace in place, for launches with many slices: image g*G of every group of G = pc_wgrad_fold_group()
+ * consecutive images becomes the sum of its group (slice order); the consumer then adds ceil(nslices / G) images G*image_floats apart. */
+int pc_wgrad_fold_group(void);
+int pc_wgrad_fold(float* ws, int64_t image_floats, int nslices, pc_stream s);
 /* Host-only work accounting of one pc_conv_wgrad launch (no GPU call; see pc_conv_work).  out[5]: multiply-accumulates ISSUED to
  * the matrix cores, EXECUTED on real rows x columns, VALID (non-padding source positions), and the kernel family the problem is
  * routed to (0 stem, 1 row-segment with 3 taps, 2 row-segment with 9 taps, 3 generic split-K), kernel launches the call makes.
@@ -277,6 +293,9 @@ typedef struct pc_transpose_job {
     uint64_t src, dst;              /* device pointers */
     int64_t  src_batch_stride, dst_batch_stride;
     int32_t  batch, R, C, src_ld, dst_ld, accum;
+    int32_t  nslices, reserved;     /* nslices > 1: src is that many images slice_stride floats apart (the K-slice images of a weight gradient,
+                                     * pc_wgrad_desc.ws_slices); they are added in slice order on the way -- dst (+)= sum_k src_k^T */
+    int64_t  slice_stride;
 } pc_transpose_job;
 int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_stream s);
 /* dx[n,h,w,c] (+)= sum over valid taps of cols[n, h-b, w-c'][(b*KW+c')*C + c]: gather half of an exact stride-1 'full'
@@ -512,6 +531,7 @@ enum {
     PC_OP_SPLIT_PLANES_MULTI,       /* p[0] = HOST pointer to pc_split_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_WSPEC_MASTER_PLANES,      /* i = Acnt, a0, Atot, B, KY, KX, U, Ur; l[0] = plane stride; p = w, tw, out_f planes, out_t planes */
     PC_OP_BN_FIN_APPLY,             /* i = npg, groups, C, ldz, ldy, relu; l = count per group, rows; f = eps, momentum; p = part, gamma, beta, running_mean, running_var, stat, z, y */
+    PC_OP_WGRAD_FOLD,               /* i[0] = nslices; l[0] = image floats; p = ws: pc_wgrad_fold */
     PC_OP__COUNT
 };
 #define PC_MAX_LANES 8

@@ -14,7 +14,7 @@ void pc_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* pc_last_error(void) { return g_err; }
-extern "C" int pc_version(void) { return 100; }
+extern "C" int pc_version(void) { return PC_VERSION; }
 
 extern "C" int pc_transpose_batched(const float*, int, int, int, int64_t, int, float*, int64_t, int, int, pc_stream);
 
@@ -78,6 +78,14 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_TO_NCDHW:
             return pc_ndhwc_to_ncdhw(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], P(float*, 1), s);
         case PC_OP_TRANSPOSE:
+            if (op.i[6] > 1) {          // the source is i[6] K-slice images of a weight gradient, l[2] floats apart: added in slice order on the way
+                pc_transpose_job j;
+                memset(&j, 0, sizeof(j));
+                j.src = op.p[0]; j.dst = op.p[1]; j.src_batch_stride = op.l[0]; j.dst_batch_stride = op.l[1];
+                j.batch = op.i[0]; j.R = op.i[1]; j.C = op.i[2]; j.src_ld = op.i[3]; j.dst_ld = op.i[4]; j.accum = op.i[5];
+                j.nslices = op.i[6]; j.slice_stride = op.l[2];
+                return pc_transpose_multi(&j, 1, s);
+            }
             return pc_transpose_batched(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.l[0], op.i[3], P(float*, 1), op.l[1], op.i[4], op.i[5], s);
         case PC_OP_FILL:
             return pc_fill(P(float*, 0), op.l[0], op.f[0], s);
@@ -147,6 +155,8 @@ static int run_one(const pc_op& op, pc_stream s) {
             return pc_tail6_bias_sums(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         case PC_OP_TRANSPOSE_MULTI:
             return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
+        case PC_OP_WGRAD_FOLD:
+            return pc_wgrad_fold(P(float*, 0), op.l[0], op.i[0], s);
         case PC_OP_WGRAD_MULTI:
             return pc_conv_wgrad_multi(P(const pc_wgrad_job*, 0), op.i[0], s);
         case PC_OP_WINO_CONV: {
@@ -192,8 +202,22 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
     }
     int cnt = 0;
     hipEvent_t* ev = nullptr;
+    // kind = op kind | (sub << 16).  PC_OP_WGRAD: sub 1 = the launches that multiply on the bf16 matrix cores (PC_WG_X6 on the row-segment /
+    // generic routes), sub 2 = the fp32-MFMA ones (stem, 9-tap spectral planes, un-flagged problems), 0 = all
+    const int sub = kind > 0 ? kind >> 16 : 0;
+    if (kind > 0) kind &= 0xffff;
+    auto timed_op = [&](const pc_op& op) {
+        if (kind <= 0 || op.kind != kind) return false;
+        if (!sub || kind != PC_OP_WGRAD) return true;
+        pc_wgrad_desc d;
+        memcpy(&d, op.i, sizeof(d));
+        double w[5] = {0, 0, 0, 0, 0};
+        if (pc_wgrad_work(&d, 0, 0, w) != PC_OK) return false;
+        const bool x6 = (d.flags & PC_WG_X6) && (w[3] == 1.0 || w[3] == 3.0);
+        return sub == 1 ? x6 : !x6;
+    };
     if (kind > 0) {
-        for (int k = 0; k < n; ++k) cnt += ops[k].kind == kind;
+        for (int k = 0; k < n; ++k) cnt += timed_op(ops[k]);
         ev = (hipEvent_t*)malloc(sizeof(hipEvent_t) * 2 * (cnt > 0 ? cnt : 1));
         for (int i = 0; i < 2 * cnt; ++i) ev[i] = take_event();
     }
@@ -222,10 +246,11 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         }
         const int ln = (op.lane > 0 && op.lane < nlanes) ? op.lane : 0;
         const pc_stream s = lanes[ln];
-        const bool t = kind > 0 && op.kind == kind;
+        const bool t = timed_op(op);
         // a conv op is exactly one kernel: its event pair rides in the dispatch itself (no extra packets on the stream);
-        // any other kind is bracketed by recorded events
-        const bool ext = t && (op.kind == PC_OP_CONV || op.kind == PC_OP_CONV_X6 || op.kind == PC_OP_WINO_CONV) && !g_no_ext_events;
+        // any other kind is bracketed by recorded events.  (A weight-gradient op is one kernel too, except the direct PrimaryCaps form's
+        // two row ranges, where the pair brackets the last of the two launches.)
+        const bool ext = t && (op.kind == PC_OP_CONV || op.kind == PC_OP_CONV_X6 || op.kind == PC_OP_WINO_CONV || op.kind == PC_OP_WGRAD) && !g_no_ext_events;
         if (ext) { pc_tl_ev_start = ev[2 * j]; pc_tl_ev_stop = ev[2 * j + 1]; }
         else if (t) (void)hipEventRecord(ev[2 * j], (hipStream_t)s);
         rc = run_one(op, s);

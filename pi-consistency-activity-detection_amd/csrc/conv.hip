@@ -752,6 +752,8 @@ struct WgK {
     int nsplit, dbs, sbs, gbs;       // blockIdx.z = problem * nsplit + K slice; pointers advance by these strides per problem
     int dlat, Td, Hd, Wd, doff[3];   // dlat: D is a sub-lattice (Tq,Hq,Wq) at doff of a [N][Td][Hd][Wd] tensor instead of dense
     int mt, ntl;                     // tiles along Cd and along the columns; the grid is 1-D: mt * ntl * problems * slices blocks
+    long long wss;                   // > 0: g is a workspace of K-slice images wss floats apart -- slice k leaves its partial sums in image k with
+                                     // plain stores and the gradient re-layout adds the images in slice order (no atomics: bit-identical reruns)
 };
 
 // X6: the multiplications on the bf16 matrix cores (conv_x6.hip's scheme; both operands are activations, so both are split in registers: a
@@ -779,7 +781,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
     if (c_begin >= c_end) return;
     const float* Dp = p.D + (size_t)prob * p.dbs;
     const float* Sp = p.S + (size_t)prob * p.sbs;
-    float* gp = p.g + (size_t)prob * p.gbs;
+    float* gp = p.g + (size_t)prob * p.gbs + (size_t)slice * p.wss;
 
     // column decode for the S tile (constant over the K loop)
     constexpr int SC4 = BN / 4, DC4 = BM / 4;          // float4 columns per row
@@ -944,7 +946,7 @@ __device__ __forceinline__ void wgrad_body(const WgK& p, const int lid) {
                     const int ta = tl / tapHW, tr = tl - ta * tapHW, tb = tr / p.ntap[2], tc = tr - tb * p.ntap[2];
                     const int full = ((p.wk0[0] + ta) * p.KH + p.wk0[1] + tb) * p.KW + p.wk0[2] + tc;
                     float* dst = gp + (size_t)m * p.NtotFull + (size_t)full * p.Cs + cc;
-                    if (p.store) *dst = acc[i][j][r];
+                    if (p.store || p.wss) *dst = acc[i][j][r];
                     else atomicAdd(dst, acc[i][j][r]);
                 }
             }
@@ -990,6 +992,7 @@ struct Wg3K {
     int taps_full;                            // KT*KH*KW: g is [Cd][taps_full][Cs]
     int Wsw, padw;                            // width of S and the padding along w (D width W = Wsw - KW + 1 + 2*padw)
     int nprob, store; long long dbs, sbs, gbs; // independent problems in one launch (pointer strides); plain stores (one K slice)
+    long long wss;                            // > 0: K-slice images in a workspace instead of atomics (WgK::wss)
 };
 
 template <int BM, int BKP, int CSB, int WMW, int KW = 3>
@@ -1017,7 +1020,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
     const int slice = (lid / tiles) % p.nsplit, prob = lid / (tiles * p.nsplit);
     const float* Dp = p.D + (size_t)prob * p.dbs;
     const float* Sp = p.S + (size_t)prob * p.sbs;
-    float* gp = p.g + (size_t)prob * p.gbs;
+    float* gp = p.g + (size_t)prob * p.gbs + (size_t)slice * p.wss;
     const int mtile = tile % p.mt; tile /= p.mt;
     const int csb = tile % p.ncs; tile /= p.ncs;
     const int kh_ = tile % p.ntap_h, kt_ = tile / p.ntap_h;
@@ -1119,7 +1122,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_kernel(const Wg3K p) {
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 float* dst = gp + ((size_t)m * p.taps_full + tapbase + kwj[j]) * p.Cs + cs0 + csj[j];
-                if (p.store) *dst = acc[i][j][r];
+                if (p.store || p.wss) *dst = acc[i][j][r];
                 else atomicAdd(dst, acc[i][j][r]);
             }
         }
@@ -1155,7 +1158,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_x6_kernel(const Wg3K p) {
     const int slice = (lid / tiles) % p.nsplit, prob = lid / (tiles * p.nsplit);
     const float* Dp = p.D + (size_t)prob * p.dbs;
     const float* Sp = p.S + (size_t)prob * p.sbs;
-    float* gp = p.g + (size_t)prob * p.gbs;
+    float* gp = p.g + (size_t)prob * p.gbs + (size_t)slice * p.wss;
     const int mtile = tile % p.mt; tile /= p.mt;
     const int csb = tile % p.ncs; tile /= p.ncs;
     const int kh_ = tile % p.ntap_h, kt_ = tile / p.ntap_h;
@@ -1275,7 +1278,7 @@ __global__ __launch_bounds__(256, 2) void wgrad3_x6_kernel(const Wg3K p) {
             const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (m >= p.Cd) continue;
             float* dst = gp + ((size_t)m * p.taps_full + tapbase + j) * p.Cs + cs0 + csl;
-            if (p.store) *dst = acc[r];
+            if (p.store || p.wss) *dst = acc[r];
             else atomicAdd(dst, acc[r]);
         }
     }
@@ -1298,6 +1301,7 @@ struct Wg4K {
     int nseg, mt, taps_full;
     int pre[11];                               // slice prefix per kt (ntap_t + 1 entries)
     int interleave;                            // 1: order[] below is valid
+    long long wss;                             // > 0: K-slice images in a workspace instead of atomics (WgK::wss); image index = slice within its kt
     unsigned short order[1024];                // block q of an m tile -> slice index (kt slices interleaved by their position in the volume)
 };
 
@@ -1317,6 +1321,7 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     __shared__ __attribute__((aligned(16))) float Ds1[BKP][BM];
     __shared__ __attribute__((aligned(16))) float Ss0[SI * 256];
     __shared__ __attribute__((aligned(16))) float Ss1[SI * 256];
+    __shared__ float xch[2][16][64];                                     // epilogue of the K-slice-image form: wave wk = 1 -> wave wk = 0
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave & 1, wk = wave >> 1;
     const int lid = xcd_remap(blockIdx.x, gridDim.x);
@@ -1415,6 +1420,29 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
         if (c + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c + 1);
     }
     const size_t tap0 = (size_t)((kt_ + p.wk0_t) * p.KH + p.wk0_h) * KW * 4;       // g offset of (kt, kh = 0, kw = 0, cs = 0)
+    if (p.wss) {
+        // K-slice image instead of atomics: the two k-step parities (waves wk = 0 / 1) hold partial sums of the SAME outputs, which the atomics
+        // used to combine -- here wave wk = 1 hands its accumulators to wave wk = 0 through LDS (one accumulator per round), which adds them in a
+        // fixed order and stores the image with plain stores
+        float* image = p.g + (size_t)slice * p.wss;
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            if (wk == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) xch[wm][r][lane] = acc[j][r];
+            }
+            __syncthreads();
+            if (wk == 0 && gcol[j] >= 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (m < p.Cd) image[(size_t)m * p.taps_full * 4 + tap0 + gcol[j]] = acc[j][r] + xch[wm][r][lane];
+                }
+            }
+            __syncthreads();
+        }
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -1554,12 +1582,31 @@ extern "C" int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, d
     return PC_OK;
 }
 
-extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s_) {
+namespace {
+// floats of one K-slice image of a problem's gradient: g's own layout [Cd][KT*KH*KW][Cs] (x the problems of a batched launch)
+inline long long wg_image_floats(const pc_wgrad_desc* d) {
+    return d->nbatch > 1 ? (long long)d->gbstride * d->nbatch : (long long)d->Cd * d->KT * d->KH * d->KW * d->Cs;
+}
+}  // namespace
+
+// weight-gradient launch: carries pc_run_ops_timed's event pair in its own dispatch when one is set (as the conv launches do)
+#define WG_LAUNCH(kernel, grid, s, arg)                                                                        \
+    do {                                                                                                       \
+        if (pc_tl_ev_start) hipExtLaunchKernelGGL(kernel, grid, dim3(256), 0, s, pc_tl_ev_start, pc_tl_ev_stop, 0, arg); \
+        else hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, arg);                                           \
+    } while (0)
+
+// dry != NULL: no launch -- *dry = the number of K slices (workspace images) the launch would write (pc_wgrad_slices)
+static int wgrad_run(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s_, int* dry) {
     hipStream_t s = (hipStream_t)s_;
-    PC_CHECK_ARG(d && D && S && g, "pc_conv_wgrad: null pointer");
+    PC_CHECK_ARG(d && (dry || (D && S && g)), "pc_conv_wgrad: null pointer");
     PC_CHECK_ARG(d->Cd % 4 == 0 && d->Cs % 4 == 0 && d->ldd % 4 == 0 && d->lds % 4 == 0,
                  "pc_conv_wgrad: channel counts / strides must be multiples of 4 (Cd=%d Cs=%d)", d->Cd, d->Cs);
-    PC_CHECK_ARG(((uintptr_t)D % 16 == 0) && ((uintptr_t)S % 16 == 0), "pc_conv_wgrad: D/S must be 16-byte aligned");
+    PC_CHECK_ARG(dry || (((uintptr_t)D % 16 == 0) && ((uintptr_t)S % 16 == 0)), "pc_conv_wgrad: D/S must be 16-byte aligned");
+    PC_CHECK_ARG(d->ws_slices >= 0 && !(d->ws_slices > 0 && d->splitk == -1), "pc_conv_wgrad: ws_slices = %d with splitk = %d", d->ws_slices, d->splitk);
+    // ws_slices > 0: g is a workspace of that many K-slice images (wg_image_floats apart); slice k writes image k with plain stores
+    const long long wss = d->ws_slices > 0 ? wg_image_floats(d) : 0;
+    int nslices = 1;
     WgK k;
     k.D = D; k.S = S; k.g = g;
     k.N = d->N; k.Tq = d->Tq; k.Hq = d->Hq; k.Wq = d->Wq; k.Cd = d->Cd; k.ldd = d->ldd;
@@ -1617,6 +1664,10 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             q.pre[a + 1] = q.pre[a] + sl;
         }
         const dim3 grid((unsigned)(q.pre[q.ntap_t] * q.mt));
+        for (int a = 0; a < q.ntap_t; ++a) nslices = std::max(nslices, q.pre[a + 1] - q.pre[a]);
+        if (dry) { *dry = nslices; return PC_OK; }
+        PC_CHECK_ARG(!wss || nslices <= d->ws_slices, "pc_conv_wgrad: the workspace holds %d slice images, this launch writes %d (pc_wgrad_slices)", d->ws_slices, nslices);
+        q.wss = wss;
         {   // block order: slices sorted by where in the volume they are (their relative position inside their kt's slice range), kt as tie-break
             static const int il = getenv("PICONS_WGRAD_STEM_INTERLEAVE") ? atoi(getenv("PICONS_WGRAD_STEM_INTERLEAVE")) : 1;
             const int tot_sl = q.pre[q.ntap_t];
@@ -1632,8 +1683,8 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             }
         }
         static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
-        if ((d->flags & PC_WG_CS3) && pack3) hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7, true>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((wgrad4_kernel<28, 7, 2, 7, false>), grid, dim3(256), 0, s, q);
+        if ((d->flags & PC_WG_CS3) && pack3) WG_LAUNCH((wgrad4_kernel<28, 7, 2, 7, true>), grid, s, q);
+        else WG_LAUNCH((wgrad4_kernel<28, 7, 2, 7, false>), grid, s, q);
         PC_CHECK_LAUNCH("wgrad4_kernel");
         return PC_OK;
     }
@@ -1664,23 +1715,27 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         q.chunks_per_split = cdiv(q.nchunks, splitk);
         q.nsplit = cdiv(q.nchunks, q.chunks_per_split);
         q.store = d->splitk == -1;
+        if (dry) { *dry = q.nsplit; return PC_OK; }
+        PC_CHECK_ARG(!wss || q.nsplit <= d->ws_slices, "pc_conv_wgrad: the workspace holds %d slice images, this launch writes %d (pc_wgrad_slices)", d->ws_slices, q.nsplit);
+        q.wss = wss;
         const dim3 grid((unsigned)(tiles * q.nsplit * nprob));
         if (geo.x6) {
-            if (csb64 && bkp == 64) hipLaunchKernelGGL((wgrad3_x6_kernel<64, 64, 64, 2>), grid, dim3(256), 0, s, q);
-            else if (csb64) hipLaunchKernelGGL((wgrad3_x6_kernel<64, 32, 64, 2>), grid, dim3(256), 0, s, q);
-            else if (bkp == 64) hipLaunchKernelGGL((wgrad3_x6_kernel<128, 64, 32, 4>), grid, dim3(256), 0, s, q);
-            else hipLaunchKernelGGL((wgrad3_x6_kernel<128, 32, 32, 4>), grid, dim3(256), 0, s, q);
+            if (csb64 && bkp == 64) WG_LAUNCH((wgrad3_x6_kernel<64, 64, 64, 2>), grid, s, q);
+            else if (csb64) WG_LAUNCH((wgrad3_x6_kernel<64, 32, 64, 2>), grid, s, q);
+            else if (bkp == 64) WG_LAUNCH((wgrad3_x6_kernel<128, 64, 32, 4>), grid, s, q);
+            else WG_LAUNCH((wgrad3_x6_kernel<128, 32, 32, 4>), grid, s, q);
             PC_CHECK_LAUNCH("wgrad3_x6_kernel");
             return PC_OK;
         }
-        if (row9) hipLaunchKernelGGL((wgrad3_kernel<64, 20, 64, 2, 9>), grid, dim3(256), 0, s, q);
-        else if (!csb64) hipLaunchKernelGGL((wgrad3_kernel<128, 28, 32, 4>), grid, dim3(256), 0, s, q);
-        else if (small_m && bkp == 56) hipLaunchKernelGGL((wgrad3_kernel<64, 56, 64, 2>), grid, dim3(256), 0, s, q);
-        else if (small_m) hipLaunchKernelGGL((wgrad3_kernel<64, 28, 64, 2>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((wgrad3_kernel<128, 28, 64, 2>), grid, dim3(256), 0, s, q);
+        if (row9) WG_LAUNCH((wgrad3_kernel<64, 20, 64, 2, 9>), grid, s, q);
+        else if (!csb64) WG_LAUNCH((wgrad3_kernel<128, 28, 32, 4>), grid, s, q);
+        else if (small_m && bkp == 56) WG_LAUNCH((wgrad3_kernel<64, 56, 64, 2>), grid, s, q);
+        else if (small_m) WG_LAUNCH((wgrad3_kernel<64, 28, 64, 2>), grid, s, q);
+        else WG_LAUNCH((wgrad3_kernel<128, 28, 64, 2>), grid, s, q);
         PC_CHECK_LAUNCH("wgrad3_kernel");
         return PC_OK;
     }
+    bool ws_short = false;
     auto launch = [&](int m_lo, int m_hi, bool small_m) {
         // 256-column tiles with 16-position chunks for the long-K launches: 17-25 % less tile traffic per FLOP.  The kernel
         // is bound by the LDS-DMA fill rate, not by the MFMA loop (fetch ablation: 148 TF/s without the fetch, 113-118 with either
@@ -1711,21 +1766,25 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
         splitk = cdiv(k.nchunks, kk.chunks_per_split);
         kk.nsplit = splitk;
         kk.mt = mt; kk.ntl = ntl;
+        nslices = std::max(nslices, splitk);
+        if (dry) return;
+        if (wss && splitk > d->ws_slices) { ws_short = true; return; }
+        kk.wss = wss;
         dim3 grid((unsigned)((int64_t)mt * ntl * nb * splitk));
 #ifdef PICONS_DIAG
         if (abl == 2) {          // + fragment reads hoisted out of the k-step loop
-            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 2>), grid, dim3(256), 0, s, kk);
-            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 2>), grid, dim3(256), 0, s, kk);
+            if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 2>), grid, s, kk);
+            else WG_LAUNCH((wgrad_kernel<128, 128, 2>), grid, s, kk);
         } else if (abl >= 4 && abl <= 6) {
-            if (abl == 4) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 4>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 4>), grid, dim3(256), 0, s, kk); }
-            if (abl == 5) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 5>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 5>), grid, dim3(256), 0, s, kk); }
-            if (abl == 6) { if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 6>), grid, dim3(256), 0, s, kk); else hipLaunchKernelGGL((wgrad_kernel<128, 128, 6>), grid, dim3(256), 0, s, kk); }
+            if (abl == 4) { if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 4>), grid, s, kk); else WG_LAUNCH((wgrad_kernel<128, 128, 4>), grid, s, kk); }
+            if (abl == 5) { if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 5>), grid, s, kk); else WG_LAUNCH((wgrad_kernel<128, 128, 5>), grid, s, kk); }
+            if (abl == 6) { if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 6>), grid, s, kk); else WG_LAUNCH((wgrad_kernel<128, 128, 6>), grid, s, kk); }
         } else if (abl == 3) {   // + no barrier per chunk
-            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 3>), grid, dim3(256), 0, s, kk);
-            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 3>), grid, dim3(256), 0, s, kk);
+            if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 3>), grid, s, kk);
+            else WG_LAUNCH((wgrad_kernel<128, 128, 3>), grid, s, kk);
         } else if (abl) {
-            if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128, 1>), grid, dim3(256), 0, s, kk);
-            else hipLaunchKernelGGL((wgrad_kernel<128, 128, 1>), grid, dim3(256), 0, s, kk);
+            if (small_m) WG_LAUNCH((wgrad_kernel<64, 128, 1>), grid, s, kk);
+            else WG_LAUNCH((wgrad_kernel<128, 128, 1>), grid, s, kk);
         } else
 #endif
         if (d->flags & PC_WG_X6) {
@@ -1733,21 +1792,35 @@ extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float
             // diagnostic library only (tools/wgrad_x6_acc_probe.py): flag bit 4 = one accumulator per tile instead of the hi / lo pair -- 1.1x the
             // fp32 kernel's distance from fp64 where the pair is at 0.5 - 0.6x, at the same speed
             if (d->flags & 4) {
-                if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128, false>), grid, dim3(256), 0, s, kk);
-                else hipLaunchKernelGGL((wgrad_x6_kernel<128, 128, false>), grid, dim3(256), 0, s, kk);
+                if (small_m) WG_LAUNCH((wgrad_x6_kernel<64, 128, false>), grid, s, kk);
+                else WG_LAUNCH((wgrad_x6_kernel<128, 128, false>), grid, s, kk);
             } else
 #endif
-            if (small_m) hipLaunchKernelGGL((wgrad_x6_kernel<64, 128>), grid, dim3(256), 0, s, kk);
-            else hipLaunchKernelGGL((wgrad_x6_kernel<128, 128>), grid, dim3(256), 0, s, kk);
-        } else if (small_m && wide) hipLaunchKernelGGL((wgrad_kernel<64, 256, 0, 16>), grid, dim3(256), 0, s, kk);
-        else if (small_m) hipLaunchKernelGGL((wgrad_kernel<64, 128>), grid, dim3(256), 0, s, kk);
-        else if (wide) hipLaunchKernelGGL((wgrad_kernel<128, 256, 0, 16>), grid, dim3(256), 0, s, kk);
-        else hipLaunchKernelGGL((wgrad_kernel<128, 128>), grid, dim3(256), 0, s, kk);
+            if (small_m) WG_LAUNCH((wgrad_x6_kernel<64, 128>), grid, s, kk);
+            else WG_LAUNCH((wgrad_x6_kernel<128, 128>), grid, s, kk);
+        } else if (small_m && wide) WG_LAUNCH((wgrad_kernel<64, 256, 0, 16>), grid, s, kk);
+        else if (small_m) WG_LAUNCH((wgrad_kernel<64, 128>), grid, s, kk);
+        else if (wide) WG_LAUNCH((wgrad_kernel<128, 256, 0, 16>), grid, s, kk);
+        else WG_LAUNCH((wgrad_kernel<128, 128>), grid, s, kk);
     };
     const WgSplit w = wg_generic_split(d);
     for (int i = 0; i < w.n; ++i) launch(w.lo[i], w.hi[i], w.small_m[i]);
+    if (dry) { *dry = nslices; return PC_OK; }
+    PC_CHECK_ARG(!ws_short, "pc_conv_wgrad: the workspace holds %d slice images, this launch writes %d (pc_wgrad_slices)", d->ws_slices, nslices);
     PC_CHECK_LAUNCH("wgrad_kernel");
     return PC_OK;
+}
+
+extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s) {
+    return wgrad_run(d, D, S, g, s, nullptr);
+}
+
+extern "C" int pc_wgrad_slices(const pc_wgrad_desc* d) {
+    int n = 0;
+    pc_wgrad_desc e;
+    if (!d) { pc_set_error("pc_wgrad_slices: null descriptor"); return -1; }
+    e = *d; e.ws_slices = 0;
+    return wgrad_run(&e, nullptr, nullptr, nullptr, nullptr, &n) == PC_OK ? n : -1;
 }
 
 
@@ -1782,7 +1855,8 @@ int wg_fill(const pc_wgrad_desc* d, const float* D, const float* S, float* g, Wg
     k.P = (int)P;
     k.Ntot = d->ntap[0] * d->ntap[1] * d->ntap[2] * d->Cs;
     k.nchunks = cdiv(P, 32);
-    k.mbase = 0; k.mend = d->Cd; k.store = 0;
+    k.mbase = 0; k.mend = d->Cd; k.store = 0; k.wss = 0;
+    PC_CHECK_ARG(d->ws_slices == 0, "pc_conv_wgrad_multi: K-slice workspaces are not supported in grouped launches");
     const int nb = d->nbatch > 1 ? d->nbatch : 1;
     k.dbs = nb > 1 ? d->dbstride : 0; k.sbs = nb > 1 ? d->sbstride : 0; k.gbs = nb > 1 ? d->gbstride : 0;
     return PC_OK;

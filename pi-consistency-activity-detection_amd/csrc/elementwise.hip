@@ -552,7 +552,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // Many independent transposes in one launch (the ~160 weight re-layouts at the start of every step): the jobs travel
 // by value in the kernel arguments, a block finds its job from the tile prefix sums.
 constexpr int TM_JOBS = 40;
-struct TJobK { const float* src; float* dst; long long sbs, dbs; int R, Cc, sld, dld, accum, tiles_c, tiles_rc, pad_; };
+struct TJobK { const float* src; float* dst; long long sbs, dbs, sst; int R, Cc, sld, dld, accum, tiles_c, tiles_rc, nsl, tr, pad_; };
 struct TPack { TJobK j[TM_JOBS]; int first[TM_JOBS + 1]; int n; };
 
 __global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
@@ -562,19 +562,60 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
     const TJobK& J = pk.j[k];
     const int t = blockIdx.x - pk.first[k];
     const int b = t / J.tiles_rc, rem = t - b * J.tiles_rc;
-    const int r0 = (rem / J.tiles_c) * 32, c0 = (rem % J.tiles_c) * 32;
+    // tr = rows of a tile: 32, or 8 for a job that sums many K-slice images (four times the blocks, one element per thread)
+    const int r0 = (rem / J.tiles_c) * J.tr, c0 = (rem % J.tiles_c) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    for (int i = ty; i < 32; i += 8) {
-        const int r = r0 + i, c = c0 + tx;
-        tile[i][tx] = (r < J.R && c < J.Cc) ? J.src[(size_t)b * J.sbs + (size_t)r * J.sld + c] : 0.f;
+    if (J.nsl <= 1) {
+        for (int i = ty; i < J.tr; i += 8) {
+            const int r = r0 + i, c = c0 + tx;
+            tile[i][tx] = (r < J.R && c < J.Cc) ? J.src[(size_t)b * J.sbs + (size_t)r * J.sld + c] : 0.f;
+        }
+    } else {
+        // src is nsl K-slice images of a split-K weight gradient, sst floats apart (pc_conv_wgrad with ws_slices): added in slice
+        // order, sixteen loads in flight -- the sum does not depend on which block finished when (no atomics anywhere on the way)
+        for (int i = ty; i < J.tr; i += 8) {
+            const int r = r0 + i, c = c0 + tx;
+            float sum = 0.f;
+            if (r < J.R && c < J.Cc) {
+                const float* q = J.src + (size_t)b * J.sbs + (size_t)r * J.sld + c;
+                int k = 0;
+                for (; k + 16 <= J.nsl; k += 16) {
+                    float t[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) t[u] = q[(size_t)(k + u) * J.sst];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) sum += t[u];
+                }
+                for (; k < J.nsl; ++k) sum += q[(size_t)k * J.sst];
+            }
+            tile[i][tx] = sum;
+        }
     }
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i, r = r0 + tx;
-        if (c < J.Cc && r < J.R) {
+        if (tx < J.tr && c < J.Cc && r < J.R) {
             float* o = J.dst + (size_t)b * J.dbs + (size_t)c * J.dld + r;
             *o = (J.accum ? *o : 0.f) + tile[tx][i];
         }
+    }
+}
+
+// K-slice images of an ordered split-K weight gradient, folded in place: image g * group of every group of `group` consecutive images
+// becomes the sum of the group's images, added in slice order.  One thread per float4 of the image and group: `group` independent loads.
+template <int GROUP>
+__global__ __launch_bounds__(256) void slices_fold_kernel(float* __restrict__ ws, int64_t image4, int nslices, int64_t total) {
+    for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+        const int64_t e = idx % image4; const int g = (int)(idx / image4);
+        float4* base = (float4*)ws + (int64_t)g * GROUP * image4 + e;
+        const int n = min(GROUP, nslices - g * GROUP);
+        float4 t[GROUP];
+#pragma unroll
+        for (int k = 0; k < GROUP; ++k) if (k < n) t[k] = base[(int64_t)k * image4];
+        float4 sum = t[0];
+#pragma unroll
+        for (int k = 1; k < GROUP; ++k) if (k < n) { sum.x += t[k].x; sum.y += t[k].y; sum.z += t[k].z; sum.w += t[k].w; }
+        base[0] = sum;
     }
 }
 
@@ -864,8 +905,10 @@ extern "C" int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_st
             PC_CHECK_ARG(a.src && a.dst && a.batch >= 1 && a.R >= 1 && a.C >= 1, "pc_transpose_multi: bad job %d", j0 + q);
             TJobK& k = pk.j[q];
             k.src = (const float*)(uintptr_t)a.src; k.dst = (float*)(uintptr_t)a.dst; k.sbs = a.src_batch_stride; k.dbs = a.dst_batch_stride;
-            k.R = a.R; k.Cc = a.C; k.sld = a.src_ld; k.dld = a.dst_ld; k.accum = a.accum; k.pad_ = 0;
-            k.tiles_c = cdiv(a.C, 32); k.tiles_rc = k.tiles_c * cdiv(a.R, 32);
+            PC_CHECK_ARG(a.nslices >= 0 && (a.nslices <= 1 || a.slice_stride > 0), "pc_transpose_multi: job %d has %d slices %lld floats apart", j0 + q, a.nslices, (long long)a.slice_stride);
+            k.R = a.R; k.Cc = a.C; k.sld = a.src_ld; k.dld = a.dst_ld; k.accum = a.accum; k.nsl = a.nslices; k.sst = a.slice_stride;
+            k.tr = a.nslices > 4 ? 8 : 32; k.pad_ = 0;
+            k.tiles_c = cdiv(a.C, 32); k.tiles_rc = k.tiles_c * cdiv(a.R, k.tr);
             pk.first[q] = tiles;
             tiles += a.batch * k.tiles_rc;
         }
@@ -873,6 +916,18 @@ extern "C" int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_st
         hipLaunchKernelGGL(transpose_multi_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)s, pk);
         PC_CHECK_LAUNCH("transpose_multi");
     }
+    return PC_OK;
+}
+
+extern "C" int pc_wgrad_fold_group(void) { return 16; }
+
+extern "C" int pc_wgrad_fold(float* ws, int64_t image_floats, int nslices, pc_stream s) {
+    PC_CHECK_ARG(ws && image_floats > 0 && image_floats % 4 == 0 && nslices >= 1 && (uintptr_t)ws % 16 == 0, "pc_wgrad_fold: bad args (image %lld floats, %d slices)", (long long)image_floats, nslices);
+    constexpr int GROUP = 16;
+    if (nslices <= 1) return PC_OK;
+    const int64_t total = (image_floats / 4) * cdiv(nslices, GROUP);
+    hipLaunchKernelGGL(slices_fold_kernel<GROUP>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, ws, image_floats / 4, nslices, total);
+    PC_CHECK_LAUNCH("slices_fold");
     return PC_OK;
 }
 

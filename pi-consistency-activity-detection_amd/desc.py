@@ -83,7 +83,7 @@ def wgrad(N, dense_thw, Cd, ldd, gath_thw, Cs, lds_, k, stride, pad_front, split
     return dict(N=N, Tq=dense_thw[0], Hq=dense_thw[1], Wq=dense_thw[2], Cd=Cd, ldd=ldd,
                 Ts=gath_thw[0], Hs=gath_thw[1], Ws=gath_thw[2], Cs=Cs, lds=lds_,
                 istr=_t3(stride), ntap=_t3(k), ioff0=[-int(p) for p in pad_front], istep=[1, 1, 1],
-                wk0=[0, 0, 0], KT=k[0], KH=k[1], KW=k[2], splitk=splitk, nbatch=0, dbstride=0, sbstride=0, gbstride=0, Td=0, Hd=0, Wd=0, doff=[0, 0, 0], flags=0, reserved=0)
+                wk0=[0, 0, 0], KT=k[0], KH=k[1], KW=k[2], splitk=splitk, nbatch=0, dbstride=0, sbstride=0, gbstride=0, Td=0, Hd=0, Wd=0, doff=[0, 0, 0], flags=0, ws_slices=0)
 
 
 def _valid_tap_range(Q, istr, ioff0, istep, ntap, I):
@@ -137,7 +137,7 @@ CONV_FIELDS = ["N", "Ti", "Hi", "Wi", "Ci", "ldi", "Tq", "Hq", "Wq", "To", "Ho",
                "ostr", "ooff", "istr", "ntap", "ioff0", "istep", "wk0", "wkstep", "KT", "KH", "KW", "ldw",
                "act", "flags", "wgstride", "bgstride", "act_c0", "groups"]
 WGRAD_FIELDS = ["N", "Tq", "Hq", "Wq", "Cd", "ldd", "Ts", "Hs", "Ws", "Cs", "lds", "istr", "ntap", "ioff0",
-                "istep", "wk0", "KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride", "Td", "Hd", "Wd", "doff", "flags", "reserved"]
+                "istep", "wk0", "KT", "KH", "KW", "splitk", "nbatch", "dbstride", "sbstride", "gbstride", "Td", "Hd", "Wd", "doff", "flags", "ws_slices"]
 POOL_FIELDS = ["N", "Ti", "Hi", "Wi", "C", "ldi", "To", "Ho", "Wo", "ldo", "k", "s", "padf"]
 
 

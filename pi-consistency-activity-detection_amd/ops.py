@@ -103,6 +103,35 @@ def conv_wgrad(d, Dt, St, g):
     return g
 
 
+def wgrad_slices(d):
+    """K slices pc_conv_wgrad makes for descriptor d (host-only): the workspace images an ordered (atomic-free) launch needs."""
+    n = capi.lib().pc_wgrad_slices(C.byref(_fill_struct(capi.WgradDesc(), dict(d, ws_slices=0))))
+    if n < 1:
+        raise RuntimeError("pc_wgrad_slices: %s" % capi.lib().pc_last_error().decode())
+    return int(n)
+
+
+def conv_wgrad_ordered(d, Dt, St, ws=None):
+    """The weight gradient without atomics: the K slices leave their partial sums in `ws` ([slices][Cd][taps][Cs], zero before its first
+    use) and are added in slice order -> (g [Cd][taps][Cs], ws).  Bit-identical from run to run."""
+    n = wgrad_slices(d)
+    taps = d["KT"] * d["KH"] * d["KW"]
+    image = d["gbstride"] * d["nbatch"] if d.get("nbatch", 0) > 1 else d["Cd"] * taps * d["Cs"]
+    if ws is None:
+        ws = torch.zeros(n * image, device=Dt.device, dtype=torch.float32)
+    conv_wgrad(dict(d, ws_slices=n), Dt, St, ws)
+    g = ws.view(n, image)[0].clone()
+    for k in range(1, n):
+        g += ws.view(n, image)[k]
+    return g, ws
+
+
+def wgrad_fold(ws, image_floats, nslices):
+    """pc_wgrad_fold: the K-slice images of `ws` folded in place to groups of pc_wgrad_fold_group() (slice order)."""
+    capi.call("pc_wgrad_fold", ptr(ws), int(image_floats), int(nslices), stream())
+    return ws
+
+
 def wgrad_job_table(jobs):
     """[(desc dict, D ptr, S ptr, g ptr)] with integer device addresses -> host array of pc_wgrad_job."""
     tab = np.zeros(len(jobs), dtype=capi.WJOB_DTYPE)
@@ -353,10 +382,12 @@ def transpose_multi(jobs):
     for src / dst: dst[b][c][r] (+)= src[b][r][c] for all of them in one launch."""
     import numpy as np
     tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
-    for q, (src, dst, batch, R, Cc, sbs, sld, dbs, dld, accum) in enumerate(jobs):
+    for q, job in enumerate(jobs):
+        src, dst, batch, R, Cc, sbs, sld, dbs, dld, accum = job[:10]
+        nslices, sst = (job[10], job[11]) if len(job) > 10 else (0, 0)       # K-slice images of a weight gradient, added in slice order on the way
         if not (src.is_cuda and dst.is_cuda):
             raise RuntimeError("picons ops need CUDA/HIP tensors (no CPU fallback)")
-        tab[q] = (src.data_ptr(), dst.data_ptr(), sbs, dbs, batch, R, Cc, sld, dld, int(accum))
+        tab[q] = (src.data_ptr(), dst.data_ptr(), sbs, dbs, batch, R, Cc, sld, dld, int(accum), int(nslices), 0, int(sst))
     capi.call("pc_transpose_multi", C.c_void_p(tab.ctypes.data), len(jobs), stream())
 
 

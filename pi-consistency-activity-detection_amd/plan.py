@@ -39,6 +39,9 @@ class TR:
         return TR((self.ref[0], self.ref[1] + 4 * c0), self.N, self.thw, c, self.ld, self.name)
 
 
+FOLD_AT = 128       # an ordered split-K weight gradient with more K slices than this is folded to groups before its re-layout
+
+
 def off(ref, nfloats):
     return (ref[0], ref[1] + 4 * int(nfloats))
 
@@ -82,6 +85,10 @@ class Plan:
         self.final_lane = {}      # param name -> lane of the op that finalises its gradient
         self.deferred = None      # build_backward: side-lane closures held back until the EM backward is enqueued
         self.wgrad_collect = None  # inside a wgrad group: [(descriptor, pointer refs)] collected for one pc_conv_wgrad_multi op
+        # Ordered split-K (round 6): the K slices of a weight gradient leave their partial sums as images in a workspace (plain stores) and
+        # the gradient re-layout adds the images in slice order -- no fp32 atomics, no zero fill of the kernel-layout gradient, and every
+        # gradient is bit-identical from run to run.  PICONS_WGRAD_ATOMIC=1 restores the atomic epilogue (the A/B switch).
+        self.wg_ordered = os.environ.get("PICONS_WGRAD_ATOMIC", "0") == "0"
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
         self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
         # convolutions multiplied on the bf16 matrix cores (csrc/conv_x6.hip: fp32 operands as exact sums of three bf16 terms, six products,
@@ -536,19 +543,56 @@ class Plan:
             il = self.emit(capi.OP_CONV, i=D.flatten(t, D.CONV_FIELDS), p=[x_ref, w_ref, bias, cscale, out_ref, bnpart])
         self.op_work[id(il)] = w          # keyed by the op's own int list (it survives the re-laning of finalize()): tools/launch_table.py
 
-    def wgrad_op(self, d, p):
+    def wgrad_op(self, d, p, w=None):
         """Emit a weight-gradient launch and book the FLOPs its (already trimmed) descriptor multiplies.  Inside a wgrad_group the
-        launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op."""
+        launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op.
+        w: the weight record (prep_conv_weight / prep_convT_weight) whose re-layout consumes the result -- with ordered split-K the launch
+        writes K-slice images into a workspace of its own (p[2] is replaced) and w's re-layout jobs are pointed at them."""
         if self.x6 and os.environ.get("PICONS_SPLIT_WGRAD", "1") != "0":
             d = dict(d, flags=int(d.get("flags", 0)) | capi.WG_X6)       # row-segment and generic split-K routes (the stem and the 9-tap spectral planes stay fp32)
+        if w is not None and self.wg_ordered and int(d.get("splitk", 0)) != -1:
+            ns = capi.lib().pc_wgrad_slices(_wdesc(d))
+            if ns < 1:
+                raise RuntimeError("pc_wgrad_slices: %s" % capi.lib().pc_last_error().decode())
+            image = d["Cd"] * d["KT"] * d["KH"] * d["KW"] * d["Cs"]
+            ws = self.alloc(ns * image)
+            self.zero_once.append((ws, ns * image))          # trimmed taps / padding channels / empty slices are never written
+            d = dict(d, ws_slices=ns)
+            p = list(p)
+            kg, p[2] = p[2], ws
+            nim, stride = ns, image
+            if ns > FOLD_AT:        # many slices: folded in place to groups first (pc_wgrad_fold), the re-layout then adds the group sums
+                G = capi.lib().pc_wgrad_fold_group()
+                d["_post"] = [(capi.OP_WGRAD_FOLD, [ns], [ws], [image])]
+                nim, stride = -(-ns // G), G * image
+            # taps the descriptor trimmed away (Mixed_4b..4f: T = 1, only the centre temporal tap is ever real) are never written: their rows
+            # of G come from ONE (zero) image instead of being "summed" over every slice
+            taps, khw = d["KT"] * d["KH"] * d["KW"], d["KH"] * d["KW"]
+            r0, r1 = d["wk0"][0] * khw, (d["wk0"][0] + d["ntap"][0]) * khw
+            jobs = []
+            for nm, (kind, i, f, pp, l) in w["unprep"]:
+                src = off(ws, (pp[0][1] - kg[1]) // 4)
+                assert kind == capi.OP_TRANSPOSE and i[1] == taps, (nm, i)
+                for a, b, n_ in ((0, r0, 1), (r0, r1, nim), (r1, taps, 1)):
+                    if b > a:
+                        jobs.append((nm, (kind, [i[0], b - a, i[2], i[3], i[4], i[5], n_], f, [off(src, a * i[3]), off(pp[1], a)], list(l) + [stride])))
+            w["unprep"] = jobs
+            w["ordered"] = True
         self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
-        w = wgrad_work(d)
-        for key, v in (("wg_mfma", w["issued"]), ("wg_executed", w["executed"]), ("wg_valid", w["valid"])):
-            self.work[(self.cur, key)] = self.work.get((self.cur, key), 0) + 2 * v
+        wk = wgrad_work(d)
+        fam = "wgx6_" if (int(d.get("flags", 0)) & capi.WG_X6) and wk["route"] in (1, 3) else "wgf32_"       # the stem / 9-tap routes ignore PC_WG_X6
+        for key, v in (("mfma", wk["issued"]), ("executed", wk["executed"]), ("valid", wk["valid"])):
+            for pre in ("wg_", fam):
+                self.work[(self.cur, pre + key)] = self.work.get((self.cur, pre + key), 0) + 2 * v
         if self.wgrad_collect is not None:
             self.wgrad_collect.append((d, list(p)))
             return
-        self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p))] = w
+        self._emit_wgrad(d, p, wk)
+
+    def _emit_wgrad(self, d, p, wk=None):
+        self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p))] = wk or wgrad_work(d)
+        for kind, i, pp, l in d.get("_post", ()):
+            self.emit(kind, i=i, p=pp, l=l)
 
     def wgrad_group_begin(self):
         """Weight gradients emitted until wgrad_group_end() are held back and leave together at the group's end, on the weight-gradient
@@ -562,9 +606,9 @@ class Plan:
             return
 
         def emit_all():
-            if len(jobs) == 1 or os.environ.get("PICONS_WGRAD_MULTI", "0") == "0":
+            if len(jobs) == 1 or self.wg_ordered or os.environ.get("PICONS_WGRAD_MULTI", "0") == "0":
                 for d, p in jobs:
-                    self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d, D.WGRAD_FIELDS), p=p))] = wgrad_work(d)
+                    self._emit_wgrad(d, p)
             else:
                 self.wjobs = getattr(self, "wjobs", [])
                 self.wjobs.append(jobs)
@@ -661,7 +705,7 @@ class Plan:
                 wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
                 wd["Cs_real"] = Ci_real
                 wd["flags"] = capi.WG_CS3 if ci3 else 0
-                self.on_wgrad_lane(lambda: (self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]]), self.flush_grad(w)))
+                self.on_wgrad_lane(lambda: (self.wgrad_op(wd, [dz.ref, x.ref, w["kg"]], w), self.flush_grad(w)))
                 self.mark_final(*[q + sfx for q in pres for sfx in (".bn.weight", ".bn.bias")])
             if need_dx and part in ("all", "B"):
                 dz = st["dz"]
@@ -797,7 +841,7 @@ class Plan:
             ws = self.alloc(_act_bwd_ws(out.rows, cout))
             self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                       p=[dy.ref, out.ref, dz.ref, self.G(name + ".bias"), ws])
-            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), [dz.ref, x.ref, w["kg"]]),
+            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, x.C, x.ld, k, (1, 1, 1), pad)), [dz.ref, x.ref, w["kg"]], w),
                                         self.flush_grad(w)))
             self.mark_final(name + ".bias")
             if need_dx:
@@ -886,7 +930,7 @@ class Plan:
             else:
                 self.emit(capi.OP_ACT_BWD, i=[dy.ld, out.ld, act, cout, dz.ld, self.acc], l=[out.rows],
                           p=[dy.ref, out.ref, dz.ref if act != capi.ACT_NONE else None, self.G(name + ".bias"), ws])
-            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), [x.ref, dz.ref, w["kg"]]),
+            self.on_wgrad_lane(lambda: (self.wgrad_op(D.trim_wgrad(D.wgrad(x.N, x.thw, Ci, x.ld, othw, cout, dz.ld, k, stride, pad)), [x.ref, dz.ref, w["kg"]], w),
                                         self.flush_grad(w)))
             self.mark_final(name + ".bias")
             dx, acc = self.grad_for_write(x)
@@ -1108,7 +1152,7 @@ class Plan:
                 self.on_wgrad_lane(pc_wgrad)
             else:
                 self.wgrad_op(D.trim_wgrad(D.wgrad(N, caps_in.thw, caps_in.C, dcaps.ld, xd.thw, xd.C, xd.ld, (1, KP, KP), (1, 1, 1), (0, 0, 0))),
-                              [dcaps.ref, xd.ref, wpc["kg"]])
+                              [dcaps.ref, xd.ref, wpc["kg"]], wpc)
             if not spectral_pc:
                 self.flush_grad(wpc)
             self.mark_final("conv_caps.weights", "conv_caps.beta_u", "conv_caps.beta_a", "primary_caps.pose.bias", "primary_caps.a.bias")
@@ -1257,7 +1301,7 @@ class Plan:
                     self.wjobs.append(jobs)
                     if os.environ.get("PICONS_WGRAD_MULTI_TAIL", "0") == "0":
                         for d_, p_ in jobs:
-                            self.op_work[id(self.emit(capi.OP_WGRAD, i=D.flatten(d_, D.WGRAD_FIELDS), p=p_))] = wgrad_work(d_)
+                            self._emit_wgrad(d_, p_)
                     else:
                         self.emit(capi.OP_WGRAD_MULTI, i=[len(jobs)], p=[("WJOBS", len(self.wjobs) - 1)])
 
@@ -1479,7 +1523,8 @@ class Plan:
         tab = np.zeros(len(jobs), dtype=capi.TJOB_DTYPE)
         for q, op in enumerate(jobs):
             _kind, i, _f, p, l = op[:5]
-            tab[q] = (bases[p[0][0]] + p[0][1], bases[p[1][0]] + p[1][1], l[0], l[1], i[0], i[1], i[2], i[3], i[4], i[5])
+            ns, sst = (i[6], l[2]) if len(i) > 6 else (0, 0)          # K-slice images of an ordered split-K weight gradient
+            tab[q] = (bases[p[0][0]] + p[0][1], bases[p[1][0]] + p[1][1], l[0], l[1], i[0], i[1], i[2], i[3], i[4], i[5], ns, 0, sst)
         return tab
 
     def _merge_prep_transposes(self, lst, bases, keep):
@@ -1525,6 +1570,10 @@ class Plan:
     def wgrad_flops_executed(self):
         """The same three counts for the weight-gradient launches (pc_wgrad_work)."""
         return {name: {k: self.work.get((name, "wg_" + k), 0) for k in ("mfma", "executed", "valid")} for name in self.lists}
+
+    def wgrad_flops_by_family(self):
+        """(bf16-split launches, fp32-MFMA launches): the counts of wgrad_flops_executed summed over the lists, per kernel family."""
+        return tuple({k: sum(self.work.get((name, pre + k), 0) for name in self.lists) for k in ("mfma", "executed", "valid")} for pre in ("wgx6_", "wgf32_"))
 
     def flops(self, only_kind=None):
         """FLOPs ISSUED per list (2*M*N*K of the emitted, tap-trimmed descriptors with the real channel counts -- zero-padding

@@ -43,9 +43,9 @@ def test_bench_line_contract():
     rs = j["resident"]
     assert rs["unit"] == "clips/s" and abs(rs["value"] - 8 * 1000.0 / rs["ms_per_step"]) < 1e-6 * rs["value"] and j["value_resident"] == rs["value"]
     assert j["ms_per_step"] < 1.5 * rs["ms_per_step"] + 5.0
-    fams = [j[k] for k in ("roofline_conv_x6", "roofline_fp32_conv", "roofline_winograd")]
+    fams = [j[k] for k in ("roofline_conv_x6", "roofline_fp32_conv", "roofline_winograd", "roofline_wgrad_x6", "roofline_wgrad_fp32")]
     assert all(f.get("invalid") is None and f["timed_steps"] == 3 for f in fams)             # every leg: three measured replays that agree within 1.5x
-    d = j["roofline"]                                       # = the family with the largest single-stream kernel time per step
+    d = j["roofline"]                                       # = the family with the largest single-stream kernel time per step among all FIVE
     assert d["bound"] == "mfma" and d["kernel_ms_per_step"] == max(f["kernel_ms_per_step"] for f in fams) and "dominant_by" in d
     assert abs(d["frac"] - d["achieved"] / d["peak"]) < 1e-9 and 0.1 < d["frac"] < 1.0 and d["kernel_ms_per_step"] < j["ms_per_step"]
     r = j["roofline_conv_x6"]                               # fp32 on the bf16 matrix cores, roof = bf16 peak / 6 products
@@ -60,6 +60,12 @@ def test_bench_line_contract():
     assert f["peak"] == 157.3 and f["launches_per_step"] >= 5 and 0.1 < f["frac"] <= f["frac_mfma_issued"] < 1.0
     w = j["roofline_winograd"]                               # the Winograd family, timed in its own replays
     assert w["launches_per_step"] >= 8 and 0.2 < w["frac"] <= w["frac_mfma_issued"] < 1.0 and w["direct_equivalent_tflops"] > w["achieved"]
+    gx, gf = j["roofline_wgrad_x6"], j["roofline_wgrad_fp32"]  # the weight gradients: bf16-split launches against bf16 peak / 6, the fp32 ones against 157.3
+    assert abs(gx["peak"] - 2500.0 / 6) < 1e-6 and "wgrad3_x6_kernel" in gx["kernel"] and gx["launches_per_step"] >= 30 and 0.1 < gx["frac"] <= gx["frac_mfma_issued"] < 1.0
+    assert gf["peak"] == 157.3 and "wgrad4_kernel" in gf["kernel"] and 3 <= gf["launches_per_step"] <= 16 and 0.1 < gf["frac"] <= gf["frac_mfma_issued"] < 1.0
+    assert gx["launches_per_step"] + gf["launches_per_step"] >= 46
+    wg_gf = (gx["flops_per_launch"] * gx["launches_per_step"] + gf["flops_per_launch"] * gf["launches_per_step"]) / 1e9
+    assert abs(wg_gf - j["roofline_step"]["gflop_by_family"]["wgrad"]) < 1e-3 * wg_gf            # the two legs' numerators are the whole family's FLOPs
     fam = j["roofline_step"]["gflop_by_family"]
     assert fam["conv_bf16_split"] > fam["conv_fp32_mfma"] > 0 and fam["wgrad"] > 0 and fam["winograd_conv"] > 0
     dc = j["dict_contract"]                                 # the reference's float64 host dicts inside the timed region

@@ -20,7 +20,7 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_TAIL_GRADS: (6, 7, 8, 9), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
           capi.OP_WSPEC_MASTER_BWD: (2,), capi.OP_LOSS: (4, 5, 6, 7, 8, 9), capi.OP_SPREAD: (3, 4), capi.OP_ADAM: (0, 2, 3), capi.OP_COL2IM: (1,),
           capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,),
-          capi.OP_CONV_X6: (4, 5, 6), capi.OP_SPLIT_PLANES: (1,), capi.OP_WSPEC_MASTER_PLANES: (2, 3)}
+          capi.OP_CONV_X6: (4, 5, 6), capi.OP_SPLIT_PLANES: (1,), capi.OP_WSPEC_MASTER_PLANES: (2, 3), capi.OP_WGRAD_FOLD: (0,)}
 
 
 def _plan(lanes, bs=1, hw=112, early_adam=False):
@@ -165,6 +165,7 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
 
 def test_inception_wgrads_as_grouped_launches(monkeypatch):
     monkeypatch.setenv("PICONS_WGRAD_MULTI", "1"); monkeypatch.setenv("PICONS_WGRAD_MULTI_TAIL", "1")
+    monkeypatch.setenv("PICONS_WGRAD_ATOMIC", "1")           # grouped launches exist in the atomic split-K form only (no K-slice workspaces)
     p = _plan(4)
     _check_list(p, p.lists["bwd"], 4)
     assert sorted(len(j) for j in p.wjobs) == [4] * 7 + [8]
