@@ -193,8 +193,9 @@ typedef struct pc_wgrad_desc {
                                      * zero before its FIRST use (trimmed taps and empty slices are never written) and needs no fill after. */
 } pc_wgrad_desc;
 #define PC_WG_CS3    1
-#define PC_WG_X6     2              /* the row-segment kernel (3 taps along w, padding 1) multiplies on the bf16 matrix cores: both operands split
-                                     * into three bf16 terms in registers, six products, fp32 accumulate (as pc_conv_fwd_x6); other routes ignore it */
+#define PC_WG_X6     2              /* the row-segment (3 taps along w, padding 1), generic split-K and -- together with PC_WG_CS3 -- stem kernels multiply
+                                     * on the bf16 matrix cores: both operands split into three bf16 terms in registers, six products, fp32
+                                     * accumulate (as pc_conv_fwd_x6); the 9-tap spectral route ignores it (pc_wgrad_uses_x6) */
 int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s);
 /* K slices the launch(es) of pc_conv_wgrad make for this problem (host-only, no GPU call; ws_slices is ignored): the number of workspace
  * images a caller that sets ws_slices has to provide.  -1 on a bad descriptor. */
@@ -208,6 +209,9 @@ int pc_wgrad_fold(float* ws, int64_t image_floats, int nslices, pc_stream s);
  * routed to (0 stem, 1 row-segment with 3 taps, 2 row-segment with 9 taps, 3 generic split-K), kernel launches the call makes.
  * cd_real / cs_real: 0 = Cd / Cs. */
 int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, double* out);
+/* 1 if the problem's launch multiplies on the bf16 matrix cores (PC_WG_X6 on the row-segment, generic and -- with PC_WG_CS3 -- stem routes), 0 if on
+ * fp32 MFMA (host-only; bench.py's two weight-gradient roofline legs and pc_run_ops_timed's sub-filter split the family by it) */
+int pc_wgrad_uses_x6(const pc_wgrad_desc* d);
 /* Several weight gradients in one call (the wgrads of one Inception module; the eight position classes of the merged tail):
  * the problems the generic split-K kernel would take share ONE grid, each with a range of blocks in proportion to its work; the
  * others (stem, row-segment, long-K shapes) get their usual launch.  Same results as njobs pc_conv_wgrad calls up to the order

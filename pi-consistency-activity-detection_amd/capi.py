@@ -96,6 +96,7 @@ _SIGS = {
     "pc_conv_wgrad": (i32, [C.POINTER(WgradDesc), vp, vp, vp, vp]),
     "pc_conv_wgrad_multi": (i32, [vp, i32, vp]),
     "pc_wgrad_slices": (i32, [C.POINTER(WgradDesc)]),
+    "pc_wgrad_uses_x6": (i32, [C.POINTER(WgradDesc)]),
     "pc_wgrad_fold_group": (i32, []),
     "pc_wgrad_fold": (i32, [vp, i64, i32, vp]),
     "pc_wgrad_work": (i32, [C.POINTER(WgradDesc), i32, i32, C.POINTER(C.c_double)]),

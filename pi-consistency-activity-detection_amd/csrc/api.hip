@@ -203,7 +203,7 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
     int cnt = 0;
     hipEvent_t* ev = nullptr;
     // kind = op kind | (sub << 16).  PC_OP_WGRAD: sub 1 = the launches that multiply on the bf16 matrix cores (PC_WG_X6 on the row-segment /
-    // generic routes), sub 2 = the fp32-MFMA ones (stem, 9-tap spectral planes, un-flagged problems), 0 = all
+    // generic / stem routes: pc_wgrad_uses_x6), sub 2 = the fp32-MFMA ones (9-tap spectral planes, un-flagged problems), 0 = all
     const int sub = kind > 0 ? kind >> 16 : 0;
     if (kind > 0) kind &= 0xffff;
     auto timed_op = [&](const pc_op& op) {
@@ -211,9 +211,7 @@ static int run_list(const pc_op* ops, int n, const pc_stream* lanes, int nlanes,
         if (!sub || kind != PC_OP_WGRAD) return true;
         pc_wgrad_desc d;
         memcpy(&d, op.i, sizeof(d));
-        double w[5] = {0, 0, 0, 0, 0};
-        if (pc_wgrad_work(&d, 0, 0, w) != PC_OK) return false;
-        const bool x6 = (d.flags & PC_WG_X6) && (w[3] == 1.0 || w[3] == 3.0);
+        const bool x6 = pc_wgrad_uses_x6(&d) != 0;
         return sub == 1 ? x6 : !x6;
     };
     if (kind > 0) {

@@ -1453,6 +1453,186 @@ __global__ __launch_bounds__(256, 2) void wgrad4_kernel(const Wg4K p) {
     }
 }
 
+// ---- the stem's weight gradient on the bf16 matrix cores (round 6; conv_x6.hip has the scheme: three bf16 terms per fp32 operand, six products,
+// hi / lo accumulators).  Same problem and LDS images as wgrad4_kernel<.., PACK3> -- a block owns all 7 x 7 (kh, kw) taps x 3 real source channels
+// of one kt, packed into five 32-column accumulators; every input piece is fetched once per chunk -- but the K chunk is TWO sub-chunks of 16
+// consecutive output positions of a row (112 = 7 x 16: no padding positions, where 28-position segments would leave 4 of 32 empty), one k16
+// step each: waves = 2 halves of D's 64 channels x the 2 sub-chunks.  Both operands are activations, so both are split in registers: a lane's
+// MFMA operand is eight consecutive POSITIONS of one column -- eight ds_read_b32 down the D tile, eight ds_read_b32 eight dwords apart (SW * 4)
+// along an input row for (kh, kw, cs).  Per wave and chunk: 48 LDS reads, 24 two-element splits, 30 MFMAs -- 0.6 microseconds of matrix-pipe
+// time, less than the latency of an LDS-DMA fetch: the tiles live in a THREE-deep ring (chunk c + 2 is fetched while chunk c is multiplied) with
+// counted waits (every wave issues the same five DMA instructions per chunk, so "chunk c has landed" is vmcnt <= 5 while chunk c + 1 is in flight).
+template <int KW, int SW, int NKH>
+__global__ __launch_bounds__(256, 2) void wgrad4_x6_kernel(const Wg4K p) {
+    constexpr int BM = 64, SUB = 16, BKP = 2 * SUB;
+    constexpr int ROWP = SW * SUB + KW - 1;                  // pieces per kh row of a sub-chunk
+    constexpr int SPIECES = NKH * ROWP, SI = 6, SSUB = SI * 256, DI = BKP * BM * 4 / 1024;     // six DMA instructions per sub-chunk image (the last two partly / all padding)
+    constexpr int NCOL = NKH * KW * 3, NACC = (NCOL + 31) / 32;
+    constexpr int NDMA = 5;                                  // DMA instructions per wave and chunk: 2 of D, 3 of S
+    static_assert(DI == 8 && SPIECES <= SI * 64 && 2 * SI == 12, "tile shape");
+    __shared__ __attribute__((aligned(16))) float Ds0[BKP][BM];          // one variable per ring slot: see wgrad3_kernel
+    __shared__ __attribute__((aligned(16))) float Ds1[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ds2[BKP][BM];
+    __shared__ __attribute__((aligned(16))) float Ss0[2 * SSUB];
+    __shared__ __attribute__((aligned(16))) float Ss1[2 * SSUB];
+    __shared__ __attribute__((aligned(16))) float Ss2[2 * SSUB];
+    __shared__ float xch[2][16][64];                                     // epilogue: wave wk = 1 -> wave wk = 0
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave & 1, wk = wave >> 1;
+    const int lid = xcd_remap(blockIdx.x, gridDim.x);
+    const int mtile = lid % p.mt, sl = p.interleave ? (int)p.order[lid / p.mt] : lid / p.mt;
+    int kt_ = 0;
+    while (kt_ + 1 < p.ntap_t && sl >= p.pre[kt_ + 1]) ++kt_;
+    const int slice = sl - p.pre[kt_], nsplit = p.pre[kt_ + 1] - p.pre[kt_];
+    int tlo = 0, thi = p.T - 1;
+    while (tlo <= thi && tlo * p.istr_t + p.ioff_t + kt_ < 0) ++tlo;
+    while (thi >= tlo && thi * p.istr_t + p.ioff_t + kt_ >= p.Ts) --thi;
+    const int ntv = thi - tlo + 1;
+    const int nsub = p.N * ntv * p.H * p.nseg;               // sub-chunks (p.nseg = ceil(W / 16) per row)
+    const int nchunks = (nsub + 1) / 2;
+    const int cps = (nchunks + nsplit - 1) / nsplit;
+    const int c_begin = slice * cps, c_end = min(nchunks, c_begin + cps);
+    if (c_begin >= c_end) return;
+    const int m0 = mtile * BM;
+
+    // sub-chunk -> (n, t, h, seg) as a counter advanced by every fetch (two sub-chunks per chunk, in order)
+    int q_seg, q_h, q_t, q_n, q_idx = 2 * c_begin;
+    { int r = q_idx; q_seg = r % p.nseg; r /= p.nseg; q_h = r % p.H; r /= p.H; q_t = r % ntv; q_n = r / ntv; }
+    auto gload = [&](auto slot) {
+        constexpr int buf = decltype(slot)::value;
+        float* ld = buf == 0 ? &Ds0[0][0] : buf == 1 ? &Ds1[0][0] : &Ds2[0][0];
+        float* ls = buf == 0 ? &Ss0[0] : buf == 1 ? &Ss1[0] : &Ss2[0];
+        dma_rsrc_t rsS[2];
+        int hs0_[2], w0_[2]; bool live_[2];
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            const bool live = q_idx < nsub;                   // an odd number of sub-chunks: the last chunk's second half reads zeros
+            const int seg = q_seg, h = q_h, t = tlo + q_t, n = q_n;
+            ++q_idx;
+            if (++q_seg == p.nseg) { q_seg = 0; if (++q_h == p.H) { q_h = 0; if (++q_t == ntv) { q_t = 0; ++q_n; } } }
+            const int w0 = seg * SUB;
+            const int row_d = ((n * p.T + t) * p.H + h) * p.W;
+            const int ts = t * p.istr_t + p.ioff_t + kt_, hs0 = h * p.istr_h + p.ioff_h;
+            const dma_rsrc_t rsD = dma_rsrc(p.D + (live ? (size_t)(row_d + w0) * p.ldd + m0 : 0));
+            rsS[sub] = dma_rsrc(p.S + (live ? (((long long)(n * p.Ts + ts) * p.Hs + hs0) * p.Wsw + (long long)w0 * SW - p.padw) * p.lds : 0));
+            hs0_[sub] = hs0; w0_[sub] = w0; live_[sub] = live;
+            {   // D: DMA instruction sub * 4 + wave = rows 16 sub + 4 wave .. + 3 of the chunk's tile
+                const int i = sub * 4 + wave;
+                const int rr = lane >> 4, c4 = lane & 15, r16 = wave * 4 + rr;
+                const bool v = live && (w0 + r16) < p.W && (m0 + c4 * 4) < p.Cd;
+                glds16b(rsD, v ? (unsigned)(r16 * p.ldd + c4 * 4) * 4u : DMA_OOB, ld + i * 256);
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) {                      // S: instruction wave + 4 jj of the chunk's twelve: sub-chunk image i / 6, its piece row i % 6
+            const int i = jj * 4 + wave, sub = i / SI, ii = i - sub * SI;
+            const int e = ii * 64 + lane, kh = e / ROWP, rr = e - kh * ROWP;
+            const int hs = hs0_[sub] + kh, w = w0_[sub] * SW - p.padw + rr;
+            const bool v = live_[sub] && kh < NKH && (unsigned)hs < (unsigned)p.Hs && (unsigned)w < (unsigned)p.Wsw;
+            glds16b(rsS[sub], v ? (unsigned)((kh * p.Wsw + rr) * p.lds) * 4u : DMA_OOB, ls + i * 256);
+        }
+    };
+
+    f32x16 acc_hi[NACC], acc_lo[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc_hi[j][r] = 0.f; acc_lo[j][r] = 0.f; }
+    const int nl = lane & 31, kg = lane >> 5, ml = wm * 32 + nl;
+    int boff[NACC], gcol[NACC];                // LDS dword of this lane's column in accumulator j at its first position / its offset inside g's [tap][4] rows (-1: none)
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        const int G = j * 32 + nl, kh = G / (KW * 3), rem = G - kh * (KW * 3), kw = rem / 3, cs = rem - kw * 3;
+        const bool v = G < NCOL;
+        boff[j] = (v ? kh * ROWP * 4 + kw * 4 + cs : 0) + wk * SSUB + 4 * SW * 8 * kg;
+        gcol[j] = v ? (kh * KW + kw) * 4 + cs : -1;
+    }
+    typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
+    typedef __attribute__((ext_vector_type(4))) uint32_t u4;
+#define WG_MF(X, Y, Cc) Cc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf8, X), __builtin_bit_cast(bf8, Y), Cc, 0, 0, 0)
+    auto chunk = [&](auto slot, int c) {
+        constexpr int buf = decltype(slot)::value;
+        // chunk c has landed for every wave (counted: chunk c + 1, if any, stays in flight) and every wave is done with chunk c - 1, whose slot
+        // the fetch of chunk c + 2 overwrites.  The waits are written out (PC_SYNC_DMA, common.h: the compiler's own bookkeeping lost them once)
+        if (c + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        if (c + 2 < c_end) gload(std::integral_constant<int, (buf + 2) % 3>{});
+        const float* sb = buf == 0 ? &Ss0[0] : buf == 1 ? &Ss1[0] : &Ss2[0];
+        const float (*Dt)[BM] = buf == 0 ? Ds0 : buf == 1 ? Ds1 : Ds2;
+        u4 A[3];
+        {
+            float a[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) a[q] = Dt[wk * SUB + 8 * kg + q][ml];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { uint32_t h_, m_, l_; x6_split2(a[2 * q], a[2 * q + 1], h_, m_, l_); A[0][q] = h_; A[1][q] = m_; A[2][q] = l_; }
+        }
+        float b[NACC][8];
+#pragma unroll
+        for (int j = 0; j < NACC; ++j)
+#pragma unroll
+            for (int q = 0; q < 8; ++q) b[j][q] = sb[boff[j] + 4 * SW * q];
+        // software pipeline inside the chunk: the split of column tile j + 1 is issued between the six MFMAs of tile j (worth 1.5 %: the vector
+        // and the matrix instructions of the waves of a SIMD mostly take turns whatever their order -- SQ_VALU_MFMA_COEXEC_CYCLES 0.12 of the kernel's
+        // cycles, MFMA-busy 0.38 + vector-busy 0.51 of them -- so what bounds this kernel is the SUM of its 30 MFMAs and ~310 vector instructions per
+        // wave and chunk, profiles/r06_stem_wgrad_x6.txt)
+        u4 B[2][3];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { uint32_t h_, m_, l_; x6_split2(b[0][2 * q], b[0][2 * q + 1], h_, m_, l_); B[0][0][q] = h_; B[0][1][q] = m_; B[0][2][q] = l_; }
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) {
+            const int cur = j & 1;
+            if (j + 1 < NACC) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { uint32_t h_, m_, l_; x6_split2(b[j + 1][2 * q], b[j + 1][2 * q + 1], h_, m_, l_); B[cur ^ 1][0][q] = h_; B[cur ^ 1][1][q] = m_; B[cur ^ 1][2][q] = l_; }
+            }
+            WG_MF(A[0], B[cur][2], acc_lo[j]); WG_MF(A[2], B[cur][0], acc_lo[j]); WG_MF(A[1], B[cur][1], acc_lo[j]);
+            WG_MF(A[0], B[cur][1], acc_lo[j]); WG_MF(A[1], B[cur][0], acc_lo[j]);
+            WG_MF(A[0], B[cur][0], acc_hi[j]);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);       // ... eight vector instructions in its shadow
+            }
+        }
+    };
+#undef WG_MF
+    gload(std::integral_constant<int, 0>{});
+    if (c_begin + 1 < c_end) gload(std::integral_constant<int, 1>{});
+    for (int c = c_begin; c < c_end; c += 3) {
+        chunk(std::integral_constant<int, 0>{}, c);
+        if (c + 1 < c_end) chunk(std::integral_constant<int, 1>{}, c + 1);
+        if (c + 2 < c_end) chunk(std::integral_constant<int, 2>{}, c + 2);
+    }
+    __syncthreads();                           // every wave is behind its last chunk
+    const size_t tap0 = (size_t)((kt_ + p.wk0_t) * p.KH + p.wk0_h) * KW * 4;       // g offset of (kt, kh = 0, kw = 0, cs = 0)
+    // the two sub-chunk waves hold partial sums of the SAME outputs: wave wk = 1 hands its sums to wave wk = 0 through LDS, one accumulator
+    // per round
+    float* image = p.g + (size_t)slice * p.wss;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) {
+        const f32x16 acc = acc_hi[j] + acc_lo[j];
+        if (wk == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) xch[wm][r][lane] = acc[r];
+        }
+        __syncthreads();
+        if (wk == 0 && gcol[j] >= 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (m < p.Cd) {
+                    float* dst = image + (size_t)m * p.taps_full * 4 + tap0 + gcol[j];
+                    const float v = acc[r] + xch[wm][r][lane];
+                    if (p.wss) *dst = v;
+                    else atomicAdd(dst, v);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // Which kernel family pc_conv_wgrad gives a problem to -- ONE classification for pc_conv_wgrad, pc_conv_wgrad_multi and the host-side
 // work accounting (pc_wgrad_work), so the A/B switches mean the same everywhere and the fp32 atomic sum order the goldens were
 // made with cannot drift between copies of the predicates.
@@ -1477,6 +1657,19 @@ inline WgRoute wg_route(const pc_wgrad_desc* d) {
         d->istep[2] == 1 && (row3 || row9))
         return row9 ? WG_ROW9 : WG_ROW3;
     return WG_GENERIC;
+}
+// the stem's weight gradient on the bf16 matrix cores (wgrad4_x6_kernel): asked for (PC_WG_X6) and the 4th source channel is padding (PC_WG_CS3:
+// the kernel packs the 3 real channels of the 7 x 7 taps into five accumulators)
+inline bool wg_stem_x6(const pc_wgrad_desc* d) {
+    static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
+    static const int x6env = getenv("PICONS_WGRAD_STEM_X6") ? atoi(getenv("PICONS_WGRAD_STEM_X6")) : 1;
+    return x6env && pack3 && (d->flags & PC_WG_X6) && (d->flags & PC_WG_CS3) && wg_route(d) == WG_STEM;
+}
+// does the problem's launch multiply on the bf16 matrix cores?  (the 9-tap spectral planes and un-flagged problems stay on fp32 MFMA)
+inline bool wg_uses_x6(const pc_wgrad_desc* d) {
+    if (!(d->flags & PC_WG_X6)) return false;
+    const WgRoute r = wg_route(d);
+    return r == WG_ROW3 || r == WG_GENERIC || (r == WG_STEM && wg_stem_x6(d));
 }
 // 256-column tiles with 16-position chunks for the long-K launches of the generic kernel (PICONS_WGRAD_WIDE bit 0: 128-row, bit 1: 64-row tiles)
 inline bool wg_wide(const pc_wgrad_desc* d, bool small_m) {
@@ -1548,14 +1741,16 @@ extern "C" int pc_wgrad_work(const pc_wgrad_desc* d, int cd_real, int cs_real, d
     const WgRoute route = wg_route(d);
     double issued = 0, executed = 0, launches = 1;
     if (route == WG_STEM) {
-        const int nseg = d->Wq / 28, mt = cdiv(d->Cd, 64);
+        const bool x6 = wg_stem_x6(d);
+        const int nseg = x6 ? cdiv(d->Wq, 16) : d->Wq / 28, mt = cdiv(d->Cd, 64);
+        const double seg = x6 ? 16.0 : 28.0;
         static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
         const bool p3 = (d->flags & PC_WG_CS3) && pack3;
         const double nacc = p3 ? (7 * 7 * 3 + 31) / 32 : 7;
         for (int a = 0; a < d->ntap[0]; ++a) {
             const double chunks = (double)d->N * V[0][a] * d->Hq * nseg;          // every kh of the kt tap, all w
-            issued += chunks * 28.0 * (mt * 64.0) * nacc * 32.0;
-            executed += chunks * 28.0 * cd_real * (7.0 * 7.0 * cs_real);
+            issued += chunks * seg * (mt * 64.0) * nacc * 32.0;
+            executed += (double)d->N * V[0][a] * d->Hq * d->Wq * cd_real * (7.0 * 7.0 * cs_real);
         }
     } else if (route == WG_ROW3 || route == WG_ROW9) {
         const Row3Geo r = wg_row_geo(d, route == WG_ROW9);
@@ -1643,7 +1838,9 @@ static int wgrad_run(const pc_wgrad_desc* d, const float* D, const float* S, flo
         q.ntap_t = d->ntap[0]; q.wk0_t = d->wk0[0]; q.wk0_h = d->wk0[1]; q.KH = d->KH;
         q.Ts = d->Ts; q.Hs = d->Hs; q.Wsw = d->Ws; q.istr_t = d->istr[0]; q.istr_h = d->istr[1]; q.ioff_t = d->ioff0[0]; q.ioff_h = d->ioff0[1];
         q.padw = -d->ioff0[2];
-        q.nseg = d->Wq / 28; q.mt = cdiv(d->Cd, 64); q.taps_full = d->KT * d->KH * d->KW;
+        static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
+        const bool x6 = wg_stem_x6(d);                  // bf16-split kernel: chunks of two 16-position sub-chunks
+        q.nseg = x6 ? cdiv(d->Wq, 16) : d->Wq / 28; q.mt = cdiv(d->Cd, 64); q.taps_full = d->KT * d->KH * d->KW;
         // K slices per kt in proportion to the output t planes whose source plane exists
         int ntv[10], tot = 0;
         for (int a = 0; a < q.ntap_t; ++a) {
@@ -1653,11 +1850,11 @@ static int wgrad_run(const pc_wgrad_desc* d, const float* D, const float* S, flo
         }
         PC_CHECK_ARG(tot > 0, "pc_conv_wgrad: no valid tap");
         static const int s4_slots = getenv("PICONS_WGRAD_STEM_SLOTS") ? atoi(getenv("PICONS_WGRAD_STEM_SLOTS")) : 768;   // 162 VGPRs, 28 KiB LDS: 3 blocks per CU
-        const int slots = d->splitk > 0 ? d->splitk * q.ntap_t : s4_slots / q.mt;
+        const int slots = d->splitk > 0 ? d->splitk * q.ntap_t : (x6 ? 512 : s4_slots) / q.mt;                         // the bf16-split kernel: two blocks per CU
         q.pre[0] = 0;
         for (int a = 0; a < q.ntap_t; ++a) {
             int sl = ntv[a] ? (int)((double)slots * ntv[a] / tot) : 0;
-            const int64_t nch = (int64_t)d->N * ntv[a] * d->Hq * q.nseg;
+            const int64_t nch = x6 ? ((int64_t)d->N * ntv[a] * d->Hq * q.nseg + 1) / 2 : (int64_t)d->N * ntv[a] * d->Hq * q.nseg;
             if (ntv[a] && sl < 1) sl = 1;
             if (sl > nch / 4 && nch >= 4) sl = (int)(nch / 4);
             if (ntv[a] && sl < 1) sl = 1;
@@ -1682,8 +1879,8 @@ static int wgrad_run(const pc_wgrad_desc* d, const float* D, const float* S, flo
                 for (int i = 0; i < tot_sl; ++i) q.order[i] = (unsigned short)key[i].second;
             }
         }
-        static const int pack3 = getenv("PICONS_WGRAD_STEM_PACK3") ? atoi(getenv("PICONS_WGRAD_STEM_PACK3")) : 1;
-        if ((d->flags & PC_WG_CS3) && pack3) WG_LAUNCH((wgrad4_kernel<28, 7, 2, 7, true>), grid, s, q);
+        if (x6) WG_LAUNCH((wgrad4_x6_kernel<7, 2, 7>), grid, s, q);
+        else if ((d->flags & PC_WG_CS3) && pack3) WG_LAUNCH((wgrad4_kernel<28, 7, 2, 7, true>), grid, s, q);
         else WG_LAUNCH((wgrad4_kernel<28, 7, 2, 7, false>), grid, s, q);
         PC_CHECK_LAUNCH("wgrad4_kernel");
         return PC_OK;
@@ -1814,6 +2011,8 @@ static int wgrad_run(const pc_wgrad_desc* d, const float* D, const float* S, flo
 extern "C" int pc_conv_wgrad(const pc_wgrad_desc* d, const float* D, const float* S, float* g, pc_stream s) {
     return wgrad_run(d, D, S, g, s, nullptr);
 }
+
+extern "C" int pc_wgrad_uses_x6(const pc_wgrad_desc* d) { return d && wg_uses_x6(d) ? 1 : 0; }
 
 extern "C" int pc_wgrad_slices(const pc_wgrad_desc* d) {
     int n = 0;

@@ -572,23 +572,26 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
         }
     } else {
         // src is nsl K-slice images of a split-K weight gradient, sst floats apart (pc_conv_wgrad with ws_slices): added in slice
-        // order, sixteen loads in flight -- the sum does not depend on which block finished when (no atomics anywhere on the way)
-        for (int i = ty; i < J.tr; i += 8) {
-            const int r = r0 + i, c = c0 + tx;
-            float sum = 0.f;
-            if (r < J.R && c < J.Cc) {
-                const float* q = J.src + (size_t)b * J.sbs + (size_t)r * J.sld + c;
+        // order -- the sum does not depend on which block finished when (no atomics anywhere on the way).  A thread owns four consecutive
+        // columns of one row (one 16-byte load per image, eight in flight); J.tr = 8: a quarter of the threads' rows, four times the blocks
+        const int i = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+        if (i < J.tr) {
+            const int r = r0 + i, c = c0 + c4;
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+            if (r < J.R && c < J.Cc) {                     // src_ld % 4 == 0 (checked by the host): the quad lies inside the row (columns >= Cc are padding, never stored)
+                const f32x4* q = (const f32x4*)(J.src + (size_t)b * J.sbs + (size_t)r * J.sld + c);
+                const size_t st4 = (size_t)J.sst / 4;
                 int k = 0;
-                for (; k + 16 <= J.nsl; k += 16) {
-                    float t[16];
+                for (; k + 8 <= J.nsl; k += 8) {
+                    f32x4 t[8];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) t[u] = q[(size_t)(k + u) * J.sst];
+                    for (int u = 0; u < 8; ++u) t[u] = q[(size_t)(k + u) * st4];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) sum += t[u];
+                    for (int u = 0; u < 8; ++u) sum += t[u];
                 }
-                for (; k < J.nsl; ++k) sum += q[(size_t)k * J.sst];
+                for (; k < J.nsl; ++k) sum += q[(size_t)k * st4];
             }
-            tile[i][tx] = sum;
+            tile[i][c4] = sum[0]; tile[i][c4 + 1] = sum[1]; tile[i][c4 + 2] = sum[2]; tile[i][c4 + 3] = sum[3];
         }
     }
     __syncthreads();
@@ -907,7 +910,9 @@ extern "C" int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_st
             k.src = (const float*)(uintptr_t)a.src; k.dst = (float*)(uintptr_t)a.dst; k.sbs = a.src_batch_stride; k.dbs = a.dst_batch_stride;
             PC_CHECK_ARG(a.nslices >= 0 && (a.nslices <= 1 || a.slice_stride > 0), "pc_transpose_multi: job %d has %d slices %lld floats apart", j0 + q, a.nslices, (long long)a.slice_stride);
             k.R = a.R; k.Cc = a.C; k.sld = a.src_ld; k.dld = a.dst_ld; k.accum = a.accum; k.nsl = a.nslices; k.sst = a.slice_stride;
-            k.tr = a.nslices > 4 ? 8 : 32; k.pad_ = 0;
+            PC_CHECK_ARG(a.nslices <= 1 || (a.C <= a.src_ld && a.src_ld % 4 == 0 && a.slice_stride % 4 == 0 && a.src_batch_stride % 4 == 0 && a.src % 16 == 0),
+                         "pc_transpose_multi: job %d sums slice images: src_ld (>= C) and the strides must be multiples of 4 floats and src 16-byte aligned", j0 + q);
+            k.tr = a.nslices > 16 ? 8 : 32; k.pad_ = 0;
             k.tiles_c = cdiv(a.C, 32); k.tiles_rc = k.tiles_c * cdiv(a.R, k.tr);
             pk.first[q] = tiles;
             tiles += a.batch * k.tiles_rc;

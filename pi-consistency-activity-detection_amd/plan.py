@@ -580,7 +580,7 @@ class Plan:
             w["ordered"] = True
         self.issued[(self.cur, capi.OP_WGRAD)] = self.issued.get((self.cur, capi.OP_WGRAD), 0) + _wgrad_flops(d)
         wk = wgrad_work(d)
-        fam = "wgx6_" if (int(d.get("flags", 0)) & capi.WG_X6) and wk["route"] in (1, 3) else "wgf32_"       # the stem / 9-tap routes ignore PC_WG_X6
+        fam = "wgx6_" if capi.lib().pc_wgrad_uses_x6(_wdesc(d)) else "wgf32_"       # the 9-tap spectral route ignores PC_WG_X6
         for key, v in (("mfma", wk["issued"]), ("executed", wk["executed"]), ("valid", wk["valid"])):
             for pre in ("wg_", fam):
                 self.work[(self.cur, pre + key)] = self.work.get((self.cur, pre + key), 0) + 2 * v
@@ -1360,7 +1360,8 @@ class Plan:
 
     def build_backward(self):
         self.cur = "bwd"
-        self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
+        if not self.wg_ordered:       # the atomic split-K form adds into the kernel-layout gradients; the ordered form writes K-slice images (plain stores)
+            self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
         if (self.wg_lane or self.skip_lane) and os.environ.get("PICONS_DEFER_SIDE", "0") != "0":
             self.deferred = []
         for idx, fn in enumerate(reversed(self.tape)):

@@ -38,6 +38,7 @@ def _cold(junk, it):
 # (Ci, Co, k, stride, thw, N, flags, route): route as pc_wgrad_work reports it (0 stem, 1 row-segment, 3 generic split-K)
 ORDERED_CASES = [
     (4, 64, (7, 7, 7), (2, 2, 2), (8, 56, 56), 2, capi.WG_CS3, 0),            # wgrad4_kernel, packed 3-channel columns
+    (4, 64, (7, 7, 7), (2, 2, 2), (8, 56, 56), 2, capi.WG_CS3 | capi.WG_X6, 0),  # wgrad4_x6_kernel (two 16-position sub-chunks per chunk)
     (64, 64, (3, 3, 3), (1, 1, 1), (2, 8, 112), 2, 0, 1),                      # wgrad3_kernel, 56-position segments
     (64, 64, (3, 3, 3), (1, 1, 1), (2, 8, 112), 2, capi.WG_X6, 1),             # wgrad3_x6_kernel<64, 64, 64, 2>
     (64, 192, (3, 3, 3), (2, 1, 1), (4, 6, 56), 2, capi.WG_X6, 1),             # temporal stride 2

@@ -178,6 +178,36 @@ def test_x6_row_segment_wgrad_vs_fp64_and_native(Ci, Co, thw, N, st):
     assert e_x6 < 5e-6
 
 
+@pytest.mark.parametrize("Co,thw,N", [(64, (8, 56, 56), 2), (64, (6, 224, 224), 1), (24, (5, 18, 112), 1)])
+def test_x6_stem_wgrad_vs_fp64_and_native(Co, thw, N):
+    """PC_WG_X6 | PC_WG_CS3 on the stem's 7x7x7 stride-2 weight gradient (round 6: csrc/conv.hip wgrad4_x6_kernel; autograd of Conv3d_1a_7x7,
+    /root/reference/models/pytorch_i3d.py:221-225): chunks of two 16-position sub-chunks incl. rows that are not whole sub-chunks (W = 28 = 16 + 12),
+    the real 112-wide rows, fewer than 64 output channels, odd extents along t / h.  Bar as for every converted kernel: no further from fp64 than
+    the native fp32-MFMA kernel (wgrad4_kernel) on the same launch; operands as the step has them (a clip in [0, 1], a gradient of mixed sign)."""
+    g = torch.Generator().manual_seed(23)
+    k, s = (7, 7, 7), (2, 2, 2)
+    x3 = torch.rand(N, 3, *thw, generator=g)
+    w = torch.zeros(Co, 3, *k, dtype=torch.float64, requires_grad=True)
+    pads = [spec.same_pad(thw[i], k[i], s[i]) for i in range(3)]
+    xp = F.pad(x3.double(), (pads[2][0], pads[2][1], pads[1][0], pads[1][1], pads[0][0], pads[0][1]))
+    y = F.conv3d(xp, w, None, s)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy.double())
+    ref = w.grad.reshape(Co, 3, 343).permute(0, 2, 1)
+    othw = tuple(y.shape[2:]); pf = [p[0] for p in pads]
+    x4 = cl(torch.cat([x3, torch.zeros(N, 1, *thw)], 1))
+    dyg = cl(dy)
+    wd = dict(desc.wgrad(N, othw, Co, Co, thw, 4, 4, k, s, pf), flags=capi.WG_CS3)
+    assert capi.lib().pc_wgrad_uses_x6(ops._fill_struct(capi.WgradDesc(), wd)) == 0
+    assert capi.lib().pc_wgrad_uses_x6(ops._fill_struct(capi.WgradDesc(), dict(wd, flags=capi.WG_CS3 | capi.WG_X6))) == 1
+    nat = ops.conv_wgrad(wd, dyg, x4, torch.zeros(Co, 343, 4, device=DEV))
+    got = ops.conv_wgrad(dict(wd, flags=capi.WG_CS3 | capi.WG_X6), dyg, x4, torch.zeros(Co, 343, 4, device=DEV))
+    assert torch.all(got[:, :, 3] == 0), "padding column of g was written"
+    e_nat, e_x6 = _rel(nat[:, :, :3].cpu(), ref), _rel(got[:, :, :3].cpu(), ref)
+    assert e_x6 <= 1.05 * e_nat + 1e-9, "stem wgrad: bf16-split error %.3e vs native fp32 MFMA %.3e (against fp64)" % (e_x6, e_nat)
+    assert e_x6 < 5e-6
+
+
 @pytest.mark.parametrize("Ci,Co,k,thw,N", [(256, 288, (1, 1, 1), (1, 28, 28), 16), (528, 128, (1, 1, 1), (1, 28, 28), 8), (64, 96, (1, 3, 3), (2, 14, 30), 4)])
 def test_x6_generic_wgrad_vs_fp64_and_native(Ci, Co, k, thw, N):
     """PC_WG_X6 on the generic split-K weight-gradient kernel (the 1x1x1 layers, widths that are not multiples of 28): 64- and 128-row
