@@ -358,6 +358,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29511")
         torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1)
     reducer = eng.make_reducer(force=forced) if (world > 1 or forced) else None
+    if reducer is not None:
+        reducer.diagnostics = True            # comm_wait_ms / exposed_ms of the `reducer` block (off in a training loop)
     ramp = pstep.exp_rampup(100)(a.epoch)
     main_kind = None if a.no_kernel_timing else (capi.OP_CONV_X6 if split_on else capi.OP_CONV)
     ranks_observed = 1
@@ -537,7 +539,7 @@ def main():
                 fam_avg = lambda pred: (lambda ws: (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ws) / max(sum(v["launches"] for v in ws), 1)) if ws else None)(
                     [v for k, v in tj.get("kernels", {}).items() if pred(k)])
                 traffic_of = {"x6": tj.get("conv_x6_hbm_bytes_per_launch"), "f32": tj.get("conv_gemm_hbm_bytes_per_launch"),
-                              "wgx6": fam_avg(lambda k: "wgrad3_x6_kernel" in k or "wgrad_x6_kernel" in k),
+                              "wgx6": fam_avg(lambda k: "wgrad3_x6_kernel" in k or "wgrad_x6_kernel" in k or "wgrad4_x6_kernel" in k),
                               "wgf32": fam_avg(lambda k: ("wgrad4_kernel" in k or "wgrad3_kernel" in k or "wgrad_kernel" in k) and "_x6" not in k),
                               "wino": (lambda ws: (sum(v["hbm_bytes_per_launch"] * v["launches"] for v in ws) / max(sum(v["launches"] for v in ws), 1)) if ws else None)(
                                   [v for k, v in tj.get("kernels", {}).items() if "wino_conv_kernel" in k or "wino4_conv_kernel" in k])}
@@ -590,13 +592,14 @@ def main():
     roof_wgx6 = roof_wgf32 = None
     if main_kind is not None:
         wx, wf = pl.wgrad_flops_by_family()
-        roof_wgx6 = roof("wgrad3_x6_kernel + wgrad_x6_kernel (weight gradients of the 3x3x3 / 1x1x1 / transposed layers on the bf16 matrix cores: both operands split into "
-                         "3 bf16 terms in registers, 6 products, hi / lo fp32 accumulators; K slices summed in slice order by the gradient re-layout, no atomics)",
+        roof_wgx6 = roof("wgrad3_x6_kernel + wgrad_x6_kernel + wgrad4_x6_kernel (weight gradients of the 3x3x3 / 1x1x1 / transposed layers and the RGB stem on the bf16 matrix "
+                         "cores: both operands split into 3 bf16 terms in registers, 6 products, hi / lo fp32 accumulators; K slices summed in slice order by the gradient "
+                         "re-layout, no atomics)",
                          wx["executed"], wx["mfma"], wx["valid"], legs.get("wgx6"), PEAK_BF16_MFMA_TFLOPS / 6.0,
                          {"flops_counted": "executed: real rows x real columns x the positions each K slice walks (pc_wgrad_work)",
                           "peak_note": "dense bf16 MFMA peak / 6 products per fp32 multiply-accumulate", "traffic": traffic_of.get("wgx6"), "traffic_source": traffic_src})
-        roof_wgf32 = roof("wgrad4_kernel + wgrad3_kernel<.., 9> + wgrad_kernel (fp32 MFMA weight gradients: the RGB stem, the 9-tap spectral PrimaryCaps / upsample1 planes, "
-                          "the tail's per-sample classes)", wf["executed"], wf["mfma"], wf["valid"], legs.get("wgf32"), PEAK_FP32_MFMA_TFLOPS,
+        roof_wgf32 = roof("wgrad3_kernel<.., 9> (fp32 MFMA weight gradients: the 9-tap spectral PrimaryCaps / upsample1 planes -- 20-position rows, a k16 step would be "
+                          "37 % padding; with PICONS_SPLIT=0 also wgrad4_kernel / wgrad3_kernel / wgrad_kernel for every other layer)", wf["executed"], wf["mfma"], wf["valid"], legs.get("wgf32"), PEAK_FP32_MFMA_TFLOPS,
                           {"flops_counted": "executed (pc_wgrad_work)", "traffic": traffic_of.get("wgf32"), "traffic_source": traffic_src})
     # `roofline` = the GEMM family with the LARGEST single-stream kernel time per step (the dominant kernel) among ALL FIVE families; the others keep their own blocks
     fam = [r for r in (roof_x6, roof_f32conv, roof_wino, roof_wgx6, roof_wgf32) if r is not None and r.get("kernel_ms_per_step")]
@@ -629,7 +632,13 @@ def main():
                                % (a.bs, "--gv" if a.gv else "--bv --n_frames 5 L2"),
                    "global_batch": world * a.bs, "clip": [3, 8, 224, 224], "parallelism": "dp%d" % world,
                    "epoch": a.epoch, "thresh_epoch": 11, "executed_gflop_per_step_per_gpu": step_exec / 1e9, "inputs": inputs_note,
-                   "bf16_split_conv": split_on},
+                   "bf16_split_conv": split_on,
+                   # which Winograd form each launch takes (a line must say what arithmetic ran) and whether any experiment switch was in force
+                   "winograd_launches": {"F(4x4,3x3)": sum(1 for n in lists for op in pl.lists[n] if op[0] == capi.OP_WINO_CONV and op[1][15] == 4),
+                                         "F(2x2,3x3)": sum(1 for n in lists for op in pl.lists[n] if op[0] == capi.OP_WINO_CONV and op[1][15] != 4)},
+                   "weight_gradients": "K-slice images added in slice order (no atomics)" if pl.wg_ordered else "fp32 atomics between K slices (PICONS_WGRAD_ATOMIC=1)",
+                   "experiment_switches": sorted(k for k in __import__("picons_amd.switches", fromlist=["x"]).EXPERIMENTS
+                                                 if os.environ.get(k) and os.environ.get("PICONS_DIAG_LIB", "0") not in ("", "0"))},
         "loss": last,
         "value_resident": None if resident is None else resident["value"],
         "resident": resident,

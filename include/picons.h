@@ -255,7 +255,8 @@ int pc_bn_finalize_apply(const float* part, int nparts_per_group, int groups, in
 int pc_bn_eval_stat(const float* gamma, const float* beta, const float* running_mean,
                     const float* running_var, float eps, int C, float* stat, pc_stream s);
 /* backward: dy (grad after ReLU, row stride lddy), z -> dz; dgamma/dbeta (+)= if accum.
- * ws: >= pc_bn_bwd_ws_floats(rows,C,groups) floats. */
+ * ws: >= pc_bn_bwd_ws_floats(rows,C,groups) floats.  relu: bit 0 = the layer has a ReLU; bit 1 = the finalize folded into the apply kernel
+ * (two launches instead of three; measured: no gain, the planner never sets it by itself -- switches.py PICONS_BN_FUSED). */
 int64_t pc_bn_bwd_ws_floats(int64_t rows, int C, int groups);
 int pc_bn_bwd(const float* dy, int lddy, const float* z, int ldz, const float* stat, int C,
               int64_t rows, int groups, int relu, float* dz, int lddz, float* dgamma, float* dbeta,

@@ -372,6 +372,8 @@ __global__ __launch_bounds__(256, 1) void wino4_conv_kernel(const Wino4K p) {
     if (wave == 3) k_loop(std::integral_constant<int, 1>{});
     else k_loop(std::integral_constant<int, 0>{});
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // the last MFMAs' results (inline asm: the compiler does not count their latency)
+    __builtin_amdgcn_sched_barrier(0);                           // ... and nothing that reads an accumulator may be scheduled above the nops (a memory
+                                                                 // clobber does not order register reads)
 
     if (VAR & (32 | 64)) stamp[2] = __builtin_amdgcn_s_memtime();
     // ---- epilogue: Y = A^T M A per (tile, channel).  Accumulator register r is tile (r&3) + 8*(r>>2) + 4*(lane>>5), the lane's column is the

@@ -92,6 +92,8 @@ class GradReducer:
         # per-step diagnostics (bench.py's `reducer` block): host time spent in wait(), and -- device side -- how long the main stream sat
         # between the last backward kernel and the last collective's completion (the EXPOSED communication time).  Event pairs are kept
         # pending and read by stats() after a synchronize, so the step itself gains no host wait.
+        # OFF in a training loop (an event pair per step that nobody reads); bench.py and the tests that read stats() switch it on
+        self.diagnostics = False
         self.comm_wait_ms = []
         self._exposed_pending = []
         self._exposed_ms = []
@@ -175,7 +177,7 @@ class GradReducer:
             return
         t0 = time.perf_counter()
         ev = None
-        if self.cuda:
+        if self.cuda and self.diagnostics:
             ev = (self._ev_pool.pop() if self._ev_pool else torch.cuda.Event(enable_timing=True),
                   self._ev_pool.pop() if self._ev_pool else torch.cuda.Event(enable_timing=True))
             ev[0].record(torch.cuda.current_stream())          # behind the backward's last kernel on the main stream
@@ -195,16 +197,21 @@ class GradReducer:
         self._work = {}
         if self.cuda and self.active:
             torch.cuda.current_stream().wait_stream(self.comm_stream)
-            ev[1].record(torch.cuda.current_stream())          # the main stream gets here once every collective has finished
-            self._exposed_pending.append(ev)
-            if len(self._exposed_pending) > 4096:               # nobody reads the diagnostics: do not grow without bound
-                self._ev_pool += list(self._exposed_pending.pop(0))
-        dt = (time.perf_counter() - t0) * 1e3
-        self.comm_wait_ms.append(dt)
-        if len(self.comm_wait_ms) > 65536:
-            del self.comm_wait_ms[:32768]
-        if not self.cuda:
-            self._exposed_ms.append(dt)
+            if ev is not None:
+                ev[1].record(torch.cuda.current_stream())      # the main stream gets here once every collective has finished
+                self._exposed_pending.append(ev)
+                if len(self._exposed_pending) > 4096:           # stats() was never called: give the oldest pair back (both events have long completed)
+                    old = self._exposed_pending.pop(0)
+                    old[1].synchronize()
+                    self._ev_pool += list(old)
+        if self.diagnostics:
+            dt = (time.perf_counter() - t0) * 1e3
+            self.comm_wait_ms.append(dt)
+            if not self.cuda:
+                self._exposed_ms.append(dt)
+            for lst in (self.comm_wait_ms, self._exposed_ms):   # bounded on every path (the gloo path's list used to grow without limit)
+                if len(lst) > 65536:
+                    del lst[:32768]
 
     @property
     def gscale(self):

@@ -182,9 +182,10 @@ def bn_eval_stat(gamma, beta, rm, rv, eps):
     return stat
 
 
-def bn_bwd(dy, lddy, z, ldz, stat, C_, rows, groups, relu, dz, lddz, dgamma, dbeta, accum=False):
+def bn_bwd(dy, lddy, z, ldz, stat, C_, rows, groups, relu, dz, lddz, dgamma, dbeta, accum=False, fused=False):
+    """fused: the finalize folded into the apply kernel (bit 1 of pc_bn_bwd's `relu`)."""
     ws = torch.empty(capi.lib().pc_bn_bwd_ws_floats(int(rows), C_, groups), device=dy.device, dtype=torch.float32)
-    capi.call("pc_bn_bwd", ptr(dy), lddy, ptr(z), ldz, ptr(stat), C_, int(rows), groups, int(relu), ptr(dz), lddz, ptr(dgamma), ptr(dbeta),
+    capi.call("pc_bn_bwd", ptr(dy), lddy, ptr(z), ldz, ptr(stat), C_, int(rows), groups, int(bool(relu)) | (2 if fused else 0), ptr(dz), lddz, ptr(dgamma), ptr(dbeta),
               int(accum), ptr(ws), stream())
     return dz
 

@@ -16,7 +16,7 @@ import os
 
 import numpy as np
 
-from . import capi, desc as D, spec, spectral, tail6
+from . import capi, desc as D, spec, spectral, switches as sw, tail6
 
 ALIGN = 256
 
@@ -48,17 +48,18 @@ def off(ref, nfloats):
 
 class Plan:
     def __init__(self, num_classes=24, hw=224, n=4, groups=2, training=True, jhmdb=False, accum_grads=False, lanes=1, spectral_pc=None,
-                 early_adam=False):
+                 early_adam=False, exp=None):
         """n = clips per forward pass; the batch the kernels see is N = groups*n.
         accum_grads: backward adds into the flat G buffer instead of overwriting it (drop-in nn.Module path,
         where the reference's two forward passes are two separate autograd graphs).
         lanes: HIP streams the runner may use; >1 tags the four branches of every Inception module (and their
         backward) onto separate lanes between FORK/JOIN ops, so the under-filled 14x14 launches overlap."""
         self.acc = 1 if accum_grads else 0
+        self.exp = dict(exp or {})        # experiment switches passed explicitly (switches.py): the environment alone does not select them
         # early_adam: the backward list carries an (un-armed: length 0) Adam op over every parameter but the stem's, on a side lane in
         # front of the stem's backward -- the HBM-bound optimiser pass then runs beside the stem's MFMA-bound weight gradient, the last
         # kernel of the step, instead of behind it.  The caller arms it (StepEngine, single process); see build_backward.
-        self.early_adam = bool(early_adam) and lanes >= 2 and training and os.environ.get("PICONS_EARLY_ADAM", "1") != "0"
+        self.early_adam = bool(early_adam) and lanes >= 2 and training and sw.get("PICONS_EARLY_ADAM", "1") != "0"
         self.op_adam_early, self.adam_split = None, 0
         if hw % 8 or hw // 8 < spec.PRIMARY_K:
             # the reference fails the same way, inside nn.Conv2d (capsules_ucf101.py:43-49: a 9x9 valid conv on the hw/8 feature map)
@@ -75,9 +76,9 @@ class Plan:
         # goes to a side lane too (PICONS_WGRAD_LANE=0 turns it off; a lane of its own with >= 4 lanes, else the skip lane):
         # nothing in the backward waits for a weight gradient except the optimiser, so the dgrad / BatchNorm chain and the wgrad
         # stream overlap, and their blocks fill the slots the under-filled 28x28 launches leave idle.
-        want_skip = os.environ.get("PICONS_SKIP_LANE", "1") != "0" and lanes >= 3
-        want_wg = os.environ.get("PICONS_WGRAD_LANE", "1") != "0" and lanes >= 3
-        own_wg = want_wg and want_skip and lanes >= 4 and os.environ.get("PICONS_WGRAD_SEPARATE", "1") != "0"
+        want_skip = sw.get("PICONS_SKIP_LANE", "1") != "0" and lanes >= 3
+        want_wg = sw.get("PICONS_WGRAD_LANE", "1") != "0" and lanes >= 3
+        own_wg = want_wg and want_skip and lanes >= 4 and sw.get("PICONS_WGRAD_SEPARATE", "1") != "0"
         self.wg_lane = lanes - 1 if want_wg else 0
         self.skip_lane = (lanes - 2 if own_wg else lanes - 1) if want_skip else 0
         self.branch_lanes = lanes - len({ln for ln in (self.wg_lane, self.skip_lane) if ln})
@@ -88,22 +89,22 @@ class Plan:
         # Ordered split-K (round 6): the K slices of a weight gradient leave their partial sums as images in a workspace (plain stores) and
         # the gradient re-layout adds the images in slice order -- no fp32 atomics, no zero fill of the kernel-layout gradient, and every
         # gradient is bit-identical from run to run.  PICONS_WGRAD_ATOMIC=1 restores the atomic epilogue (the A/B switch).
-        self.wg_ordered = os.environ.get("PICONS_WGRAD_ATOMIC", "0") == "0"
+        self.wg_ordered = sw.get("PICONS_WGRAD_ATOMIC", "0") == "0"
         # PrimaryCaps in its row-spectral form (spectral.py): a third of the direct form's FLOPs
-        self.spectral_pc = (os.environ.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
+        self.spectral_pc = (sw.get("PICONS_SPECTRAL", "1") != "0") if spectral_pc is None else bool(spectral_pc)
         # convolutions multiplied on the bf16 matrix cores (csrc/conv_x6.hip: fp32 operands as exact sums of three bf16 terms, six products,
         # fp32 accumulate); PICONS_SPLIT=0 keeps every launch on the fp32 MFMA kernels
-        self.x6 = os.environ.get("PICONS_SPLIT", "1") != "0"
+        self.x6 = sw.get("PICONS_SPLIT", "1") != "0"
         self.wbufs = []           # kernel-layout weight buffers: dict(ref, n floats, lst / lane of the producing ops, planes ref once split)
         self.consts = []          # (arena ref, float32 ndarray): constant tables the owner uploads once (upload_consts)
         self.zero_once = []       # (arena ref, floats): buffers the owner zeroes once (upload_consts): workspaces whose counters every launch leaves zero
         # decoder tail as one five-tap transposed conv with a single output channel (csrc/tail6.hip) instead of the
         # 27-channel form + tap sum
-        self.merged_tail = os.environ.get("PICONS_TAIL6", "1") != "0"
+        self.merged_tail = sw.get("PICONS_TAIL6", "1") != "0"
         # the decoder's forward sits on lane 0 with the side lanes idle: the position classes of a stride-2 transposed conv (8 independent
         # launches of 196 - 784 blocks) are dealt to all lanes, and conv28 (196 blocks, K = 7488) runs on the skip lane beside PrimaryCaps
-        self.spread_classes = lanes >= 2 and os.environ.get("PICONS_SPREAD_CLASSES", "1") != "0"
-        self.conv28_aside = os.environ.get("PICONS_CONV28_ASIDE", "1") != "0"
+        self.spread_classes = lanes >= 2 and sw.get("PICONS_SPREAD_CLASSES", "1") != "0"
+        self.conv28_aside = sw.get("PICONS_CONV28_ASIDE", "1") != "0"
         self.C = num_classes
         self.hw = hw
         self.n = n
@@ -116,7 +117,7 @@ class Plan:
         # Weight-layout prep of everything but the first trunk layers goes to `prep_late`: enqueued on the side lanes behind `prep`
         # and joined inside the forward list before Mixed_3b, so it runs beside the stem / Conv3d_2b / Conv3d_2c instead of in front
         # of them (0.65 ms of the step's critical path).  PICONS_LATE_PREP=0 or a plan without side lanes: everything in `prep`.
-        self.late_prep = bool(self.wg_lane) and os.environ.get("PICONS_LATE_PREP", "1") != "0"
+        self.late_prep = bool(self.wg_lane) and sw.get("PICONS_LATE_PREP", "1") != "0"
         self.prep_target = "prep_late" if self.late_prep else "prep"
         self.cur = "fwd"
         self.tape = []
@@ -129,7 +130,7 @@ class Plan:
         # over their stacked output channels (unit3d with several prefixes): their BN parameters and running statistics
         # sit next to each other in the flat buffers, in that order.  Names and shapes are the reference's; only the
         # offsets inside the flat buffers differ from nn.Module.parameters() order.
-        self.fuse_1x1 = os.environ.get("PICONS_FUSE1X1", "1") != "0"
+        self.fuse_1x1 = sw.get("PICONS_FUSE1X1", "1") != "0"
         self.fused_groups = ([["conv1.%s.%s" % (ent[0], b) for b in ("b1a", "b2a", "b0")] for ent in spec.TRUNK if ent[1] == "mixed"]
                              if self.fuse_1x1 else [])
         head = {g[2] + ".conv3d.weight": g for g in self.fused_groups}      # b0 comes first in reference order
@@ -373,7 +374,7 @@ class Plan:
         """BatchNorm(train) statistics of a Unit3D from the conv's partial rows: either the finalize launch is emitted here (-> None), or --
         few partial rows per batch group AND PICONS_BN_FUSED=1 (off by default: no gain measured) -- the caller folds it into the apply launch (-> what that op needs)."""
         npg = nrows // self.groups
-        if os.environ.get("PICONS_BN_FUSED", "0") != "0" and capi.lib().pc_bn_finalize_apply_ok(int(npg), int(cout)):
+        if sw.exp("PICONS_BN_FUSED", "0", self.exp) != "0" and capi.lib().pc_bn_finalize_apply_ok(int(npg), int(cout)):
             return dict(npg=npg, part=part)
         self.emit(capi.OP_BN_FINALIZE, i=[npg, self.groups, cout], l=[z.rows // self.groups], f=[spec.BN_EPS, spec.BN_MOMENTUM],
                   p=[part, gamma, beta, self.R(pre + ".bn.running_mean"), self.R(pre + ".bn.running_var"), stat, self.bn_fin_ws(npg, cout)])
@@ -391,27 +392,26 @@ class Plan:
         padding, even H, W and enough channels to fill the kernel's 64 x 64 (tiles x channels) block.  The one-frame 28x28 layers
         (Mixed_4b..4f, 1x3x3 once the padding taps are dropped) are 0.97x alone -- 320 whole-CU blocks on 256 CUs -- but 2.25x fewer
         MFMAs in a step whose lanes keep the chip full: kept (PICONS_WINO_T1=0 restores the gather-GEMM form).  PICONS_WINO=0: off."""
-        if os.environ.get("PICONS_WINO", "1") == "0":
+        if sw.get("PICONS_WINO", "1") == "0":
             return False
         if tuple(k) != (3, 3, 3) or tuple(stride[1:]) != (1, 1) or stride[0] not in (1, 2) or (pad is not None and tuple(pad) != (1, 1, 1)):
             return False
         T, H, W = x.thw
-        tmin = 1 if os.environ.get("PICONS_WINO_T1", "1") != "0" else 2     # one frame (Mixed_4b..4f: only the centre temporal tap is real): -0.13 ms on the step
+        tmin = 1 if sw.get("PICONS_WINO_T1", "1") != "0" else 2     # one frame (Mixed_4b..4f: only the centre temporal tap is real): -0.13 ms on the step
         # the input gradient runs the same kernel with the roles swapped: its Ci is cout, read from a gradient tensor whose leading dimension is cout
-        return (T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(os.environ.get("PICONS_WINO_CMIN", "32")) and cout >= 64
+        return (T >= tmin and H % 2 == 0 and W % 2 == 0 and x.C % 8 == 0 and x.C >= int(sw.get("PICONS_WINO_CMIN", "32")) and cout >= 64
                 and cout % 8 == 0 and x.ld % 4 == 0)
 
-    @staticmethod
-    def wino_m(x):
+    def wino_m(self, x):
         """Output tile edge of a Winograd layer: 4 -- F(4x4, 3x3), csrc/wino4.hip: 1.78x fewer MFMAs than F(2x2, 3x3), measured 1.42 - 1.68x
         faster on the 112 x 112 and 56 x 56 layers (tools/bench_wino4.py) -- where H, W are multiples of 4 and a frame has at least
         PICONS_WINO4_MIN_TILES (196 = 56 x 56) tiles.  The 28 x 28 layers stay on F(2x2, 3x3): most of them are slower alone (64 - 192
         whole-CU blocks), the step is 0.3 ms faster with them -- and five step-level parity tests fail (they are the trunk, in
         front of EM routing).  PICONS_WINO4=0: F(2x2, 3x3) everywhere."""
         _T, H, W = x.thw
-        if os.environ.get("PICONS_WINO4", "1") == "0" or H % 4 or W % 4:
+        if sw.get("PICONS_WINO4", "1") == "0" or H % 4 or W % 4:
             return 2
-        return 4 if (H // 4) * (W // 4) >= int(os.environ.get("PICONS_WINO4_MIN_TILES", "196")) else 2
+        return 4 if (H // 4) * (W // 4) >= int(sw.exp("PICONS_WINO4_MIN_TILES", "196", self.exp)) else 2
 
     def wino_weights(self, wname, O, I, need_tr, m=2, m_tr=None):
         """Transform-domain weights of a layer, built per step straight from the master OIDHW parameter (and, for the input
@@ -485,15 +485,15 @@ class Plan:
         weights are a registered kernel-layout buffer that can be split into planes), else unchanged."""
         if not self.x6 or (d["flags"] & capi.F_X6) or self._wbuf_of(w_ref) is None:
             return d
-        if os.environ.get("PICONS_SPLIT_ONLY_SPECTRAL", "0") != "0" and w_ref[0] != "V":     # A/B diagnostics (tools/probe_tensor_grad.py)
+        if sw.exp("PICONS_SPLIT_ONLY_SPECTRAL", "0", self.exp) != "0" and w_ref[0] != "V":     # A/B diagnostics (tools/probe_tensor_grad.py)
             return d
         if w_ref[0] == "V":           # weights that exist as planes only: no choice
             return dict(d, flags=d["flags"] | capi.F_X6) if capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(d), flags=d["flags"] | capi.F_X6))) else d
-        if self.cur not in os.environ.get("PICONS_SPLIT_LISTS", "fwd,bwd").split(","):
+        if self.cur not in sw.exp("PICONS_SPLIT_LISTS", "fwd,bwd", self.exp).split(","):
             return d
-        if not int(os.environ.get("PICONS_SPLIT_CI_MIN", "0")) <= d["Ci"] <= int(os.environ.get("PICONS_SPLIT_CI_MAX", "1000000")):
+        if not int(sw.exp("PICONS_SPLIT_CI_MIN", "0", self.exp)) <= d["Ci"] <= int(sw.exp("PICONS_SPLIT_CI_MAX", "1000000", self.exp)):
             return d
-        if not int(os.environ.get("PICONS_SPLIT_ROWS_MIN", "0")) <= d["N"] * d["Tq"] * d["Hq"] * d["Wq"] <= int(os.environ.get("PICONS_SPLIT_ROWS_MAX", "2000000000")):
+        if not int(sw.exp("PICONS_SPLIT_ROWS_MIN", "0", self.exp)) <= d["N"] * d["Tq"] * d["Hq"] * d["Wq"] <= int(sw.exp("PICONS_SPLIT_ROWS_MAX", "2000000000", self.exp)):
             return d
         t = dict(D.trim_conv(d), flags=d["flags"] | capi.F_X6)
         if not capi.lib().pc_conv_x6_ok(_cdesc(t)):
@@ -533,7 +533,7 @@ class Plan:
             wp, pstride = self.planes_of(w_ref)
             # workspace for the launch's tail split (csrc/conv_x6.hip: the tiles of the last, partly filled round of resident blocks run as K
             # slices); private to the op, its counters zeroed once by the arena's owner (upload_consts) and left zero by every launch
-            n_ws = int(capi.lib().pc_conv_x6_ws_floats(_cdesc(t))) if os.environ.get("PICONS_X6_TAIL_SPLIT", "1") != "0" else 0
+            n_ws = int(capi.lib().pc_conv_x6_ws_floats(_cdesc(t))) if sw.get("PICONS_X6_TAIL_SPLIT", "1") != "0" else 0
             ws = None
             if n_ws > 0:
                 ws = self.alloc(n_ws)
@@ -548,7 +548,7 @@ class Plan:
         launch is only collected: the group leaves as ONE pc_conv_wgrad_multi op.
         w: the weight record (prep_conv_weight / prep_convT_weight) whose re-layout consumes the result -- with ordered split-K the launch
         writes K-slice images into a workspace of its own (p[2] is replaced) and w's re-layout jobs are pointed at them."""
-        if self.x6 and os.environ.get("PICONS_SPLIT_WGRAD", "1") != "0":
+        if self.x6 and sw.get("PICONS_SPLIT_WGRAD", "1") != "0":
             d = dict(d, flags=int(d.get("flags", 0)) | capi.WG_X6)       # row-segment and generic split-K routes (the stem and the 9-tap spectral planes stay fp32)
         if w is not None and self.wg_ordered and int(d.get("splitk", 0)) != -1:
             ns = capi.lib().pc_wgrad_slices(_wdesc(d))
@@ -606,7 +606,7 @@ class Plan:
             return
 
         def emit_all():
-            if len(jobs) == 1 or self.wg_ordered or os.environ.get("PICONS_WGRAD_MULTI", "0") == "0":
+            if len(jobs) == 1 or self.wg_ordered or sw.exp("PICONS_WGRAD_MULTI", "0", self.exp) == "0":
                 for d, p in jobs:
                     self._emit_wgrad(d, p)
             else:
@@ -645,7 +645,7 @@ class Plan:
         # amplifies any perturbation of the trunk's forward arithmetic -- with Conv3d_2c's forward in F(4x4, 3x3) (2.9x the rms rounding error) the
         # stem's BatchNorm gradients sit at 2.0 - 2.4x the fp32 reference's own distance from its fp64 run instead of 1.0 - 1.2x
         wm_b = self.wino_m(x) if wino else 2
-        wm = wm_b if os.environ.get("PICONS_WINO4_TRUNK_FWD", "0") == "1" else 2
+        wm = wm_b if sw.exp("PICONS_WINO4_TRUNK_FWD", "0", self.exp) == "1" else 2
         wu = self.wino_weights(pre + ".conv3d.weight", cout, Ci, need_dx and self.training, wm, wm_b) if wino else None
         fin = None
         tmap_f = (stride[0], -pf[0], 1)                    # forward: tap kt of output frame t reads input frame t * s - pad_front + kt
@@ -670,7 +670,7 @@ class Plan:
             # gate said no.  Per kernel the split is the more accurate of the two, but EM routing amplifies ANY perturbation of the trunk's
             # activations into the trunk's gradients, and with these ~20 launches split one per-tensor bar of the full-size suite
             # (Mixed_4f.b2a.bn.bias, bs-8 JHMDB case) went from 0.80 to 1.06 of its bar; they were worth 0.05 ms.
-            trunk_x6 = os.environ.get("PICONS_SPLIT_TRUNK_FWD", "0") != "0"
+            trunk_x6 = sw.exp("PICONS_SPLIT_TRUNK_FWD", "0", self.exp) != "0"
             if trunk_x6:
                 d = self.maybe_x6(d, w["fwd"])     # the tile (hence the partial rows) is the bf16-split kernel's where that kernel runs
             nrows = _bnpart_rows(d)
@@ -700,7 +700,8 @@ class Plan:
                 dy = self.grad_of(y)
                 dz = st["dz"] = self.tensor(x.N, othw, cout, pre + ".dz")
                 ws = self.alloc(_bn_bwd_ws(z.rows, cout, self.groups))
-                self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1, dz.ld, self.acc], l=[z.rows],
+                fused_bwd = 2 if sw.exp("PICONS_BN_FUSED", "0", self.exp) != "0" else 0       # the planner's decision travels in the op (bit 1 of `relu`)
+                self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1 | fused_bwd, dz.ld, self.acc], l=[z.rows],
                           p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
                 wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
                 wd["Cs_real"] = Ci_real
@@ -753,7 +754,7 @@ class Plan:
             self.unit3d([pre + ".b1a", pre + ".b2a", pre + ".b0"], x, [oc[1], oc[3], oc[0]], one, one, out=wide.slice(0, e + oc[0]))
             # the big 3x3x3 branch on lane 0, pool branch + the small 3x3x3 branch on lane 1 (measured best of four assignments);
             # in the forward the weight-gradient lane is idle and takes the small 3x3x3 branch (PICONS_FWD_BRANCH3=0: off)
-            third = self.wg_lane if (self.wg_lane and os.environ.get("PICONS_FWD_BRANCH3", "1") != "0") else 0
+            third = self.wg_lane if (self.wg_lane and sw.get("PICONS_FWD_BRANCH3", "1") != "0") else 0
             fmask = ((1 << self.branch_lanes) - 2) | (1 << third if third else 0)
             self.fork(fmask)
             self.lane = L(0)
@@ -1003,7 +1004,7 @@ class Plan:
         if self.skip_lane:       # the decoder's concat buffers exist before the trunk so the skip convs can write into them early
             cat56 = self.tensor(N, (2, 2 * s28e, 2 * s28e), 128, "cat56")
             cat112 = self.tensor(N, (4, 4 * s28e, 4 * s28e), 128, "cat112")
-        pending_skip, skip_after = [], os.environ.get("PICONS_SKIP_FWD_AFTER", "")
+        pending_skip, skip_after = [], sw.exp("PICONS_SKIP_FWD_AFTER", "", self.exp)
         for ent in spec.TRUNK:
             name = "conv1." + ent[0]
             if ent[0] == "Mixed_3b" and self.late_prep:
@@ -1072,7 +1073,7 @@ class Plan:
             sm = {k: self.const(v) for k, v in spectral.matrices(xd.thw[2], KP).items()}
             pl = self.next_prep_lane()
             nW = SL.G * SL.w_g
-            x6_pc = self.x6 and os.environ.get("PICONS_SPLIT_SPECTRAL", "1") != "0" and all(capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(dd), flags=dd["flags"] | capi.F_X6))) for dd in [SL.conv()] + SL.dgrad())
+            x6_pc = self.x6 and sw.get("PICONS_SPLIT_SPECTRAL", "1") != "0" and all(capi.lib().pc_conv_x6_ok(_cdesc(dict(D.trim_conv(dd), flags=dd["flags"] | capi.F_X6))) for dd in [SL.conv()] + SL.dgrad())
             if x6_pc:
                 # the 2 x 167 M-element weight planes leave the producer as bf16 terms (6 B per element): no fp32 copy exists, the
                 # "fp32" references below are virtual addresses that only locate a group inside the planes
@@ -1299,7 +1300,7 @@ class Plan:
                     jobs, self.wgrad_collect = self.wgrad_collect, None
                     self.wjobs = getattr(self, "wjobs", [])
                     self.wjobs.append(jobs)
-                    if os.environ.get("PICONS_WGRAD_MULTI_TAIL", "0") == "0":
+                    if sw.exp("PICONS_WGRAD_MULTI_TAIL", "0", self.exp) == "0":
                         for d_, p_ in jobs:
                             self._emit_wgrad(d_, p_)
                     else:
@@ -1362,7 +1363,7 @@ class Plan:
         self.cur = "bwd"
         if not self.wg_ordered:       # the atomic split-K form adds into the kernel-layout gradients; the ordered form writes K-slice images (plain stores)
             self.emit(capi.OP_FILL, p=[self.kg_base], l=[self.kg_used // 4], f=[0.0])
-        if (self.wg_lane or self.skip_lane) and os.environ.get("PICONS_DEFER_SIDE", "0") != "0":
+        if (self.wg_lane or self.skip_lane) and sw.exp("PICONS_DEFER_SIDE", "0", self.exp) != "0":
             self.deferred = []
         for idx, fn in enumerate(reversed(self.tape)):
             if self.early_adam and idx == len(self.tape) - 1:

@@ -12,7 +12,7 @@ from types import SimpleNamespace
 import numpy as np
 import torch
 
-from . import capi, ops, spec, synthetic
+from . import capi, ops, spec, switches as sw, synthetic
 from .plan import Plan
 
 
@@ -36,11 +36,12 @@ def exp_rampup(rampup_length):
 
 
 class StepEngine:
-    def __init__(self, args, bs=8, hw=224, num_classes=24, device="cuda:0", jhmdb=False, state=None, seed=47, lanes=None):
+    def __init__(self, args, bs=8, hw=224, num_classes=24, device="cuda:0", jhmdb=False, state=None, seed=47, lanes=None, exp=None):
         if not torch.cuda.is_available():
             raise RuntimeError("StepEngine needs a GPU: the hot path is HIP-only (no CPU fallback)")
         capi.lib()
         self.args = args
+        self.exp = dict(exp or {})          # experiment switches passed explicitly (switches.py)
         self.dev = torch.device(device)
         torch.cuda.set_device(self.dev)
         self.bs = bs
@@ -50,16 +51,16 @@ class StepEngine:
         if lanes is None:
             # measured best on MI355X: lane 1 for the second Inception branch, lane 2 for the decoder's skip convs,
             # lane 3 for the weight gradients
-            lanes = int(os.environ.get("PICONS_LANES", "4"))
-        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes, early_adam=True)
+            lanes = int(sw.get("PICONS_LANES", "4"))
+        p = Plan(num_classes, hw, n=bs, groups=2, training=True, jhmdb=jhmdb, lanes=lanes, early_adam=True, exp=self.exp)
         self.side = [torch.cuda.Stream(device=self.dev) for _ in range(lanes - 1)]   # lanes 1.. of the op lists
         # ROCm binds a stream to one of its (by default four) hardware queues when the stream is first used, and two lanes on one
         # hardware queue serialise: use the lanes, in order, before anything else in this process creates work on another stream
         # (the collectives of a process group, the loss read-back stream) -- GPU_MAX_HW_QUEUES != 4 is 3-25 % slower
-        if os.environ.get("PICONS_BIND_LANES", "1") != "0":
+        if sw.exp("PICONS_BIND_LANES", "1", self.exp) != "0":
             tick = torch.zeros(64, device=self.dev)
             order = [torch.cuda.current_stream(self.dev)] + self.side
-            perm = os.environ.get("PICONS_BIND_ORDER")             # diagnostic: e.g. "0,3,2,1"
+            perm = sw.exp("PICONS_BIND_ORDER", "", self.exp)             # diagnostic: e.g. "0,3,2,1"
             if perm:
                 order = [order[int(q)] for q in perm.split(",") if int(q) < len(order)]
             for st in order:
@@ -68,7 +69,7 @@ class StepEngine:
             torch.cuda.synchronize(self.dev)
         # PICONS_PRIO=1: lane 0 (the dependency chain) on a high-priority stream of its own, so its workgroups win the CU slots and
         # the side lanes fill what is left
-        self.main = torch.cuda.Stream(device=self.dev, priority=-1) if (lanes > 1 and os.environ.get("PICONS_PRIO", "0") != "0") else None
+        self.main = torch.cuda.Stream(device=self.dev, priority=-1) if (lanes > 1 and sw.exp("PICONS_PRIO", "0", self.exp) != "0") else None
         p.build_forward()
         p.build_loss(args)
         p.build_backward()
@@ -335,7 +336,7 @@ class StepEngine:
         self.arm_early_adam(lr, on=False)
         k = self.plan.op_adam_early
         ok = (k is not None and reducer is not None and reducer.active and reducer.cuda and not reducer.host_staged
-              and os.environ.get("PICONS_EARLY_ADAM_DP", "1") != "0")
+              and sw.get("PICONS_EARLY_ADAM_DP", "1") != "0")
         self._early_dp = bool(ok)
 
     def adam(self, lr, gscale=1.0):
@@ -402,7 +403,7 @@ class StepEngine:
     def make_reducer(self, group=None, target_floats=3_000_000, force=False, check=True):
         """check: refuse to train if the ranks do not hold identical parameters (dist.check_replicas_agree: one 3-number all-reduce)."""
         from . import dist as pdist
-        joined = os.environ.get("PICONS_BUCKETS_JOINED", "0") != "0"      # A/B switch: buckets only where lane 0 has joined their lane
+        joined = sw.exp("PICONS_BUCKETS_JOINED", "0", self.exp) != "0"      # A/B switch: buckets only where lane 0 has joined their lane
         if check:
             pdist.check_replicas_agree(self.P, group)
         return pdist.GradReducer(self.G, self.plan.grad_buckets(target_floats, joined=joined), group, force=force)
@@ -473,7 +474,7 @@ class HostDictStager:
         # A normal-priority stream.  (A high-priority one -- a hardware queue of its own instead of sharing a lane's, DESIGN.md 5 -- was measured
         # and is SLOWER: the staged step 19.92 - 20.04 ms against 19.33 - 19.43, tools/gpu/r04_o.sh: its kernels then pre-empt the lanes' blocks.
         # PICONS_STAGE_STREAM_PRIO=-1 selects it.)
-        self.copy_stream = torch.cuda.Stream(device=eng.dev, priority=int(os.environ.get("PICONS_STAGE_STREAM_PRIO", "0")))
+        self.copy_stream = torch.cuda.Stream(device=eng.dev, priority=int(sw.exp("PICONS_STAGE_STREAM_PRIO", "0", eng.exp)))
         self.ready = [torch.cuda.Event(), torch.cuda.Event()]
         self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
         self.used = [False, False]
@@ -481,7 +482,7 @@ class HostDictStager:
         # the 180 MB gather is 24 sample-sized memcpys: one thread moves ~5 GB/s (33 ms per step, more than the step itself); tensor.copy_
         # releases the GIL, so a small pool brings it to a few ms
         from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(max_workers=int(os.environ.get("PICONS_STAGE_THREADS", "8"))) if host else None
+        self.pool = ThreadPoolExecutor(max_workers=int(sw.get("PICONS_STAGE_THREADS", "8"))) if host else None
         if not hasattr(eng, "_to_ndhwc_orig"):
             eng._to_ndhwc_orig = {idx: (int(eng.ops["fwd"][idx]["i"][0]), int(eng.ops["fwd"][idx]["p"][0])) for idx in eng.plan.op_to_ndhwc}
 

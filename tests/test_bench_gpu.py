@@ -62,10 +62,12 @@ def test_bench_line_contract():
     assert w["launches_per_step"] >= 8 and 0.2 < w["frac"] <= w["frac_mfma_issued"] < 1.0 and w["direct_equivalent_tflops"] > w["achieved"]
     gx, gf = j["roofline_wgrad_x6"], j["roofline_wgrad_fp32"]  # the weight gradients: bf16-split launches against bf16 peak / 6, the fp32 ones against 157.3
     assert abs(gx["peak"] - 2500.0 / 6) < 1e-6 and "wgrad3_x6_kernel" in gx["kernel"] and gx["launches_per_step"] >= 30 and 0.1 < gx["frac"] <= gx["frac_mfma_issued"] < 1.0
-    assert gf["peak"] == 157.3 and "wgrad4_kernel" in gf["kernel"] and 3 <= gf["launches_per_step"] <= 16 and 0.1 < gf["frac"] <= gf["frac_mfma_issued"] < 1.0
+    assert gf["peak"] == 157.3 and "wgrad3_kernel<.., 9>" in gf["kernel"] and 2 <= gf["launches_per_step"] <= 16 and 0.1 < gf["frac"] <= gf["frac_mfma_issued"] < 1.0
+    assert "wgrad4_x6_kernel" in gx["kernel"]            # the stem's weight gradient runs on the bf16 split since round 6
     assert gx["launches_per_step"] + gf["launches_per_step"] >= 46
     wg_gf = (gx["flops_per_launch"] * gx["launches_per_step"] + gf["flops_per_launch"] * gf["launches_per_step"]) / 1e9
     assert abs(wg_gf - j["roofline_step"]["gflop_by_family"]["wgrad"]) < 1e-3 * wg_gf            # the two legs' numerators are the whole family's FLOPs
+    assert j["config"]["winograd_launches"] == {"F(4x4,3x3)": 5, "F(2x2,3x3)": 21} and j["config"]["experiment_switches"] == [] and "no atomics" in j["config"]["weight_gradients"]
     fam = j["roofline_step"]["gflop_by_family"]
     assert fam["conv_bf16_split"] > fam["conv_fp32_mfma"] > 0 and fam["wgrad"] > 0 and fam["winograd_conv"] > 0
     dc = j["dict_contract"]                                 # the reference's float64 host dicts inside the timed region

@@ -27,7 +27,8 @@ def test_header_symbols_exported(built):
     for n in names:
         assert hasattr(built, n), "libpicons.so does not export %s" % n
     assert sorted(n for n in names) == sorted(capi.EXPORTS), set(names) ^ set(capi.EXPORTS)
-    assert built.pc_version() >= 100
+    assert built.pc_version() == capi.ABI_VERSION            # the library and the Python mirror of include/picons.h agree (capi.lib() refuses otherwise)
+    assert ("#define PC_VERSION %d" % capi.ABI_VERSION) in hdr
 
 
 def test_product_library_holds_no_wrong_result_diagnostics(built):
@@ -44,6 +45,33 @@ def test_product_library_holds_no_wrong_result_diagnostics(built):
     env.pop("PICONS_DIAG_LIB", None)
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT)
     assert p.returncode != 0 and "diagnostic build" in p.stderr
+
+
+def test_experiment_switches_do_not_reach_the_product_plan(built, monkeypatch):
+    """the switches that select arithmetic the parity suite REJECTED (F(4x4, 3x3) in front of EM routing, the trunk's forward convs
+    on the bf16 split) or configurations measured to give nothing are honoured only with PICONS_DIAG_LIB=1 or when passed explicitly
+    (picons_amd/switches.py).  A default plan built with every one of them set in the environment is identical, op for op, to one built
+    without; passed explicitly they do change the plan."""
+    from picons_amd import step as pstep, switches as sw
+    from picons_amd.plan import Plan
+
+    def build(exp=None):
+        p = Plan(24, 112, n=1, groups=2, lanes=4, early_adam=True, exp=exp)
+        p.build_forward(); p.build_loss(pstep.default_args(bv=True, n_frames=5)); p.build_backward(); p.build_adam(); p.finalize()
+        return [(n, [(op[0], tuple(op[1]), tuple(op[2]), tuple(map(str, op[3])), tuple(op[4]), op[5]) for op in lst]) for n, lst in p.lists.items()]
+    monkeypatch.delenv("PICONS_DIAG_LIB", raising=False)
+    base = build()
+    values = {"PICONS_WINO4_MIN_TILES": "49", "PICONS_SKIP_FWD_AFTER": "Mixed_3c", "PICONS_SPLIT_LISTS": "fwd", "PICONS_SPLIT_CI_MAX": "64",
+              "PICONS_SPLIT_ROWS_MAX": "1000", "PICONS_BIND_ORDER": "0,3,2,1"}
+    for name in sw.EXPERIMENTS:
+        monkeypatch.setenv(name, values.get(name, "1"))
+    assert build() == base, "an experiment switch in the environment changed the product plan"
+    assert sw.exp("PICONS_WINO4_TRUNK_FWD", "0") == "0" and sw.exp("PICONS_WINO4_TRUNK_FWD", "0", {"PICONS_WINO4_TRUNK_FWD": "1"}) == "1"
+    for name in sw.EXPERIMENTS:
+        monkeypatch.delenv(name)
+    assert build({"PICONS_BN_FUSED": "1"}) != base
+    with pytest.raises(AssertionError):
+        sw.get("PICONS_BN_FUSED", "0")                  # an experiment cannot be read as a product switch
 
 
 def test_struct_layouts_match_header(built):

@@ -135,6 +135,7 @@ def _skew_worker(rank, world, port, nparams, buckets, q):
     pdist.init_from_env("gloo")
     flat = torch.randn(nparams, generator=torch.Generator().manual_seed(200 + rank))
     red = pdist.GradReducer(flat, buckets)
+    red.diagnostics = True                                 # off by default (a training loop reads no statistics); bench.py switches it on
     rng = np.random.default_rng(rank)
     for i in range(len(buckets)):                          # every rank reaches a bucket's launch point at its own host time
         time.sleep(float(rng.uniform(0.0, 0.05)) * (1 + (rank + i) % 3))

@@ -422,10 +422,10 @@ def test_bn_finalize_folded_into_apply_matches_the_two_launches(rows_g, C, ld, n
 
 @pytest.mark.parametrize("fused", ["0", "1"])
 @pytest.mark.parametrize("rows_g,C", [(6272, 512), (12544, 112), (20000, 64)])
-def test_bn_backward_both_forms_vs_autograd(rows_g, C, fused, monkeypatch):
-    """pc_bn_bwd in its three-launch form (default) and with the finalize folded into the apply kernel (PICONS_BN_FUSED=1, read per call; layers of
+def test_bn_backward_both_forms_vs_autograd(rows_g, C, fused):
+    """pc_bn_bwd in its three-launch form (default) and with the finalize folded into the apply kernel (bit 1 of its `relu` argument; layers of
     <= 16 384 rows per group) against torch autograd of BatchNorm(train) + ReLU in float64, two batch groups."""
-    monkeypatch.setenv("PICONS_BN_FUSED", fused)
+    fused = fused == "1"
     g = torch.Generator().manual_seed(C)
     groups, rows = 2, 2 * rows_g
     z = torch.randn(rows, C, generator=g, dtype=torch.float64) * 2 + 0.3
@@ -444,12 +444,12 @@ def test_bn_backward_both_forms_vs_autograd(rows_g, C, fused, monkeypatch):
         stat[i, 0], stat[i, 1] = mean.float().to(DEV), inv.float().to(DEV)
         stat[i, 2], stat[i, 3] = (gamma.detach() * inv).float().to(DEV), (beta.detach() - mean * gamma.detach() * inv).float().to(DEV)
     dz = torch.empty(rows, C, device=DEV); dgam = torch.zeros(C, device=DEV); dbet = torch.zeros(C, device=DEV)
-    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dgam, dbet)
+    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dgam, dbet, fused=fused)
     close(dz.cpu(), zr.grad, rtol=2e-4, atol=2e-5, what="dz")
     close(dgam.cpu(), gamma.grad, rtol=2e-4, atol=2e-3, what="dgamma")
     close(dbet.cpu(), beta.grad, rtol=2e-4, atol=2e-3, what="dbeta")
     dg2 = dgam.clone(); db2 = dbet.clone()
-    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dg2, db2, accum=True)
+    ops.bn_bwd(dy.float().to(DEV), C, zg, C, stat, C, rows, groups, True, dz, C, dg2, db2, accum=True, fused=fused)
     assert torch.allclose(dg2, 2 * dgam, rtol=1e-6, atol=1e-6) and torch.allclose(db2, 2 * dbet, rtol=1e-6, atol=1e-6)
 
 

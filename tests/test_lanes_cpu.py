@@ -23,9 +23,9 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_CONV_X6: (4, 5, 6), capi.OP_SPLIT_PLANES: (1,), capi.OP_WSPEC_MASTER_PLANES: (2, 3), capi.OP_WGRAD_FOLD: (0,)}
 
 
-def _plan(lanes, bs=1, hw=112, early_adam=False):
+def _plan(lanes, bs=1, hw=112, early_adam=False, exp=None):
     args = pstep.default_args(bv=True, n_frames=5)
-    p = Plan(24, hw, n=bs, groups=2, lanes=lanes, early_adam=early_adam)
+    p = Plan(24, hw, n=bs, groups=2, lanes=lanes, early_adam=early_adam, exp=exp)
     p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
     p.finalize()
     return p
@@ -164,9 +164,8 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
 
 
 def test_inception_wgrads_as_grouped_launches(monkeypatch):
-    monkeypatch.setenv("PICONS_WGRAD_MULTI", "1"); monkeypatch.setenv("PICONS_WGRAD_MULTI_TAIL", "1")
     monkeypatch.setenv("PICONS_WGRAD_ATOMIC", "1")           # grouped launches exist in the atomic split-K form only (no K-slice workspaces)
-    p = _plan(4)
+    p = _plan(4, exp={"PICONS_WGRAD_MULTI": "1", "PICONS_WGRAD_MULTI_TAIL": "1"})      # experiment switches: passed explicitly (switches.py)
     _check_list(p, p.lists["bwd"], 4)
     assert sorted(len(j) for j in p.wjobs) == [4] * 7 + [8]
     assert sum(1 for op in p.lists["bwd"] if op[0] == capi.OP_WGRAD_MULTI) == 8

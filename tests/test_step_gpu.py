@@ -392,16 +392,16 @@ def test_stacked_1x1_units_match_separate_units(monkeypatch):
     assert (num / den) ** 0.5 < 2e-4
 
 
-def test_batchnorm_finalize_folded_into_apply_matches_default(monkeypatch):
-    """PICONS_BN_FUSED=1 (round 5; off by default -- no gain measured): the 28 x 28 layers' BatchNorm statistics are taken in the prologue of the
+def test_batchnorm_finalize_folded_into_apply_matches_default():
+    """PICONS_BN_FUSED (round 5; an EXPERIMENT switch -- no gain measured: passed explicitly, the environment alone does not select it,
+    picons_amd/switches.py): the 28 x 28 layers' BatchNorm statistics are taken in the prologue of the
     apply kernels, forward (PC_OP_BN_FIN_APPLY in the plan) and backward (pc_bn_bwd's two-launch form).  Against the default engine on the same
     minibatch: same outputs, scalars, running statistics and gradients (the per-channel sums are taken in fp64 in another fixed order)."""
     args = pstep.default_args(bv=True, n_frames=5, wt_cons=0.1)
     lab, unl, perm, drops = synthetic.make_step_inputs(2, step=2, hw=112)
     res = []
     for fused in ("0", "1"):
-        monkeypatch.setenv("PICONS_BN_FUSED", fused)
-        eng = pstep.StepEngine(args, bs=2, hw=112)
+        eng = pstep.StepEngine(args, bs=2, hw=112, exp={"PICONS_BN_FUSED": fused})
         nfa = sum(1 for op in eng.plan.lists["fwd"] if op[0] == capi.OP_BN_FIN_APPLY)
         assert (nfa > 10) if fused == "1" else (nfa == 0)
         eng.stage(lab, unl, perm, drops)
