@@ -36,6 +36,7 @@ struct WinoK {
     int Ti, ta, tc, tden;
     int btw_magic;
     int rpitch, rhalf;                      // raw-patch image: positions per patch row / offset of the odd columns inside a row (choose_pitch)
+    int strip, nsp;                         // strip mode (below): blocks per pair of planes = strips per plane
 };
 
 constexpr int WT = 64;            // tiles per block (rows of the transform-domain GEMMs)
@@ -95,6 +96,12 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, long long sO, l
 //      four B^T rows): 12 ds_read_b128 of R, 16 float4 adds, 8 ds_write_b128 (the XOR keeps the two halves of a store group on different banks),
 //   U  the transformed weights, contiguous in HBM by construction.
 // R runs two chunks ahead (its DMA has a whole chunk to land), U one; one barrier per chunk.
+// STRIP MODE (round 6; frames whose tile grid is a multiple of 14 wide: the 28 x 28 and 56 x 56 layers).  A 14 x 14-tile frame in 64-tile
+// rectangles is four blocks of 49 tiles: 49 of 64 tile slots multiply real data.  Instead a block is TWO strips of 2 x 14 tiles (56 of 64
+// slots), each with its own 6 x 30 raw patch, taken from the strips of a PAIR of planes (n, n + 1) of the same t in order: seven blocks per two
+// 28 x 28 frames instead of eight; only the middle block of a pair has its strips in two different planes (same t, so the same temporal taps
+// and weight chunks).  Everything behind the patch fetch and in front of the output store is unchanged: tile (row li of 4, column lj of 14)
+// of the block reads patch rows 6 (li / 2) + 2 (li % 2) .. + 3.
 // VAR (diagnostics, PICONS_WINO_VARIANT; results are WRONG with bits 1-8): 1 = no patch DMA, 2 = no U DMA, 4 = no transform stores,
 // 8 = no output stores, 32 = s_memtime stamps of prologue / K loop / epilogue per block into bnpart (4 x u64 per block).
 constexpr int RMAX = 12;          // 1 KiB DMA pieces of one raw patch image (three per wave): up to 384 positions (an 8 x 8 tile block has 18 x 18 = 324)
@@ -113,10 +120,20 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int ct = sb % p.nct; sb /= p.nct;
     const int sblock = sb;             // spatial block id (n, t, bh, bw): the BatchNorm partial row
     const int bw = sb % p.nbw; sb /= p.nbw;
-    const int bh = sb % p.nbh; sb /= p.nbh;
-    const int t = sb % p.T, n = sb / p.T;
-    const int PW = 2 * p.BTW + 2, PH = 2 * p.BTH + 2, npos = PH * PW;
+    int bh = 0, t, n, dn = 0, tia = 0, tib = 0;        // strip mode: tile row of the first / second strip in its plane, second strip's plane = n + dn
+    if (p.strip) {
+        const int sp = sb % p.nsp; sb /= p.nsp;
+        t = sb % p.T;
+        const int ga = 2 * sp, gb = ga + 1, pa = ga >= p.nsp ? 1 : 0, pb = gb >= p.nsp ? 1 : 0;    // strips ga, gb of the pair's 2 nsp; nsp strips per plane
+        n = 2 * (sb / p.T) + pa; dn = pb - pa;
+        tia = 2 * (ga - pa * p.nsp); tib = 2 * (gb - pb * p.nsp);
+    } else {
+        bh = sb % p.nbh; sb /= p.nbh;
+        t = sb % p.T; n = sb / p.T;
+    }
+    const int PW = 2 * p.BTW + 2, PH = p.strip ? 12 : 2 * p.BTH + 2, npos = PH * PW;
     const int h0 = 2 * bh * p.BTH - 1, w0 = 2 * bw * p.BTW - 1;          // image position of patch position (0, 0)
+    const unsigned dn_in = (unsigned)((size_t)dn * p.Ti * p.H * p.W * p.ldi * 4);      // byte distance of the second strip's plane (same t, next n)
 
     // raw-patch DMA role: piece j of this wave is piece wave + 4 j of the image; lane -> (position q = piece * 32 + lane / 2, 4-channel half)
     unsigned roff[3];                  // byte offset inside the source plane, DMA_OOB for padding positions (the DMA writes zeros there)
@@ -126,9 +143,10 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         const int pr = q / p.rpitch, rem = q - pr * p.rpitch;
         const int odd = rem >= p.rhalf ? 1 : 0, idx = rem - odd * p.rhalf;
         const int pc = 2 * idx + odd;
-        const int h = h0 + pr, w = w0 + pc;
+        const int second = (p.strip && pr >= 6) ? 1 : 0;                 // patch rows 6 .. 11: the second strip's 6 x 30 patch
+        const int h = p.strip ? 2 * (second ? tib : tia) - 1 + (pr - 6 * second) : h0 + pr, w = w0 + pc;
         const bool ok = pr < PH && idx < p.BTW + 1 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
-        roff[j] = ok ? (unsigned)(((h * p.W + w) * p.ldi + (lane & 1) * 4) * 4) : DMA_OOB;
+        roff[j] = ok ? (unsigned)(((h * p.W + w) * p.ldi + (lane & 1) * 4) * 4) + (second ? dn_in : 0u) : DMA_OOB;
     }
     const unsigned uoff = lane * 16;   // U pieces are contiguous images
 
@@ -136,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int ttile = (wave & 1) * 32 + (lane >> 1), tkh = lane & 1, thalf = wave >> 1;
     const int tli = ttile / p.BTW, tlj = ttile - tli * p.BTW;
     const bool tval = ttile < p.BTH * p.BTW;       // (tiles beyond the image read zero lines: their patch positions are padding)
-    const int rbase = tval ? (((2 * tli + thalf) * p.rpitch + tlj) * 2 + tkh) * 4 : tkh * 4;      // float offset of patch (row thalf, col 0) in R
+    const int rbase = tval ? (((2 * tli + thalf + (p.strip ? 2 * (tli >> 1) : 0)) * p.rpitch + tlj) * 2 + tkh) * 4 : tkh * 4;      // float offset of patch (row thalf, col 0) in R
     // temporal taps whose source frame exists: tap kt reads input frame (t * ta + kt + tc) / tden when that is an integer in [0, Ti)
     int nkt = 0, ktl0 = 0, ktl1 = 0, ktl2 = 0, ttl0 = 0, ttl1 = 0, ttl2 = 0;
     for (int kt = 0; kt < p.KT; ++kt) {
@@ -312,7 +330,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     for (int r = 0; r < 16; ++r) {
         const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;      // m / BTW for m < 64 (exact: magic = ceil(65536 / BTW))
-        const int oi = bh * p.BTH + li, oj = bw * p.BTW + lj;
+        const int second = (p.strip && li >= 2) ? 1 : 0;
+        const int oi = p.strip ? (second ? tib : tia) + (li & 1) : bh * p.BTH + li, oj = bw * p.BTW + lj;
         const bool ok = cval && m < p.BTH * p.BTW && oi < p.TH && oj < p.TW;
         float s[4][2];
 #pragma unroll
@@ -335,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
                 s1 += v; s2 += v * v;
                 if (p.act == PC_ACT_RELU) v = fmaxf(v, 0.f);
                 if (vec_ok) { Tst[((2 * li + a) * OW2 + 2 * lj + b) * WC + wn * 32 + (lane & 31)] = v; continue; }
-                float* o = obase + ((size_t)(2 * oi + a) * p.W + 2 * oj + b) * p.ldo;
+                float* o = obase + (second ? (size_t)dn * p.T * plane_out : 0) + ((size_t)(2 * oi + a) * p.W + 2 * oj + b) * p.ldo;
                 if (accum) v += *o;
                 if (!(VAR & 8) || v == 12345.678f) *o = v;
             }
@@ -349,10 +368,11 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
 #pragma unroll 4
             for (int pos = tid >> 4; pos < npo; pos += 16) {
                 const int lr = ((pos >> 1) * p.btw_magic) >> 16, lc = pos - lr * OW2;       // pos / (2 BTW)
-                const int orow = 2 * bh * p.BTH + lr, ocol = 2 * bw * p.BTW + lc;
+                const int second = (p.strip && lr >= 4) ? 1 : 0;                            // output rows 4 .. 7 of the block: the second strip
+                const int orow = p.strip ? 2 * (second ? tib : tia) + (lr & 3) : 2 * bh * p.BTH + lr, ocol = 2 * bw * p.BTW + lc;
                 if (orow >= 2 * p.TH || ocol >= 2 * p.TW) continue;
                 f32x4 v = *(const f32x4*)(Tst + pos * WC + c4 * 4);
-                float* o = ob + ((size_t)orow * p.W + ocol) * p.ldo;
+                float* o = ob + (second ? (size_t)dn * p.T * plane_out : 0) + ((size_t)orow * p.W + ocol) * p.ldo;
                 if (accum) v += *(const f32x4*)o;
                 *(f32x4*)o = v;
             }
@@ -395,8 +415,8 @@ void choose_block(int TH, int TW, int& bth, int& btw) {
 // conflict-free when its 8 tiles sit on 8 different 32-byte positions modulo 8.  Tiles of one tile row are consecutive positions of a
 // parity block; tiles of different rows are 2 rpitch apart per row -- pick the pitch (>= the patch width, image <= RMAX * 32 positions)
 // with the fewest extra LDS cycles over all groups of both wave halves.
-void choose_pitch(int bth, int btw, int& rpitch, int& rhalf) {
-    const int PW = 2 * btw + 2, PH = 2 * bth + 2;
+void choose_pitch(int bth, int btw, int& rpitch, int& rhalf, bool strip = false) {
+    const int PW = 2 * btw + 2, PH = strip ? 12 : 2 * bth + 2;
     rhalf = btw + 1;
     static const int lanes[2][16] = {{0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27}, {4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31}};
     int best = 1 << 30;
@@ -410,7 +430,7 @@ void choose_pitch(int bth, int btw, int& rpitch, int& rhalf) {
                     const int tile = half * 16 + (lanes[gset][q] >> 1);
                     if (tile >= bth * btw) continue;
                     const int ti = tile / btw, tj = tile - ti * btw;
-                    const int c = ++cnt[(2 * ti * pitch + tj) & 7];
+                    const int c = ++cnt[((2 * ti + (strip ? 2 * (ti >> 1) : 0)) * pitch + tj) & 7];
                     mx = c > mx ? c : mx;
                 }
                 cost += mx > 1 ? mx - 1 : 0;
@@ -430,7 +450,13 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     k.N = d->N; k.T = d->T; k.H = d->H; k.W = d->W; k.Ci = d->Ci; k.ldi = d->ldi; k.Co = d->Co; k.ldo = d->ldo;
     k.TH = d->H / 2; k.TW = d->W / 2;
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
-    choose_pitch(k.BTH, k.BTW, k.rpitch, k.rhalf);
+    // strip mode (kernel header): tile grids a multiple of 14 wide and an even number of tile rows high, planes paired (n, n + 1) -- N % 4 == 0 keeps
+    // a pair inside one BatchNorm batch group (groups <= 2: the partial rows of a block belong to one group)
+    static const int strips = getenv("PICONS_WINO_STRIPS") ? atoi(getenv("PICONS_WINO_STRIPS")) : 1;
+    k.strip = strips && k.TW % 14 == 0 && k.TH % 2 == 0 && d->N % 4 == 0 && (int64_t)2 * d->Ti * d->H * d->W * d->ldi * 4 < 0xff000000ll;
+    k.nsp = k.TH / 2;
+    if (k.strip) { k.BTH = 4; k.BTW = 14; }
+    choose_pitch(k.BTH, k.BTW, k.rpitch, k.rhalf, k.strip != 0);
     k.nbh = cdiv(k.TH, k.BTH); k.nbw = cdiv(k.TW, k.BTW);
     k.btw_magic = (65536 + k.BTW - 1) / k.BTW;
     k.nct = cdiv(d->Co, WC); k.nc8 = d->Ci / WK;
@@ -443,6 +469,11 @@ int fill(const pc_wino_desc* d, WinoK& k) {
 }
 
 }  // namespace
+
+// spatial blocks of a launch (x nct channel tiles = the grid): rectangles per plane, or -- strip mode -- nsp blocks per pair of planes
+static inline int64_t wino_spatial_blocks(const WinoK& k) {
+    return k.strip ? (int64_t)(k.N / 2) * k.T * k.nsp * k.nbw : (int64_t)k.N * k.T * k.nbh * k.nbw;
+}
 
 // pc_wino_desc.m == 4: the F(4x4, 3x3) kernel (wino4.hip)
 int pc_wino4_bnpart_rows_impl(const pc_wino_desc* d);
@@ -470,7 +501,7 @@ extern "C" int pc_wino_bnpart_rows(const pc_wino_desc* d) {
     if (d && d->m != 0 && d->m != 2) return -1;
     WinoK k;
     if (fill(d, k) != PC_OK) return -1;
-    return k.N * k.T * k.nbh * k.nbw * 2;
+    return wino_spatial_blocks(k) * 2;
 }
 
 // Host-only: multiply-accumulates the launch issues to the matrix cores / performs on real outputs (see pc_conv_work)
@@ -484,7 +515,7 @@ extern "C" int pc_wino_work(const pc_wino_desc* d, double* out) {
     double taps = 0;                                       // valid temporal taps summed over t
     for (int t = 0; t < k.T; ++t)
         for (int a = 0; a < k.KT; ++a) { const int num = t * k.ta + a + k.tc; taps += num >= 0 && num % k.tden == 0 && num / k.tden < k.Ti; }
-    const double blocks = (double)k.N * k.nbh * k.nbw * k.nct;
+    const double blocks = (double)wino_spatial_blocks(k) / k.T * k.nct;
     out[0] = blocks * taps * 16.0 * WT * WC * k.Ci;                                  // issued: 16 transform-domain GEMMs of 64 x 64 x Ci per tap
     out[1] = (double)k.N * taps * 16.0 * ((double)k.TH * k.TW) * k.Co * k.Ci;        // executed on real tiles / channels
     out[2] = blocks * k.T;                                                          // blocks
@@ -510,7 +541,7 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     PC_CHECK_ARG(var != 32 || bnpart, "pc_wino_conv: variant 32 writes its stamps through bnpart");
 #endif
     const size_t lds = (size_t)(4 * PLANE + 2 * RPLANE) * sizeof(float);
-    const dim3 grid((unsigned)((int64_t)k.N * k.T * k.nbh * k.nbw * k.nct));
+    const dim3 grid((unsigned)(wino_spatial_blocks(k) * k.nct));
 #define WINO_LAUNCH(V)                                                                                                            \
     {                                                                                                                             \
         PC_SET_LDS_ONCE(wino_conv_kernel<V>, lds, "wino_conv_kernel");                                                            \

@@ -146,6 +146,24 @@ def test_wino4_real_shapes_vs_f23_kernel(N, thw, Ci, Co):
     assert torch.equal(again, outs[4])
 
 
+def test_wino4_real_shape_vs_fp64_torch():
+    """F(4x4, 3x3) at a real shape of the step (conv56's forward: 8 x (2, 56, 56), 64 -> 192, bias + ReLU) against an fp64 torch
+    convolution directly -- the small shapes above are, the real ones were only compared with the F(2x2, 3x3) kernel."""
+    N, thw, Ci, Co = 8, (2, 56, 56), 64, 192
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(N, *thw, Ci, generator=g).clamp_min(0)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g) * (1.0 / np.sqrt(27 * Ci))
+    b = torch.randn(Co, generator=g) * 0.1
+    ref = torch.relu(F.conv3d(x.double().permute(0, 4, 1, 2, 3), w.double(), b.double(), padding=1)).permute(0, 2, 3, 4, 1)
+    xd, wd = x.cuda(), w.cuda().contiguous()
+    out = torch.empty(N, *thw, Co, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, *thw, Ci, Ci, Co, Co, 3, act=capi.ACT_RELU, flags=capi.F_BIAS, m=4), xd, ops.wino_weights(wd, Co, Ci, 3, m=4), out, bias=b.cuda())
+    err = (out.cpu().double() - ref).abs().max().item()
+    assert err <= TOL * max(1.0, ref.abs().max().item()), err
+    rms = ((out.cpu().double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt()).item()
+    assert rms <= 2e-6, rms          # measured 1.0e-6 of the output rms with the points (0, +-1/sqrt2, +-sqrt2, inf) (DESIGN.md 4)
+
+
 def test_wino4_refuses_shapes_it_cannot_tile():
     d = ops.wino_desc(1, 1, 14, 14, 8, 8, 8, 8, 3, m=4)
     assert capi.lib().pc_wino_bnpart_rows(d) == -1

@@ -154,3 +154,72 @@ def test_wino_real_shapes_vs_gather_gemm(thw, Ci, Co):
     torch.cuda.synchronize()
     err = (out - ref).abs().max().item()
     assert err <= 5e-5 * max(1.0, ref.abs().max().item()), err
+
+
+# ---- strip mode (round 6): frames whose tile grid is a multiple of 14 wide run as blocks of two 2 x 14-tile strips taken from a PAIR of planes
+# (56 of 64 tile slots instead of 49): csrc/wino.hip.  N % 4 == 0 selects it; the same shapes with N = 2 or 6 run the rectangle blocks.
+@pytest.mark.parametrize("N,T,HW,Ci,Co,KT", [(4, 1, 28, 32, 96, 3), (4, 2, 28, 24, 64, 3), (8, 2, 56, 16, 64, 3), (4, 1, 28, 40, 70, 1), (12, 3, 28, 8, 8, 3)])
+def test_wino_strip_blocks_match_torch_and_rectangle_blocks(N, T, HW, Ci, Co, KT):
+    """Forward with bias + BatchNorm partial sums into a channel slice of a wider tensor, then accumulate + ReLU-free second pass, against an fp64
+    torch convolution; the first two samples of the same input through a launch with N = 2 (rectangle blocks: N % 4 != 0) give bit-identical outputs
+    (a tile's arithmetic does not depend on how tiles are grouped into blocks); the BatchNorm partial rows of each sample pair sum to the column
+    sums of its outputs (a block's rows belong to one plane pair)."""
+    H = W = HW
+    ldi, ldo = Ci + 8, Co + 12
+    g = torch.Generator().manual_seed(N * 10 + T + HW)
+    xw = torch.randn(N, T, H, W, ldi, generator=g)
+    w = torch.randn(Co, Ci, KT, 3, 3, generator=g) * (1.0 / np.sqrt(Ci * KT * 9))
+    b = torch.randn(Co, generator=g)
+    x = xw[..., 4:4 + Ci].contiguous()
+    ref = _ref(x.double(), w.double(), b.double(), KT)
+    xd, bd = xw.cuda(), b.cuda()
+    U = ops.wino_weights(w.cuda().contiguous(), Co, Ci, KT)
+    d = ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS | capi.F_BNPART)
+    rows = capi.lib().pc_wino_bnpart_rows(d)
+    assert rows == (N // 2) * T * (H // 4) * (W // 28) * 2            # strips per plane = H / 4 blocks per plane pair, two partial rows per block
+    part = torch.zeros(rows, 2, Co, device="cuda")
+    outw = torch.zeros(N, T, H, W, ldo, device="cuda")
+    ops.wino_conv(d, xd[..., 4:], U, outw[..., 8:], bias=bd, bnpart=part)
+    got = outw[..., 8:8 + Co]
+    tol = 2e-5 * max(1.0, ref.abs().max().item())
+    assert (got.cpu().double() - ref).abs().max().item() <= tol
+    assert outw[..., :8].abs().max().item() == 0 and outw[..., 8 + Co:].abs().max().item() == 0
+    per = rows // (N // 2)
+    for q in range(N // 2):
+        sm = part[q * per:(q + 1) * per].sum(0).cpu().double()
+        r2 = ref[2 * q:2 * q + 2]
+        assert (sm[0] - r2.sum(dim=(0, 1, 2, 3))).abs().max().item() <= 2e-3 * max(1.0, r2.abs().sum(dim=(0, 1, 2, 3)).max().item() * 1e-3)
+        assert (sm[1] - (r2 ** 2).sum(dim=(0, 1, 2, 3))).abs().max().item() <= 1e-3 * max(1.0, (r2 ** 2).sum(dim=(0, 1, 2, 3)).max().item())
+    # rectangle blocks on the first two samples: bit-identical
+    o2 = torch.zeros(2, T, H, W, ldo, device="cuda")
+    ops.wino_conv(ops.wino_desc(2, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS), xd[:2, ..., 4:], U, o2[..., 8:], bias=bd)
+    assert torch.equal(o2[..., 8:8 + Co], got[:2])
+    # accumulate into an existing tensor
+    base = torch.randn(N, T, H, W, Co, generator=g)
+    acc = base.cuda().clone()
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, ldi, Co, Co, KT, flags=capi.F_ACCUM), xd[..., 4:], U, acc)
+    ref2 = base.double() + _ref(x.double(), w.double(), None, KT)
+    assert (acc.cpu().double() - ref2).abs().max().item() <= 2e-5 * max(1.0, ref2.abs().max().item())
+
+
+def test_wino_strip_blocks_temporal_stride_two_and_input_gradient():
+    """Conv3d_2c's shape class in strip mode (56 x 56 frames: 14 strips per plane): forward with temporal stride 2 and its transposed input gradient."""
+    N, T, H, W, Ci, Co, s = 4, 4, 56, 56, 16, 64, 2
+    pad = max(3 - s, 0)
+    front, back = pad // 2, pad - pad // 2
+    To = (T + pad - 3) // s + 1
+    g = torch.Generator().manual_seed(19)
+    x = torch.randn(N, T, H, W, Ci, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, 3, 3, 3, generator=g, dtype=torch.float64) * 0.1
+    dy = torch.randn(N, To, H, W, Co, generator=g, dtype=torch.float64)
+    xp = F.pad(x.permute(0, 4, 1, 2, 3), (1, 1, 1, 1, front, back))
+    y = F.conv3d(xp, w, stride=(s, 1, 1)).permute(0, 2, 3, 4, 1)
+    (y * dy).sum().backward()
+    wd = w.float().cuda().contiguous()
+    out = torch.empty(N, To, H, W, Co, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, To, H, W, Ci, Ci, Co, Co, 3, Ti=T, ta=s, tc=-front, tden=1), x.detach().float().cuda(), ops.wino_weights(wd, Co, Ci, 3), out)
+    assert (out.cpu().double() - y.detach()).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
+    Ut = ops.wino_weights(wd, Ci, Co, 3, flip=True, strides=(27, 1, Ci * 27))
+    dx = torch.empty(N, T, H, W, Ci, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Co, Co, Ci, Ci, 3, Ti=To, ta=1, tc=front - 2, tden=s), dy.float().cuda(), Ut, dx)
+    assert (dx.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
