@@ -233,7 +233,7 @@ class StagedInputs:
                 gscale = reducer.gscale
             eng.adam(lr, gscale)
             st.release(slot)
-            self.prep(i + 1, slot ^ 1)        # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above
+            self.prep(i + 1, slot ^ 1)        # host decisions + uploads + pc_clip_from_u8 overlap the step enqueued above (on lane 1's stream: SampleStager.prepare)
             out = eng.read_scalars()
         torch.cuda.synchronize()
         eng._restore_input_ops()

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
     } else {
         // src is nsl K-slice images of a split-K weight gradient, sst floats apart (pc_conv_wgrad with ws_slices): added in slice
         // order -- the sum does not depend on which block finished when (no atomics anywhere on the way).  A thread owns four consecutive
-        // columns of one row (one 16-byte load per image, eight in flight); J.tr = 8: a quarter of the threads' rows, four times the blocks
+        // columns of one row (one 16-byte load per image, sixteen in flight); J.tr = 8: a quarter of the threads' rows, four times the blocks
         const int i = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
         if (i < J.tr) {
             const int r = r0 + i, c = c0 + c4;
@@ -582,12 +582,19 @@ __global__ __launch_bounds__(256) void transpose_multi_kernel(const TPack pk) {
                 const f32x4* q = (const f32x4*)(J.src + (size_t)b * J.sbs + (size_t)r * J.sld + c);
                 const size_t st4 = (size_t)J.sst / 4;
                 int k = 0;
-                for (; k + 8 <= J.nsl; k += 8) {
-                    f32x4 t[8];
+                for (; k + 16 <= J.nsl; k += 16) {
+                    f32x4 t[16];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) t[u] = q[(size_t)(k + u) * st4];
+                    for (int u = 0; u < 16; ++u) t[u] = q[(size_t)(k + u) * st4];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) sum += t[u];
+                    for (int u = 0; u < 16; ++u) sum += t[u];
+                }
+                for (; k + 4 <= J.nsl; k += 4) {
+                    f32x4 t[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) t[u] = q[(size_t)(k + u) * st4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) sum += t[u];
                 }
                 for (; k < J.nsl; ++k) sum += q[(size_t)k * st4];
             }
@@ -912,7 +919,9 @@ extern "C" int pc_transpose_multi(const pc_transpose_job* jobs, int njobs, pc_st
             k.R = a.R; k.Cc = a.C; k.sld = a.src_ld; k.dld = a.dst_ld; k.accum = a.accum; k.nsl = a.nslices; k.sst = a.slice_stride;
             PC_CHECK_ARG(a.nslices <= 1 || (a.C <= a.src_ld && a.src_ld % 4 == 0 && a.slice_stride % 4 == 0 && a.src_batch_stride % 4 == 0 && a.src % 16 == 0),
                          "pc_transpose_multi: job %d sums slice images: src_ld (>= C) and the strides must be multiples of 4 floats and src 16-byte aligned", j0 + q);
-            k.tr = a.nslices > 16 ? 8 : 32; k.pad_ = 0;
+            // 32-row tiles (one 16-byte quad per thread and image, 256 threads busy) unless the job is too small to give every CU a block: then
+            // 8-row tiles, four times the blocks (the sum over many images is a chain of dependent loads per thread)
+            k.tr = (a.nslices > 1 && (long long)a.batch * cdiv(a.C, 32) * cdiv(a.R, 32) < 192) ? 8 : 32; k.pad_ = 0;
             k.tiles_c = cdiv(a.C, 32); k.tiles_rc = k.tiles_c * cdiv(a.R, k.tr);
             pk.first[q] = tiles;
             tiles += a.batch * k.tiles_rc;

@@ -107,7 +107,7 @@ __global__ void wino_weights_kernel(const float* __restrict__ w, long long sO, l
 constexpr int RMAX = 12;          // 1 KiB DMA pieces of one raw patch image (three per wave): up to 384 positions (an 8 x 8 tile block has 18 x 18 = 324)
 constexpr int RPLANE = RMAX * 256;
 
-template <int VAR>
+template <int VAR, bool STRIP = false>
 __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Vs = smem;                  // [2][PLANE]
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int sblock = sb;             // spatial block id (n, t, bh, bw): the BatchNorm partial row
     const int bw = sb % p.nbw; sb /= p.nbw;
     int bh = 0, t, n, dn = 0, tia = 0, tib = 0;        // strip mode: tile row of the first / second strip in its plane, second strip's plane = n + dn
-    if (p.strip) {
+    if constexpr (STRIP) {
         const int sp = sb % p.nsp; sb /= p.nsp;
         t = sb % p.T;
         const int ga = 2 * sp, gb = ga + 1, pa = ga >= p.nsp ? 1 : 0, pb = gb >= p.nsp ? 1 : 0;    // strips ga, gb of the pair's 2 nsp; nsp strips per plane
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         bh = sb % p.nbh; sb /= p.nbh;
         t = sb % p.T; n = sb / p.T;
     }
-    const int PW = 2 * p.BTW + 2, PH = p.strip ? 12 : 2 * p.BTH + 2, npos = PH * PW;
+    const int PW = 2 * p.BTW + 2, PH = STRIP ? 12 : 2 * p.BTH + 2, npos = PH * PW;
     const int h0 = 2 * bh * p.BTH - 1, w0 = 2 * bw * p.BTW - 1;          // image position of patch position (0, 0)
     const unsigned dn_in = (unsigned)((size_t)dn * p.Ti * p.H * p.W * p.ldi * 4);      // byte distance of the second strip's plane (same t, next n)
 
@@ -143,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
         const int pr = q / p.rpitch, rem = q - pr * p.rpitch;
         const int odd = rem >= p.rhalf ? 1 : 0, idx = rem - odd * p.rhalf;
         const int pc = 2 * idx + odd;
-        const int second = (p.strip && pr >= 6) ? 1 : 0;                 // patch rows 6 .. 11: the second strip's 6 x 30 patch
-        const int h = p.strip ? 2 * (second ? tib : tia) - 1 + (pr - 6 * second) : h0 + pr, w = w0 + pc;
+        const int second = (STRIP && pr >= 6) ? 1 : 0;                   // patch rows 6 .. 11: the second strip's 6 x 30 patch
+        const int h = STRIP ? 2 * (second ? tib : tia) - 1 + (pr - 6 * second) : h0 + pr, w = w0 + pc;
         const bool ok = pr < PH && idx < p.BTW + 1 && (unsigned)h < (unsigned)p.H && (unsigned)w < (unsigned)p.W;
         roff[j] = ok ? (unsigned)(((h * p.W + w) * p.ldi + (lane & 1) * 4) * 4) + (second ? dn_in : 0u) : DMA_OOB;
     }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     const int ttile = (wave & 1) * 32 + (lane >> 1), tkh = lane & 1, thalf = wave >> 1;
     const int tli = ttile / p.BTW, tlj = ttile - tli * p.BTW;
     const bool tval = ttile < p.BTH * p.BTW;       // (tiles beyond the image read zero lines: their patch positions are padding)
-    const int rbase = tval ? (((2 * tli + thalf + (p.strip ? 2 * (tli >> 1) : 0)) * p.rpitch + tlj) * 2 + tkh) * 4 : tkh * 4;      // float offset of patch (row thalf, col 0) in R
+    const int rbase = tval ? (((2 * tli + thalf + (STRIP ? 2 * (tli >> 1) : 0)) * p.rpitch + tlj) * 2 + tkh) * 4 : tkh * 4;      // float offset of patch (row thalf, col 0) in R
     // temporal taps whose source frame exists: tap kt reads input frame (t * ta + kt + tc) / tden when that is an integer in [0, Ti)
     int nkt = 0, ktl0 = 0, ktl1 = 0, ktl2 = 0, ttl0 = 0, ttl1 = 0, ttl2 = 0;
     for (int kt = 0; kt < p.KT; ++kt) {
@@ -330,8 +330,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
     for (int r = 0; r < 16; ++r) {
         const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         const int li = (m * p.btw_magic) >> 16, lj = m - li * p.BTW;      // m / BTW for m < 64 (exact: magic = ceil(65536 / BTW))
-        const int second = (p.strip && li >= 2) ? 1 : 0;
-        const int oi = p.strip ? (second ? tib : tia) + (li & 1) : bh * p.BTH + li, oj = bw * p.BTW + lj;
+        const int second = (STRIP && li >= 2) ? 1 : 0;
+        const int oi = STRIP ? (second ? tib : tia) + (li & 1) : bh * p.BTH + li, oj = bw * p.BTW + lj;
         const bool ok = cval && m < p.BTH * p.BTW && oi < p.TH && oj < p.TW;
         float s[4][2];
 #pragma unroll
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(256, 1) void wino_conv_kernel(const WinoK p) {
 #pragma unroll 4
             for (int pos = tid >> 4; pos < npo; pos += 16) {
                 const int lr = ((pos >> 1) * p.btw_magic) >> 16, lc = pos - lr * OW2;       // pos / (2 BTW)
-                const int second = (p.strip && lr >= 4) ? 1 : 0;                            // output rows 4 .. 7 of the block: the second strip
-                const int orow = p.strip ? 2 * (second ? tib : tia) + (lr & 3) : 2 * bh * p.BTH + lr, ocol = 2 * bw * p.BTW + lc;
+                const int second = (STRIP && lr >= 4) ? 1 : 0;                              // output rows 4 .. 7 of the block: the second strip
+                const int orow = STRIP ? 2 * (second ? tib : tia) + (lr & 3) : 2 * bh * p.BTH + lr, ocol = 2 * bw * p.BTW + lc;
                 if (orow >= 2 * p.TH || ocol >= 2 * p.TW) continue;
                 f32x4 v = *(const f32x4*)(Tst + pos * WC + c4 * 4);
                 float* o = ob + (second ? (size_t)dn * p.T * plane_out : 0) + ((size_t)orow * p.W + ocol) * p.ldo;
@@ -452,8 +452,12 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
     // strip mode (kernel header): tile grids a multiple of 14 wide and an even number of tile rows high, planes paired (n, n + 1) -- N % 4 == 0 keeps
     // a pair inside one BatchNorm batch group (groups <= 2: the partial rows of a block belong to one group)
-    static const int strips = getenv("PICONS_WINO_STRIPS") ? atoi(getenv("PICONS_WINO_STRIPS")) : 1;
-    k.strip = strips && k.TW % 14 == 0 && k.TH % 2 == 0 && d->N % 4 == 0 && (int64_t)2 * d->Ti * d->H * d->W * d->ldi * 4 < 0xff000000ll;
+    // OFF by default (measured, profiles/r06_wino_strips.txt): 12.5 % fewer blocks, but a strip block fetches a 12 x 30 raw patch where a 7 x 7-tile
+    // rectangle fetches 16 x 16 (+40 %) and holds 56 instead of 49 tiles: the twenty 28 x 28 launches take 1.83 ms single-stream against 1.60,
+    // the four-lane step is unchanged within noise.  Bit-identical results either way (tests/test_wino_gpu.py).  PICONS_WINO_STRIPS=1 selects it.
+    static const int strips = getenv("PICONS_WINO_STRIPS") ? atoi(getenv("PICONS_WINO_STRIPS")) : 0;
+    k.strip = strips && k.TW % 14 == 0 && k.TH % 2 == 0 && d->N % 4 == 0 && (int64_t)2 * d->Ti * d->H * d->W * d->ldi * 4 < 0xff000000ll &&
+              (k.TH / 2) * (k.TW / 14) < 2 * cdiv(k.TH, k.BTH) * cdiv(k.TW, k.BTW);          // ... and only where strips are fewer blocks (56 x 56 tiles in 8 x 8 rectangles are exact)
     k.nsp = k.TH / 2;
     if (k.strip) { k.BTH = 4; k.BTW = 14; }
     choose_pitch(k.BTH, k.BTW, k.rpitch, k.rhalf, k.strip != 0);
@@ -542,12 +546,13 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
 #endif
     const size_t lds = (size_t)(4 * PLANE + 2 * RPLANE) * sizeof(float);
     const dim3 grid((unsigned)(wino_spatial_blocks(k) * k.nct));
-#define WINO_LAUNCH(V)                                                                                                            \
+#define WINO_LAUNCH_(V, S)                                                                                                        \
     {                                                                                                                             \
-        PC_SET_LDS_ONCE(wino_conv_kernel<V>, lds, "wino_conv_kernel");                                                            \
-        if (pc_tl_ev_start) hipExtLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, pc_tl_ev_start, pc_tl_ev_stop, 0, k); \
-        else hipLaunchKernelGGL(wino_conv_kernel<V>, grid, dim3(256), lds, (hipStream_t)s, k);                                   \
+        PC_SET_LDS_ONCE((wino_conv_kernel<V, S>), lds, "wino_conv_kernel");                                                       \
+        if (pc_tl_ev_start) hipExtLaunchKernelGGL((wino_conv_kernel<V, S>), grid, dim3(256), lds, (hipStream_t)s, pc_tl_ev_start, pc_tl_ev_stop, 0, k); \
+        else hipLaunchKernelGGL((wino_conv_kernel<V, S>), grid, dim3(256), lds, (hipStream_t)s, k);                               \
     }
+#define WINO_LAUNCH(V) { if (k.strip) WINO_LAUNCH_(V, true) else WINO_LAUNCH_(V, false) }
 #ifdef PICONS_DIAG
     switch (var) {
         case 1: WINO_LAUNCH(1) break;
@@ -564,6 +569,7 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     WINO_LAUNCH(0)
 #endif
 #undef WINO_LAUNCH
+#undef WINO_LAUNCH_
     PC_CHECK_LAUNCH("wino_conv_kernel");
     return PC_OK;
 }

@@ -572,6 +572,9 @@ class SampleStager(HostDictStager):
         super().__init__(eng, dtype=torch.float32, host=False)
         n, hw, T = eng.bs, eng.hw, spec.FRAMES
         p = eng.plan
+        # the stream the samples are made on: lane 1's (prepare()); PICONS_STAGE_LANE=0: the copy stream of the base class (rounds 4 - 5)
+        lane = int(sw.get("PICONS_STAGE_LANE", "1"))
+        self.stage_stream = eng.side[lane - 1] if 1 <= lane <= len(eng.side) else self.copy_stream
         self.x = [torch.empty(2 * n, T, hw, hw, 4, dtype=torch.float32, device=eng.dev) for _ in range(2)]
         for d in self.dev:                             # the planar staging of the base class is not used here
             d.pop("data"); d.pop("aug_data")
@@ -618,10 +621,17 @@ class SampleStager(HostDictStager):
         perm = np.asarray(perm)
         where = np.empty(n, np.int64)
         where[perm] = np.arange(n)                     # sample i lands at position where[i]
-        if self.used[slot]:
-            self.consumed[slot].synchronize()          # the step that read this slot was enqueued two steps ago: long done
         x, m = self.x[slot], self.dev[slot]["loc_msk"]
-        with torch.cuda.stream(self.copy_stream):
+        # Round 6: the samples are made on LANE 1's stream, not on a stream of their own.  A fifth stream shares a hardware queue with one of the four
+        # lanes -- it got the skip lane's, whose last op of a step is the early Adam right in front of the stem's backward -- so the
+        # uploads and pc_clip_from_u8 launches enqueued behind the step sat in that queue until then and ran beside / behind the stem's weight
+        # gradient, the LAST kernel of the step: the next step's stem conv waited 0.5 - 0.75 ms for them (rocprofv3 kernel trace,
+        # profiles/r06_staging_lane.txt).  Lane 1 (the second Inception branch) has drained a millisecond earlier; its queue is the one to wait in.
+        st_ = self.stage_stream
+        with torch.cuda.stream(st_):
+            if self.used[slot]:
+                # the slot's last readers (the previous-but-one minibatch's step: stem conv / weight gradient, loss list): waited for on the device
+                st_.wait_event(self.consumed[slot])
             samples = [make_sample(i, (x[where[i]], x[n + where[i]], m[where[i]])) for i in range(n)]
             act = torch.tensor([float(torch.as_tensor(smp["action"]).reshape(-1)[0]) for smp in samples])[perm]
             if eng.jhmdb:                              # main_jhmdb.py:68-70
@@ -630,7 +640,7 @@ class SampleStager(HostDictStager):
                 lab_flag = torch.tensor([float(smp["label_vid"]) for smp in samples])[perm]
             self._pack_small(slot, act, lab_flag, drops)
             self.dev_small[slot].copy_(self.pin_small[slot], non_blocking=True)
-            self.ready[slot].record(self.copy_stream)
+            self.ready[slot].record(st_)
         self.used[slot] = True
 
     def commit(self, slot):

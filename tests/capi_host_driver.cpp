@@ -17,7 +17,7 @@ static int fails = 0;
     } while (0)
 
 int main() {
-    EXPECT(pc_version() >= 100);
+    EXPECT(pc_version() == PC_VERSION);
     EXPECT(pc_last_error() != nullptr);
     char dummy[256] = {0};
     float* fp = reinterpret_cast<float*>(dummy);
@@ -38,6 +38,43 @@ int main() {
     std::memset(&wd, 0, sizeof(wd));
     EXPECT(pc_conv_wgrad(&wd, nullptr, nullptr, nullptr, nullptr) == PC_E_ARG);
     EXPECT(pc_conv_wgrad(nullptr, fp, fp, fp, nullptr) == PC_E_ARG);
+    EXPECT(pc_wgrad_slices(nullptr) == -1 && pc_wgrad_uses_x6(nullptr) == 0);
+    {   // round 6: K-slice counts of every route (host arithmetic only: the split of the K range, the stem's per-tap slice table), the family a
+        // problem's launch belongs to, and the checks in front of a launch that would write more slice images than the workspace holds
+        struct { int N, T, H, W, Cd, Cs, k, s, flags; } cases[] = {
+            {16, 4, 112, 112, 64, 4, 7, 2, PC_WG_CS3}, {16, 4, 112, 112, 64, 4, 7, 2, PC_WG_CS3 | PC_WG_X6},          // stem: wgrad4 / wgrad4_x6
+            {16, 4, 112, 112, 64, 64, 3, 1, PC_WG_X6}, {16, 2, 28, 28, 128, 96, 3, 1, 0},                              // row-segment
+            {16, 1, 28, 28, 288, 512, 1, 1, PC_WG_X6}, {16, 2, 56, 56, 64, 64, 1, 1, PC_WG_X6}, {2, 1, 20, 20, 136, 48, 3, 1, 0}};   // generic
+        for (const auto& c : cases) {
+            pc_wgrad_desc w;
+            std::memset(&w, 0, sizeof(w));
+            w.N = c.N; w.Tq = c.T; w.Hq = c.H; w.Wq = c.W; w.Cd = c.Cd; w.ldd = c.Cd;
+            w.Ts = c.T * c.s; w.Hs = c.H * c.s; w.Ws = c.W * c.s; w.Cs = c.Cs; w.lds = c.Cs;
+            for (int i = 0; i < 3; ++i) { w.istr[i] = c.s; w.ntap[i] = c.k; w.ioff0[i] = -(c.k / 2 - (c.s == 2 ? 1 : 0)); w.istep[i] = 1; }
+            w.KT = w.KH = w.KW = c.k; w.flags = c.flags;
+            const int ns = pc_wgrad_slices(&w);
+            EXPECT(ns >= 1 && ns <= 1024);
+            EXPECT(pc_wgrad_uses_x6(&w) == ((c.flags & PC_WG_X6) ? 1 : 0));
+            double wk[5];
+            EXPECT(pc_wgrad_work(&w, 0, c.Cs == 4 ? 3 : 0, wk) == PC_OK && wk[0] >= wk[1] && wk[1] > 0);
+            if (ns > 1) {
+                w.ws_slices = ns - 1;                                                   // one image short: refused before any launch
+                EXPECT(pc_conv_wgrad(&w, fp, fp, fp, nullptr) == PC_E_ARG);
+                EXPECT(std::strstr(pc_last_error(), "slice images") != nullptr);
+            }
+            w.ws_slices = ns; w.splitk = -1;                                            // plain stores and slice images exclude each other
+            EXPECT(pc_conv_wgrad(&w, fp, fp, fp, nullptr) == PC_E_ARG);
+        }
+        EXPECT(pc_wgrad_fold_group() >= 2);
+        EXPECT(pc_wgrad_fold(nullptr, 64, 4, nullptr) == PC_E_ARG && pc_wgrad_fold(fp, 6, 4, nullptr) == PC_E_ARG);
+        pc_transpose_job tj;
+        std::memset(&tj, 0, sizeof(tj));
+        tj.src = (uint64_t)(uintptr_t)fp; tj.dst = (uint64_t)(uintptr_t)fp; tj.batch = 1; tj.R = 4; tj.C = 3; tj.src_ld = 3; tj.dst_ld = 4;
+        tj.nslices = 2; tj.slice_stride = 0;                                            // summed images need a stride ...
+        EXPECT(pc_transpose_multi(&tj, 1, nullptr) == PC_E_ARG);
+        tj.slice_stride = 64;                                                           // ... and 16-byte rows (src_ld % 4)
+        EXPECT(pc_transpose_multi(&tj, 1, nullptr) == PC_E_ARG);
+    }
 
     // workspace sizing: host arithmetic
     EXPECT(pc_bn_bwd_ws_floats(802816, 64, 2) > 0);
@@ -99,11 +136,17 @@ int main() {
         for (int m = 2; m <= 4; m += 2)
             for (int H = 4; H <= 256; H += 4)
                 for (int W = 4; W <= 256; W += (W < 64 ? 4 : 36)) {
-                    pc_wino_desc d{};
-                    d.N = 2; d.T = 3; d.H = H; d.W = W; d.Ci = 24; d.ldi = 24; d.Co = 72; d.ldo = 72; d.KT = 3; d.Ti = 3; d.ta = 1; d.tc = -1; d.tden = 1; d.m = m;
-                    EXPECT(pc_wino_work(&d, w3) == PC_OK && w3[0] >= w3[1] && w3[1] > 0 && w3[2] > 0);
-                    EXPECT(pc_wino_bnpart_rows(&d) > 0);
-                    EXPECT(pc_wino_conv(&d, nullptr, fp, nullptr, fp, nullptr, nullptr) == PC_E_ARG);
+                    for (int N = 2; N <= 4; N += 2) {          // N = 4: F(2x2, 3x3) strip mode where the tile grid is a multiple of 14 wide (plane pairs)
+                        pc_wino_desc d{};
+                        d.N = N; d.T = 3; d.H = H; d.W = W; d.Ci = 24; d.ldi = 24; d.Co = 72; d.ldo = 72; d.KT = 3; d.Ti = 3; d.ta = 1; d.tc = -1; d.tden = 1; d.m = m;
+                        EXPECT(pc_wino_work(&d, w3) == PC_OK && w3[0] >= w3[1] && w3[1] > 0 && w3[2] > 0);
+                        EXPECT(pc_wino_bnpart_rows(&d) > 0);
+                        EXPECT(pc_wino_conv(&d, nullptr, fp, nullptr, fp, nullptr, nullptr) == PC_E_ARG);
+                        if (m == 2 && N == 4 && H == W && (H == 28 || H == 56))       // strips: H / 4 blocks per plane pair and 28-wide column block, two partial rows each
+                            EXPECT(pc_wino_bnpart_rows(&d) == (N / 2) * d.T * (H / 4) * (W / 28) * 2);
+                        if (m == 2 && H == 112 && W == 112)                           // 56 x 56 tiles are exactly 49 rectangles of 8 x 8: strips would be MORE blocks
+                            EXPECT(pc_wino_bnpart_rows(&d) == N * d.T * 49 * 2);
+                    }
                 }
         pc_wino_desc d{};
         d.N = 1; d.T = 1; d.H = 14; d.W = 14; d.Ci = 8; d.ldi = 8; d.Co = 8; d.ldo = 8; d.KT = 3; d.Ti = 1; d.ta = 1; d.tc = -1; d.tden = 1;
