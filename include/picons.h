@@ -49,6 +49,10 @@ typedef void* pc_stream;            /* hipStream_t */
 #define PC_F_CI3     64             /* Ci == 4 whose 4th channel is padding (the RGB clip, 3 channels in 16-byte pieces): that
                                      * channel is taken as zero whatever it holds; the LDS-DMA stem kernel skips its MFMAs */
 
+#define PC_F_STRIPS  256            /* pc_wino_conv, F(2x2, 3x3) only: blocks of two 2 x 14-tile strips taken from pairs of planes (n, n + 1) instead of one
+                                     * rectangle of 64 tiles per block -- 56 instead of 49 of a block's 64 tile slots on 28 x 28 frames; needs a tile grid
+                                     * a multiple of 14 wide, an even number of tile rows and N % 4 == 0, and is ignored otherwise.  Bit-identical
+                                     * results; BatchNorm partial rows then number pc_wino_bnpart_rows(d) for THIS flag setting */
 #define PC_F_X6      128            /* the launch multiplies on the bf16 matrix cores: fp32 operands as exact sums of three bf16 values, six
                                      * products, fp32 accumulate (pc_conv_fwd_x6; the caller holds the weights as bf16 planes) */
 

@@ -76,7 +76,7 @@ TJOB_DTYPE = np.dtype([("src", np.uint64), ("dst", np.uint64), ("sbs", np.int64)
 SJOB_DTYPE = np.dtype([("src", np.uint64), ("planes", np.uint64), ("n", np.int64), ("pstride", np.int64)], align=False)
 
 ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
-F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6 = 1, 2, 4, 8, 16, 32, 64, 128
+F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6, F_STRIPS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 WG_CS3, WG_X6 = 1, 2
 
 ABI_VERSION = 101          # PC_VERSION of include/picons.h

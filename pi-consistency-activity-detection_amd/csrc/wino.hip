@@ -452,10 +452,10 @@ int fill(const pc_wino_desc* d, WinoK& k) {
     choose_block(k.TH, k.TW, k.BTH, k.BTW);
     // strip mode (kernel header): tile grids a multiple of 14 wide and an even number of tile rows high, planes paired (n, n + 1) -- N % 4 == 0 keeps
     // a pair inside one BatchNorm batch group (groups <= 2: the partial rows of a block belong to one group)
-    // OFF by default (measured, profiles/r06_wino_strips.txt): 12.5 % fewer blocks, but a strip block fetches a 12 x 30 raw patch where a 7 x 7-tile
-    // rectangle fetches 16 x 16 (+40 %) and holds 56 instead of 49 tiles: the twenty 28 x 28 launches take 1.83 ms single-stream against 1.60,
-    // the four-lane step is unchanged within noise.  Bit-identical results either way (tests/test_wino_gpu.py).  PICONS_WINO_STRIPS=1 selects it.
-    static const int strips = getenv("PICONS_WINO_STRIPS") ? atoi(getenv("PICONS_WINO_STRIPS")) : 0;
+    // Asked for per launch (PC_F_STRIPS); the planner leaves it OFF (measured, profiles/r06_wino_strips.txt): 12.5 % fewer blocks, but a strip block
+    // fetches a 12 x 30 raw patch where a 7 x 7-tile rectangle fetches 16 x 16 (+40 %) and holds 56 instead of 49 tiles: the twenty 28 x 28 launches
+    // take 1.83 ms single-stream against 1.60, the four-lane step is unchanged within noise.  Bit-identical results either way (tests/test_wino_gpu.py).
+    const int strips = (d->flags & PC_F_STRIPS) ? 1 : 0;
     k.strip = strips && k.TW % 14 == 0 && k.TH % 2 == 0 && d->N % 4 == 0 && (int64_t)2 * d->Ti * d->H * d->W * d->ldi * 4 < 0xff000000ll &&
               (k.TH / 2) * (k.TW / 14) < 2 * cdiv(k.TH, k.BTH) * cdiv(k.TW, k.BTW);          // ... and only where strips are fewer blocks (56 x 56 tiles in 8 x 8 rectangles are exact)
     k.nsp = k.TH / 2;
@@ -536,7 +536,7 @@ extern "C" int pc_wino_conv(const pc_wino_desc* d, const float* in, const float*
     PC_CHECK_ARG(((uintptr_t)in % 16 == 0) && ((uintptr_t)U % 16 == 0), "pc_wino_conv: in / U must be 16-byte aligned");
     PC_CHECK_ARG(!(d->flags & PC_F_BIAS) || bias, "pc_wino_conv: bias flag without pointer");
     PC_CHECK_ARG(!(d->flags & PC_F_BNPART) || bnpart, "pc_wino_conv: bnpart flag without pointer");
-    PC_CHECK_ARG(!(d->flags & ~(PC_F_BIAS | PC_F_ACCUM | PC_F_BNPART)), "pc_wino_conv: unsupported flag");
+    PC_CHECK_ARG(!(d->flags & ~(PC_F_BIAS | PC_F_ACCUM | PC_F_BNPART | PC_F_STRIPS)), "pc_wino_conv: unsupported flag");
     PC_CHECK_ARG(d->act == PC_ACT_NONE || d->act == PC_ACT_RELU, "pc_wino_conv: activation");
     k.in = in; k.U = U; k.bias = bias; k.out = out; k.bnpart = bnpart;
 #ifdef PICONS_DIAG

@@ -443,6 +443,8 @@ class Plan:
     def _wino_desc(N, othw, Ti, Ci, ldi, Co, ldo, tmap, act=0, flags=0, m=2):
         d = capi.WinoDesc()
         d.m = m
+        if m != 4 and sw.get("PICONS_WINO_STRIPS", "0") != "0":
+            flags |= capi.F_STRIPS          # F(2x2, 3x3) blocks of two 2 x 14-tile strips (bit-identical; measured neutral on the step, off by default)
         d.N, d.T, d.H, d.W, d.Ci, d.ldi, d.Co, d.ldo, d.KT, d.act, d.flags = N, othw[0], othw[1], othw[2], Ci, ldi, Co, ldo, 3, act, flags
         d.Ti, d.ta, d.tc, d.tden = Ti, tmap[0], tmap[1], tmap[2]
         return d

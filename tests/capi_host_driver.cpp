@@ -139,6 +139,7 @@ int main() {
                     for (int N = 2; N <= 4; N += 2) {          // N = 4: F(2x2, 3x3) strip mode where the tile grid is a multiple of 14 wide (plane pairs)
                         pc_wino_desc d{};
                         d.N = N; d.T = 3; d.H = H; d.W = W; d.Ci = 24; d.ldi = 24; d.Co = 72; d.ldo = 72; d.KT = 3; d.Ti = 3; d.ta = 1; d.tc = -1; d.tden = 1; d.m = m;
+                        d.flags = (m == 2 && N == 4) ? PC_F_STRIPS : 0;
                         EXPECT(pc_wino_work(&d, w3) == PC_OK && w3[0] >= w3[1] && w3[1] > 0 && w3[2] > 0);
                         EXPECT(pc_wino_bnpart_rows(&d) > 0);
                         EXPECT(pc_wino_conv(&d, nullptr, fp, nullptr, fp, nullptr, nullptr) == PC_E_ARG);

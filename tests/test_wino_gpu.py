@@ -156,13 +156,14 @@ def test_wino_real_shapes_vs_gather_gemm(thw, Ci, Co):
     assert err <= 5e-5 * max(1.0, ref.abs().max().item()), err
 
 
-# ---- strip mode (round 6): frames whose tile grid is a multiple of 14 wide run as blocks of two 2 x 14-tile strips taken from a PAIR of planes
-# (56 of 64 tile slots instead of 49): csrc/wino.hip.  N % 4 == 0 selects it; the same shapes with N = 2 or 6 run the rectangle blocks.
+# ---- strip mode (round 6, PC_F_STRIPS): frames whose tile grid is a multiple of 14 wide run as blocks of two 2 x 14-tile strips taken from a PAIR of
+# planes (56 of 64 tile slots instead of 49): csrc/wino.hip.  Asked for per launch; the planner leaves it off (measured neutral).
+ST = capi.F_STRIPS
 @pytest.mark.parametrize("N,T,HW,Ci,Co,KT", [(4, 1, 28, 32, 96, 3), (4, 2, 28, 24, 64, 3), (8, 2, 56, 16, 64, 3), (4, 1, 28, 40, 70, 1), (12, 3, 28, 8, 8, 3)])
 def test_wino_strip_blocks_match_torch_and_rectangle_blocks(N, T, HW, Ci, Co, KT):
     """Forward with bias + BatchNorm partial sums into a channel slice of a wider tensor, then accumulate + ReLU-free second pass, against an fp64
     torch convolution; the first two samples of the same input through a launch with N = 2 (rectangle blocks: N % 4 != 0) give bit-identical outputs
-    (a tile's arithmetic does not depend on how tiles are grouped into blocks); the BatchNorm partial rows of each sample pair sum to the column
+    (a tile's arithmetic does not depend on how tiles are grouped into blocks), and so does the whole batch without the flag; the BatchNorm partial rows of each sample pair sum to the column
     sums of its outputs (a block's rows belong to one plane pair)."""
     H = W = HW
     ldi, ldo = Ci + 8, Co + 12
@@ -174,7 +175,7 @@ def test_wino_strip_blocks_match_torch_and_rectangle_blocks(N, T, HW, Ci, Co, KT
     ref = _ref(x.double(), w.double(), b.double(), KT)
     xd, bd = xw.cuda(), b.cuda()
     U = ops.wino_weights(w.cuda().contiguous(), Co, Ci, KT)
-    d = ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS | capi.F_BNPART)
+    d = ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS | capi.F_BNPART | ST)
     rows = capi.lib().pc_wino_bnpart_rows(d)
     assert rows == (N // 2) * T * (H // 4) * (W // 28) * 2            # strips per plane = H / 4 blocks per plane pair, two partial rows per block
     part = torch.zeros(rows, 2, Co, device="cuda")
@@ -190,14 +191,17 @@ def test_wino_strip_blocks_match_torch_and_rectangle_blocks(N, T, HW, Ci, Co, KT
         r2 = ref[2 * q:2 * q + 2]
         assert (sm[0] - r2.sum(dim=(0, 1, 2, 3))).abs().max().item() <= 2e-3 * max(1.0, r2.abs().sum(dim=(0, 1, 2, 3)).max().item() * 1e-3)
         assert (sm[1] - (r2 ** 2).sum(dim=(0, 1, 2, 3))).abs().max().item() <= 1e-3 * max(1.0, (r2 ** 2).sum(dim=(0, 1, 2, 3)).max().item())
-    # rectangle blocks on the first two samples: bit-identical
+    # rectangle blocks (no flag) on the whole batch and on the first two samples: bit-identical
+    o3 = torch.zeros(N, T, H, W, ldo, device="cuda")
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS), xd[..., 4:], U, o3[..., 8:], bias=bd)
+    assert torch.equal(o3, outw)
     o2 = torch.zeros(2, T, H, W, ldo, device="cuda")
     ops.wino_conv(ops.wino_desc(2, T, H, W, Ci, ldi, Co, ldo, KT, flags=capi.F_BIAS), xd[:2, ..., 4:], U, o2[..., 8:], bias=bd)
     assert torch.equal(o2[..., 8:8 + Co], got[:2])
     # accumulate into an existing tensor
     base = torch.randn(N, T, H, W, Co, generator=g)
     acc = base.cuda().clone()
-    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, ldi, Co, Co, KT, flags=capi.F_ACCUM), xd[..., 4:], U, acc)
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Ci, ldi, Co, Co, KT, flags=capi.F_ACCUM | ST), xd[..., 4:], U, acc)
     ref2 = base.double() + _ref(x.double(), w.double(), None, KT)
     assert (acc.cpu().double() - ref2).abs().max().item() <= 2e-5 * max(1.0, ref2.abs().max().item())
 
@@ -217,9 +221,9 @@ def test_wino_strip_blocks_temporal_stride_two_and_input_gradient():
     (y * dy).sum().backward()
     wd = w.float().cuda().contiguous()
     out = torch.empty(N, To, H, W, Co, device="cuda")
-    ops.wino_conv(ops.wino_desc(N, To, H, W, Ci, Ci, Co, Co, 3, Ti=T, ta=s, tc=-front, tden=1), x.detach().float().cuda(), ops.wino_weights(wd, Co, Ci, 3), out)
+    ops.wino_conv(ops.wino_desc(N, To, H, W, Ci, Ci, Co, Co, 3, Ti=T, ta=s, tc=-front, tden=1, flags=ST), x.detach().float().cuda(), ops.wino_weights(wd, Co, Ci, 3), out)
     assert (out.cpu().double() - y.detach()).abs().max().item() <= 2e-5 * max(1.0, y.abs().max().item())
     Ut = ops.wino_weights(wd, Ci, Co, 3, flip=True, strides=(27, 1, Ci * 27))
     dx = torch.empty(N, T, H, W, Ci, device="cuda")
-    ops.wino_conv(ops.wino_desc(N, T, H, W, Co, Co, Ci, Ci, 3, Ti=To, ta=1, tc=front - 2, tden=s), dy.float().cuda(), Ut, dx)
+    ops.wino_conv(ops.wino_desc(N, T, H, W, Co, Co, Ci, Ci, 3, Ti=To, ta=1, tc=front - 2, tden=s, flags=ST), dy.float().cuda(), Ut, dx)
     assert (dx.cpu().double() - x.grad).abs().max().item() <= 2e-5 * max(1.0, x.grad.abs().max().item())
