@@ -46,7 +46,7 @@ def main():
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if any(k in r["Kernel_Name"] for k in ("conv_gemm", "conv_x6_kernel", "wgrad_kernel", "wgrad3_kernel", "wgrad4_kernel", "wgrad_x6_kernel", "wgrad3_x6_kernel", "wino_conv_kernel", "wino4_conv_kernel"))]
+    st = [r for r in rows[ad[-2] + 1:ad[-1] + 1] if any(k in r["Kernel_Name"] for k in ("conv_gemm", "conv_x6_kernel", "wgrad_kernel", "wgrad3_kernel", "wgrad4_kernel", "wgrad4_x6_kernel", "wgrad_x6_kernel", "wgrad3_x6_kernel", "wino_conv_kernel", "wino4_conv_kernel"))]
     def n_kernels(op):
         """pc_conv_wgrad gives a <=64-channel remainder of a deep grid its own 64-row-tile launch (pc_wgrad_work's launch count)."""
         return p.op_work[id(op[1])]["launches"] if op[0] == capi.OP_WGRAD else 1
