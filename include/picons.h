@@ -57,10 +57,11 @@ typedef void* pc_stream;            /* hipStream_t */
                                      * products, fp32 accumulate (pc_conv_fwd_x6; the caller holds the weights as bf16 planes) */
 
 /* ABI version of this header: bumped whenever a struct in it grows or an op's operands change (101: pc_wino_desc.m, PC_OP_BN_FIN_APPLY,
- * pc_wgrad_desc.ws_slices, pc_transpose_job.nslices / slice_stride, pc_wgrad_slices).  Descriptors must be zero-initialised by the caller:
+ * pc_wgrad_desc.ws_slices, pc_transpose_job.nslices / slice_stride, pc_wgrad_slices; 102: the workspace operands of PC_OP_TAIL6_WGRAD_MAP / PC_OP_TAIL6_BIAS_SUMS /
+ * PC_OP_TAIL_GRADS).  Descriptors must be zero-initialised by the caller:
  * fields added later read as "old behaviour" when 0.  pc_version() returns the value the library was built with; the Python host
  * (capi.lib()) refuses a library whose version differs from the header it mirrors. */
-#define PC_VERSION 101
+#define PC_VERSION 102
 int         pc_version(void);
 const char* pc_last_error(void);
 
@@ -405,6 +406,12 @@ int pc_tail_colsum(const float* dproj, int N, int64_t rows_per_n, float* sums, p
 int pc_tail_grads(const float* G, const float* sums, const float* W4, const float* b4, const float* cs,
                   const float* Wp, int N, int Ci, int Co, int taps, int J, int center, float* dW4,
                   float* db4, float* dWp, float* dbp, int accum, pc_stream s);
+/* the same with the smooth-weight gradient's N * Ci/8 block partials stored in ws (pc_tail_grads_ws_floats floats, no initialisation needed) and
+ * added in block order instead of fp32 atomics: bit-identical from run to run (round 6).  ws == NULL: pc_tail_grads. */
+int64_t pc_tail_grads_ws_floats(int N, int Ci, int Co);
+int pc_tail_grads_ws(const float* G, const float* sums, const float* W4, const float* b4, const float* cs,
+                     const float* Wp, int N, int Ci, int Co, int taps, int J, int center, float* dW4,
+                     float* db4, float* dWp, float* dbp, int accum, float* ws, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * Fused loss: everything main_ucf101.py:89-148 computes from (output, flip_op, loc_msk):
@@ -498,9 +505,17 @@ int pc_tail6_gather(const float* cols, const float* bc, const float* bsm, int N,
 int pc_tail6_scatter(const float* dout, int N, int It, int Ih, int Iw, float* dcols, pc_stream s);
 /* dW5 [N][8][Ci][128] -> gradient of the combined weights Gc [N][Ci][27][32] in the layout pc_tail_grads consumes */
 int pc_tail6_wgrad_map(const float* dW5, int N, int Ci, float* Gc, pc_stream s);
+/* the same from the classes' K-slice workspaces (pc_wgrad_desc.ws_slices, one launch per class with the N clip-passes as batched problems,
+ * gbstride = Ci*128): ws = [z][k < nslices8[z]][N][Ci][128] back to back, nslices8[z] = 0 for an empty class.  A class's images are added in slice
+ * order INTO ITS IMAGE 0 (ws is modified; the next pc_conv_wgrad into it rewrites image 0), the class sums in class order -- no fp32 atomics */
+int pc_tail6_wgrad_map_slices(float* ws, const int32_t* nslices8, int N, int Ci, float* Gc, pc_stream s);
 /* sums[n][ks] = sum of dout[n][o] over the outputs whose smooth tap ks reads an in-grid position (what pc_tail_colsum
  * gives on the 27-channel form) */
 int pc_tail6_bias_sums(const float* dout, int N, int It, int Ih, int Iw, float* sums, pc_stream s);
+/* the same without atomics: ws (pc_tail6_bias_sums_ws_floats floats, no initialisation needed) takes one partial row per block, a second
+ * kernel adds them in block order.  ws == NULL: pc_tail6_bias_sums. */
+int64_t pc_tail6_bias_sums_ws_floats(int N, int It, int Ih, int Iw);
+int pc_tail6_bias_sums_ws(const float* dout, int N, int It, int Ih, int Iw, float* sums, float* ws, pc_stream s);
 
 /* ------------------------------------------------------------------------------------------
  * Op-list runner: the host builds the step as a flat list of POD ops once (shape inference and
@@ -527,8 +542,8 @@ enum {
     PC_OP_TAIL6_WEIGHTS,            /* i = N, Ci; p = wf, W5f, W5t */
     PC_OP_TAIL6_GATHER,             /* i = N, It, Ih, Iw; p = cols, bc, bsm, out */
     PC_OP_TAIL6_SCATTER,            /* i = N, It, Ih, Iw; p = dout, dcols */
-    PC_OP_TAIL6_WGRAD_MAP,          /* i = N, Ci; p = dW5, Gc */
-    PC_OP_TAIL6_BIAS_SUMS,          /* i = N, It, Ih, Iw; p = dout, sums */
+    PC_OP_TAIL6_WGRAD_MAP,          /* i = N, Ci, sliced, nslices[8]; p = dW5 (sliced: the classes' K-slice workspaces), Gc */
+    PC_OP_TAIL6_BIAS_SUMS,          /* i = N, It, Ih, Iw; p = dout, sums, ws (or 0) */
     PC_OP_TRANSPOSE_MULTI,          /* p[0] = HOST pointer to pc_transpose_job[i[0]] (kept alive by the owner of the list) */
     PC_OP_FORK,                     /* i[0] = lane bitmask: those lanes wait for everything enqueued so far on lane i[1] (0 by default) */
     PC_OP_JOIN,                     /* i[0] = lane bitmask: lane 0 waits for everything enqueued on those lanes */

@@ -79,7 +79,7 @@ ACT_NONE, ACT_RELU, ACT_SIGMOID = 0, 1, 2
 F_ACCUM, F_BIAS, F_CSCALE, F_BNPART, F_NFAST, F_TOUT, F_CI3, F_X6, F_STRIPS = 1, 2, 4, 8, 16, 32, 64, 128, 256
 WG_CS3, WG_X6 = 1, 2
 
-ABI_VERSION = 101          # PC_VERSION of include/picons.h
+ABI_VERSION = 102          # PC_VERSION of include/picons.h
 
 _SIGS = {
     "pc_version": (i32, []),
@@ -151,6 +151,8 @@ _SIGS = {
     "pc_tail_combine": (i32, [vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, vp, vp, vp]),
     "pc_tail_colsum": (i32, [vp, i32, i64, vp, vp]),
     "pc_tail_grads": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+    "pc_tail_grads_ws_floats": (i64, [i32, i32, i32]),
+    "pc_tail_grads_ws": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp]),
     "pc_axis_linear": (i32, [vp, vp, vp, vp, vp, vp]),
     "pc_wspec_fwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
     "pc_wspec_bwd": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]),
@@ -162,6 +164,9 @@ _SIGS = {
     "pc_tail6_scatter": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "pc_tail6_wgrad_map": (i32, [vp, i32, i32, vp, vp]),
     "pc_tail6_bias_sums": (i32, [vp, i32, i32, i32, i32, vp, vp]),
+    "pc_tail6_wgrad_map_slices": (i32, [vp, vp, i32, i32, vp, vp]),
+    "pc_tail6_bias_sums_ws_floats": (i64, [i32, i32, i32, i32]),
+    "pc_tail6_bias_sums_ws": (i32, [vp, i32, i32, i32, i32, vp, vp, vp]),
     "pc_transpose_multi": (i32, [vp, i32, vp]),
     "pc_run_ops": (i32, [vp, i32, vp]),
     "pc_run_ops_lanes": (i32, [vp, i32, vp, i32]),

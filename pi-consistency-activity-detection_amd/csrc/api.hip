@@ -124,8 +124,9 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_TAIL_COLSUM:
             return pc_tail_colsum(P(const float*, 0), op.i[0], op.l[0], P(float*, 1), s);
         case PC_OP_TAIL_GRADS:
-            return pc_tail_grads(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), P(const float*, 4), P(const float*, 5),
-                                 op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), op.i[6], s);
+            return pc_tail_grads_ws(P(const float*, 0), P(const float*, 1), P(const float*, 2), P(const float*, 3), P(const float*, 4), P(const float*, 5),
+                                    op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 6), P(float*, 7), P(float*, 8), P(float*, 9), op.i[6],
+                                    P(float*, 10), s);
         case PC_OP_COL2IM:
             return pc_col2im(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], op.i[4], op.i[5], P(float*, 1), op.i[6], op.i[7], s);
         case PC_OP_AXIS: {
@@ -150,9 +151,10 @@ static int run_one(const pc_op& op, pc_stream s) {
         case PC_OP_TAIL6_SCATTER:
             return pc_tail6_scatter(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
         case PC_OP_TAIL6_WGRAD_MAP:
-            return pc_tail6_wgrad_map(P(const float*, 0), op.i[0], op.i[1], P(float*, 1), s);
+            return op.i[2] ? pc_tail6_wgrad_map_slices(P(float*, 0), &op.i[3], op.i[0], op.i[1], P(float*, 1), s)
+                           : pc_tail6_wgrad_map(P(const float*, 0), op.i[0], op.i[1], P(float*, 1), s);
         case PC_OP_TAIL6_BIAS_SUMS:
-            return pc_tail6_bias_sums(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), s);
+            return pc_tail6_bias_sums_ws(P(const float*, 0), op.i[0], op.i[1], op.i[2], op.i[3], P(float*, 1), P(float*, 2), s);
         case PC_OP_TRANSPOSE_MULTI:
             return pc_transpose_multi(P(const pc_transpose_job*, 0), op.i[0], s);
         case PC_OP_WGRAD_FOLD:

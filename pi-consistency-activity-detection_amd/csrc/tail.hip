@@ -89,10 +89,11 @@ __global__ __launch_bounds__(128) void tail_dw4_kernel(const float* __restrict__
 
 // dWp[co][j] += cs[n][co] * sum_{ci,tap} W4[ci][co][tap] * G[n][ci][tap][j]
 // Block = (sample n, 8 input channels): its 8 x taps x 32 slab of G sits in LDS; thread (co, half) accumulates 16 of the 32
-// columns over the slab, then one atomic per element (N * Ci/8 adds per element).
+// columns over the slab.  part == NULL: one atomic per element (N * Ci/8 adds per element, arrival order).  part != NULL (round 6): the block
+// leaves its [Co][32] partial in part[n * Ci/8 + slab] with plain stores and tail_dwp_sum_kernel adds the partials in block order.
 constexpr int DWP_CI = 8;
 __global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__ G, const float* __restrict__ W4, const float* __restrict__ cs,
-                                                       int Ci, int Co, int taps, int J, float* __restrict__ dWp) {
+                                                       int Ci, int Co, int taps, int J, float* __restrict__ dWp, float* __restrict__ part) {
     extern __shared__ float gs[];                       // [DWP_CI * taps][32]
     const int n = blockIdx.y, ci0 = blockIdx.x * DWP_CI;
     const int rows = DWP_CI * taps;
@@ -100,6 +101,7 @@ __global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__
     for (int e = threadIdx.x; e < rows * J32; e += 256) gs[e] = gsrc[e];
     __syncthreads();
     const int half = threadIdx.x & 1;
+    float* pb = part ? part + ((size_t)n * gridDim.x + blockIdx.x) * Co * J32 : nullptr;
     for (int co = threadIdx.x >> 1; co < Co; co += 128) {
         float acc[16];
 #pragma unroll
@@ -112,12 +114,36 @@ __global__ __launch_bounds__(256) void tail_dwp_kernel(const float* __restrict__
             for (int q = 0; q < 16; ++q) acc[q] += w * gr[q];
         }
         const float sc = cs ? cs[n * Co + co] : 1.f;
+        if (pb) {
+#pragma unroll
+            for (int q = 0; q < 16; q += 4) *(float4*)(pb + co * J32 + half * 16 + q) = make_float4(sc * acc[q], sc * acc[q + 1], sc * acc[q + 2], sc * acc[q + 3]);
+            continue;
+        }
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int j = half * 16 + q;
             if (j < J) atomicAdd(dWp + co * J + j, sc * acc[q]);
         }
     }
+}
+
+// dWp[co][j] = (accum ? dWp : 0) + sum over the np block partials [np][Co][32], in block order (16 loads in flight per thread)
+__global__ __launch_bounds__(256) void tail_dwp_sum_kernel(const float* __restrict__ part, int np, int Co, int J, float* __restrict__ dWp, int accum) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= Co * J32) return;
+    const int co = e / J32, j = e - co * J32;
+    const size_t st = (size_t)Co * J32;
+    float v = 0.f;
+    int q = 0;
+    for (; q + 16 <= np; q += 16) {
+        float t[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) t[u] = part[(size_t)(q + u) * st + e];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v += t[u];
+    }
+    for (; q < np; ++q) v += part[(size_t)q * st + e];
+    if (j < J) dWp[co * J + j] = (accum ? dWp[co * J + j] : 0.f) + v;
 }
 
 // bias-path terms: dWp[co][j] += b4[co]*sb[j], db4[co] (+)= sum_j Wp[co][j]*sb[j], dbp (+)= sum_n s[n][center];  sb[j] = sum_n cs[n][co] s[n][j]
@@ -163,15 +189,29 @@ extern "C" int pc_tail_colsum(const float* dproj, int N, int64_t rows_per_n, flo
     return PC_OK;
 }
 
-extern "C" int pc_tail_grads(const float* G, const float* sums, const float* W4, const float* b4, const float* cs, const float* Wp, int N,
-                             int Ci, int Co, int taps, int J, int center, float* dW4, float* db4, float* dWp, float* dbp, int accum, pc_stream s_) {
+extern "C" int64_t pc_tail_grads_ws_floats(int N, int Ci, int Co) {
+    if (N < 1 || Ci < DWP_CI || Ci % DWP_CI || Co < 1) return -1;
+    return (int64_t)N * (Ci / DWP_CI) * Co * J32;
+}
+
+// ws != NULL (pc_tail_grads_ws_floats floats, no initialisation needed): the smooth-weight gradient's N * Ci/8 block partials are stored and added in
+// block order -- no fp32 atomics, bit-identical from run to run.  ws == NULL: pc_tail_grads (atomics in arrival order).
+extern "C" int pc_tail_grads_ws(const float* G, const float* sums, const float* W4, const float* b4, const float* cs, const float* Wp, int N,
+                                int Ci, int Co, int taps, int J, int center, float* dW4, float* db4, float* dWp, float* dbp, int accum, float* ws,
+                                pc_stream s_) {
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(G && sums && W4 && b4 && Wp && dW4 && db4 && dWp && dbp && J <= J32, "pc_tail_grads: bad args");
     PC_CHECK_ARG(N <= DW4_MAXN && Ci % DWP_CI == 0, "pc_tail_grads: N <= %d and Ci %% %d == 0 expected (N=%d Ci=%d)", DW4_MAXN, DWP_CI, N, Ci);
     hipLaunchKernelGGL(tail_dw4_kernel, dim3(Ci * taps), dim3(128), 0, s, G, cs, Wp, N, Ci, Co, taps, J, dW4, accum);
-    if (!accum) (void)hipMemsetAsync(dWp, 0, sizeof(float) * Co * J, s);
-    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Ci / DWP_CI, N), dim3(256), (size_t)DWP_CI * taps * J32 * 4, s, G, W4, cs, Ci, Co, taps, J, dWp);
+    if (!ws && !accum) (void)hipMemsetAsync(dWp, 0, sizeof(float) * Co * J, s);
+    hipLaunchKernelGGL(tail_dwp_kernel, dim3(Ci / DWP_CI, N), dim3(256), (size_t)DWP_CI * taps * J32 * 4, s, G, W4, cs, Ci, Co, taps, J, dWp, ws);
+    if (ws) hipLaunchKernelGGL(tail_dwp_sum_kernel, dim3((Co * J32 + 255) / 256), dim3(256), 0, s, ws, N * (Ci / DWP_CI), Co, J, dWp, accum);
     hipLaunchKernelGGL(tail_dbias_kernel, dim3(Co), dim3(64), 0, s, sums, b4, cs, Wp, N, Co, J, center, dWp, db4, dbp, accum);
     PC_CHECK_LAUNCH("tail_grads");
     return PC_OK;
+}
+
+extern "C" int pc_tail_grads(const float* G, const float* sums, const float* W4, const float* b4, const float* cs, const float* Wp, int N,
+                             int Ci, int Co, int taps, int J, int center, float* dW4, float* db4, float* dWp, float* dbp, int accum, pc_stream s) {
+    return pc_tail_grads_ws(G, sums, W4, b4, cs, Wp, N, Ci, Co, taps, J, center, dW4, db4, dWp, dbp, accum, nullptr, s);
 }

@@ -197,7 +197,32 @@ __global__ __launch_bounds__(256) void tail6_scatter_kernel(const float* __restr
 
 // dW5 [N][8 z][Ci][128 slot] -> Gc [N][Ci][27 tap][32 j]: component (k4, ks) sits in slot k4 + ks of every class except
 // the classes whose index is 0 in a dimension where k4 = 0 and ks = 2
-__global__ __launch_bounds__(256) void tail6_wgrad_map_kernel(const float* __restrict__ dW5, int N, int Ci, float* __restrict__ Gc) {
+// sl.image == 0: dW5 as above (pc_conv_wgrad's atomics summed the K slices).  Otherwise dW5 is the classes' K-slice workspaces back to back,
+// [z][k < sl.n[z]][N][Ci][128] (class z at sl.zoff[z], pc_wgrad_desc.ws_slices); tail6_slices_sum_kernel has left every class's sum in its image 0.
+struct T6Slices { int n[8]; long long zoff[8]; long long image; };
+
+// image 0 of class blockIdx.y += images 1 .. n-1, in slice order (16 bytes per thread, eight loads in flight): the streaming half of the ordered sum,
+// so that the map below gathers its <= 8 scattered values per element from one image per class instead of from every slice
+__global__ __launch_bounds__(256) void tail6_slices_sum_kernel(float* __restrict__ ws, const T6Slices sl) {
+    const int z = blockIdx.y, ns = sl.n[z];
+    if (ns < 2) return;
+    float4* base = (float4*)(ws + sl.zoff[z]);
+    const long long img4 = sl.image / 4;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < img4; e += (long long)gridDim.x * 256) {
+        float4 v = base[e];
+        int k = 1;
+        for (; k + 8 <= ns; k += 8) {
+            float4 t[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) t[u] = base[(long long)(k + u) * img4 + e];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w; }
+        }
+        for (; k < ns; ++k) { const float4 t = base[(long long)k * img4 + e]; v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+        base[e] = v;
+    }
+}
+__global__ __launch_bounds__(256) void tail6_wgrad_map_kernel(const float* __restrict__ dW5, int N, int Ci, float* __restrict__ Gc, const T6Slices sl) {
     const int64_t total = (int64_t)N * Ci * 27 * J32;
     for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
         const int j = (int)(idx & 31);
@@ -211,7 +236,8 @@ __global__ __launch_bounds__(256) void tail6_wgrad_map_kernel(const float* __res
             const bool bad[3] = {k4[0] == 0 && ks[0] == 2, k4[1] == 0 && ks[1] == 2, k4[2] == 0 && ks[2] == 2};
             for (int z = 0; z < 8; ++z) {
                 if (((z & 4) && bad[0]) || ((z & 2) && bad[1]) || ((z & 1) && bad[2])) continue;
-                acc += dW5[(((size_t)n * 8 + z) * Ci + ci) * SP + slot];
+                if (!sl.image) { acc += dW5[(((size_t)n * 8 + z) * Ci + ci) * SP + slot]; continue; }
+                if (sl.n[z]) acc += dW5[sl.zoff[z] + ((size_t)n * Ci + ci) * SP + slot];
             }
         }
         Gc[idx] = acc;
@@ -219,7 +245,8 @@ __global__ __launch_bounds__(256) void tail6_wgrad_map_kernel(const float* __res
 }
 
 // sums[n][j = ks] = sum over the outputs o whose tap-ks source position o + 1 - ks lies in the grid of dout[n][o]
-__global__ __launch_bounds__(256) void tail6_bias_sums_kernel(const float* __restrict__ dout, int Ot, int Oh, int Ow, int64_t per_block, float* __restrict__ sums) {
+__global__ __launch_bounds__(256) void tail6_bias_sums_kernel(const float* __restrict__ dout, int Ot, int Oh, int Ow, int64_t per_block, float* __restrict__ sums,
+                                                              float* __restrict__ part) {
     __shared__ float sh[27][8];
     const int n = blockIdx.y;
     const int64_t per_n = (int64_t)Ot * Oh * Ow;
@@ -249,7 +276,30 @@ __global__ __launch_bounds__(256) void tail6_bias_sums_kernel(const float* __res
         if (lane == 0) sh[q][wave] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 27) atomicAdd(sums + n * J32 + threadIdx.x, sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3]);
+    if (threadIdx.x < 27) {
+        const float v = sh[threadIdx.x][0] + sh[threadIdx.x][1] + sh[threadIdx.x][2] + sh[threadIdx.x][3];
+        if (part) part[((size_t)n * gridDim.x + blockIdx.x) * J32 + threadIdx.x] = v;       // per-block partial row: summed in block order by bias_sums_final
+        else atomicAdd(sums + n * J32 + threadIdx.x, v);
+    }
+}
+
+// sums[n][j] = sum over the blocks' partial rows, in block order (no atomics: bit-identical from run to run)
+__global__ __launch_bounds__(32) void tail6_bias_sums_final_kernel(const float* __restrict__ part, int nb, float* __restrict__ sums) {
+    const int n = blockIdx.x, j = threadIdx.x;
+    float v = 0.f;
+    if (j < 27) {
+        const float* q = part + (size_t)n * nb * J32 + j;
+        int b = 0;
+        for (; b + 14 <= nb; b += 14) {          // fourteen loads in flight (nb = 98 at 8 x 224 x 224), added in block order
+            float t[14];
+#pragma unroll
+            for (int u = 0; u < 14; ++u) t[u] = q[(size_t)(b + u) * J32];
+#pragma unroll
+            for (int u = 0; u < 14; ++u) v += t[u];
+        }
+        for (; b < nb; ++b) v += q[(size_t)b * J32];
+    }
+    sums[n * J32 + j] = v;
 }
 
 }  // namespace
@@ -290,23 +340,65 @@ extern "C" int pc_tail6_scatter(const float* dout, int N, int It, int Ih, int Iw
     return PC_OK;
 }
 
-extern "C" int pc_tail6_wgrad_map(const float* dW5, int N, int Ci, float* Gc, pc_stream s) {
+static int t6_wgrad_map(float* dW5, const int32_t* nslices8, int N, int Ci, float* Gc, pc_stream s) {
     PC_CHECK_ARG(dW5 && Gc && N >= 1 && Ci >= 1, "pc_tail6_wgrad_map: bad args");
+    T6Slices sl;
+    sl.image = nslices8 ? (long long)N * Ci * SP : 0;
+    long long at = 0;
+    for (int z = 0; z < 8; ++z) {
+        sl.n[z] = nslices8 ? nslices8[z] : 1;
+        PC_CHECK_ARG(sl.n[z] >= 0 && sl.n[z] <= 65536, "pc_tail6_wgrad_map_slices: class %d has %d slice images", z, sl.n[z]);
+        sl.zoff[z] = at;
+        at += sl.n[z] * sl.image;
+    }
     const int64_t total = (int64_t)N * Ci * 27 * J32;
     int grid = (int)((total + 255) / 256); if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(tail6_wgrad_map_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dW5, N, Ci, Gc);
+    if (sl.image) {
+        int g4 = (int)((sl.image / 4 + 255) / 256); if (g4 > 512) g4 = 512;
+        hipLaunchKernelGGL(tail6_slices_sum_kernel, dim3(g4, 8), dim3(256), 0, (hipStream_t)s, dW5, sl);
+    }
+    hipLaunchKernelGGL(tail6_wgrad_map_kernel, dim3(grid), dim3(256), 0, (hipStream_t)s, dW5, N, Ci, Gc, sl);
     PC_CHECK_LAUNCH("tail6_wgrad_map");
     return PC_OK;
 }
 
-extern "C" int pc_tail6_bias_sums(const float* dout, int N, int It, int Ih, int Iw, float* sums, pc_stream s_) {
+extern "C" int pc_tail6_wgrad_map_slices(float* ws, const int32_t* nslices8, int N, int Ci, float* Gc, pc_stream s) {
+    PC_CHECK_ARG(nslices8, "pc_tail6_wgrad_map_slices: no slice counts");
+    return t6_wgrad_map(ws, nslices8, N, Ci, Gc, s);
+}
+
+extern "C" int pc_tail6_wgrad_map(const float* dW5, int N, int Ci, float* Gc, pc_stream s) {
+    return t6_wgrad_map(const_cast<float*>(dW5), nullptr, N, Ci, Gc, s);
+}
+
+namespace {
+inline void t6_bias_blocks(int It, int Ih, int Iw, int64_t& pb, int& nb) {
+    const int64_t per_n = (int64_t)8 * It * Ih * Iw;
+    pb = (per_n + 255) / 256; if (pb < 4096) pb = 4096;
+    nb = (int)((per_n + pb - 1) / pb);
+}
+}  // namespace
+
+extern "C" int64_t pc_tail6_bias_sums_ws_floats(int N, int It, int Ih, int Iw) {
+    if (N < 1 || It < 1 || Ih < 1 || Iw < 1) return -1;
+    int64_t pb; int nb;
+    t6_bias_blocks(It, Ih, Iw, pb, nb);
+    return (int64_t)N * nb * J32;
+}
+
+// ws != NULL (pc_tail6_bias_sums_ws_floats floats): per-block partial rows + a fixed-order final sum instead of fp32 atomics
+extern "C" int pc_tail6_bias_sums_ws(const float* dout, int N, int It, int Ih, int Iw, float* sums, float* ws, pc_stream s_) {
     hipStream_t s = (hipStream_t)s_;
     PC_CHECK_ARG(dout && sums && N >= 1 && N <= 65535, "pc_tail6_bias_sums: bad args");
-    (void)hipMemsetAsync(sums, 0, sizeof(float) * N * J32, s);
-    const int64_t per_n = (int64_t)8 * It * Ih * Iw;
-    int64_t pb = (per_n + 255) / 256; if (pb < 4096) pb = 4096;
-    const int nb = (int)((per_n + pb - 1) / pb);
-    hipLaunchKernelGGL(tail6_bias_sums_kernel, dim3(nb, N), dim3(256), 0, s, dout, 2 * It, 2 * Ih, 2 * Iw, pb, sums);
+    int64_t pb; int nb;
+    t6_bias_blocks(It, Ih, Iw, pb, nb);
+    if (!ws) (void)hipMemsetAsync(sums, 0, sizeof(float) * N * J32, s);
+    hipLaunchKernelGGL(tail6_bias_sums_kernel, dim3(nb, N), dim3(256), 0, s, dout, 2 * It, 2 * Ih, 2 * Iw, pb, sums, ws);
+    if (ws) hipLaunchKernelGGL(tail6_bias_sums_final_kernel, dim3(N), dim3(32), 0, s, ws, nb, sums);
     PC_CHECK_LAUNCH("tail6_bias_sums");
     return PC_OK;
+}
+
+extern "C" int pc_tail6_bias_sums(const float* dout, int N, int It, int Ih, int Iw, float* sums, pc_stream s) {
+    return pc_tail6_bias_sums_ws(dout, N, It, Ih, Iw, sums, nullptr, s);
 }

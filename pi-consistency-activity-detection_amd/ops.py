@@ -373,9 +373,29 @@ def tail6_wgrad_map(dW6, N, Ci, Gc):
     return Gc
 
 
-def tail6_bias_sums(dout, N, It, Ih, Iw, sums):
-    capi.call("pc_tail6_bias_sums", ptr(dout), N, It, Ih, Iw, ptr(sums), stream())
+def tail6_bias_sums(dout, N, It, Ih, Iw, sums, ws=None):
+    """ws (tail6_bias_sums_ws_floats floats): per-block partial rows added in block order instead of fp32 atomics."""
+    if ws is None:
+        capi.call("pc_tail6_bias_sums", ptr(dout), N, It, Ih, Iw, ptr(sums), stream())
+    else:
+        assert ws.numel() >= tail6_bias_sums_ws_floats(N, It, Ih, Iw)
+        capi.call("pc_tail6_bias_sums_ws", ptr(dout), N, It, Ih, Iw, ptr(sums), ptr(ws), stream())
     return sums
+
+
+def tail6_bias_sums_ws_floats(N, It, Ih, Iw):
+    return int(capi.lib().pc_tail6_bias_sums_ws_floats(N, It, Ih, Iw))
+
+
+def tail6_wgrad_map_slices(ws, nslices8, N, Ci, Gc):
+    """ws: the classes' K-slice workspaces back to back ([z][k < nslices8[z]][N][Ci][128], pc_wgrad_desc.ws_slices); a class's image 0 holds the
+    class's in-order sum afterwards."""
+    import ctypes
+    import numpy as np
+    ns = np.ascontiguousarray(nslices8, dtype=np.int32)
+    assert ns.shape == (8,) and ws.numel() >= int(ns.sum()) * N * Ci * 128
+    capi.call("pc_tail6_wgrad_map_slices", ptr(ws), ns.ctypes.data_as(ctypes.c_void_p), N, Ci, ptr(Gc), stream())
+    return Gc
 
 
 def transpose_multi(jobs):

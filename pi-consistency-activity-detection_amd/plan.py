@@ -1284,35 +1284,56 @@ class Plan:
             dcols = self.alloc(cat112.rows * SP)
             self.emit(capi.OP_TAIL6_SCATTER, i=[N, It, Ih, Iw], p=[self.dout, dcols])
             sums = self.alloc(N * 32)
-            self.emit(capi.OP_TAIL6_BIAS_SUMS, i=[N, It, Ih, Iw], p=[self.dout, sums])
-            dW5 = self.alloc(N * 8 * 128 * SP)
+            # ordered: per-block partial rows added in block order, K-slice images per class added in slice order -- no fp32 atomics
+            # anywhere in the tail's gradients (round 6; with upsample4 / smooth's own reduction in pc_tail_grads)
+            sums_ws = self.alloc(capi.lib().pc_tail6_bias_sums_ws_floats(N, It, Ih, Iw)) if self.wg_ordered else 0
+            self.emit(capi.OP_TAIL6_BIAS_SUMS, i=[N, It, Ih, Iw], p=[self.dout, sums, sums_ws])
+            wds = tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld, compact=self.wg_ordered)
+            ns8, zoff = [0] * 8, {}
+            if self.wg_ordered:
+                at = 0
+                for z, wd in wds:
+                    if self.x6 and sw.get("PICONS_SPLIT_WGRAD", "1") != "0":
+                        wd["flags"] = int(wd.get("flags", 0)) | capi.WG_X6           # as wgrad_op routes it: the slice count is the routed kernel's
+                    ns8[z] = capi.lib().pc_wgrad_slices(_wdesc(wd))
+                    if ns8[z] < 1:
+                        raise RuntimeError("pc_wgrad_slices: %s" % capi.lib().pc_last_error().decode())
+                    wd["ws_slices"] = ns8[z]
+                    zoff[z] = at
+                    at += ns8[z] * N * 128 * SP
+                dW5 = self.alloc(at)
+                self.zero_once.append((dW5, at))            # padding slots and empty slices are never written
+            else:
+                dW5 = self.alloc(N * 8 * 128 * SP)
             Gc = self.alloc(N * 128 * 27 * 32)
             dx, acc = self.grad_for_write(cat112)
 
             def weight_grads(lane_of):
                 """The tail's weight gradients: per-class wgrads, their map onto the 27x27 combined weights, upsample4 / smooth."""
-                self.emit(capi.OP_FILL, p=[dW5], l=[N * 8 * 128 * SP], f=[0.0])
+                if not self.wg_ordered:
+                    self.emit(capi.OP_FILL, p=[dW5], l=[N * 8 * 128 * SP], f=[0.0])
                 grouped = bool(self.wg_lane) and self.wgrad_collect is None
                 if grouped:
                     self.wgrad_collect = []
-                for z, wd in tail6.wgrad_descs(N, cat112.thw, 128, cat112.ld):
+                for z, wd in wds:
                     self.lane = lane_of(z)
-                    self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, z * 128 * SP)])
+                    self.wgrad_op(wd, [cat112.ref, dcols, off(dW5, zoff[z] if self.wg_ordered else z * 128 * SP)])
                 if grouped:              # the eight position classes (seven of them a few hundred positions) in one launch
                     jobs, self.wgrad_collect = self.wgrad_collect, None
                     self.wjobs = getattr(self, "wjobs", [])
                     self.wjobs.append(jobs)
-                    if sw.exp("PICONS_WGRAD_MULTI_TAIL", "0", self.exp) == "0":
+                    if self.wg_ordered or sw.exp("PICONS_WGRAD_MULTI_TAIL", "0", self.exp) == "0":
                         for d_, p_ in jobs:
                             self._emit_wgrad(d_, p_)
                     else:
                         self.emit(capi.OP_WGRAD_MULTI, i=[len(jobs)], p=[("WJOBS", len(self.wjobs) - 1)])
 
             def weight_grads_tail():
-                self.emit(capi.OP_TAIL6_WGRAD_MAP, i=[N, 128], p=[dW5, Gc])
+                self.emit(capi.OP_TAIL6_WGRAD_MAP, i=[N, 128, int(self.wg_ordered)] + ns8, p=[dW5, Gc])
                 self.emit(capi.OP_TAIL_GRADS, i=[N, 128, 128, 27, J, 13, self.acc],
-                          p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias")])
+                          p=[Gc, sums, W4, b4, cs_ref, Wp, self.G("upsample4.weight"), self.G("upsample4.bias"), self.G("smooth.weight"), self.G("smooth.bias"), grads_ws])
                 self.mark_final("upsample4.weight", "upsample4.bias", "smooth.weight", "smooth.bias")
+            grads_ws = self.alloc(capi.lib().pc_tail_grads_ws_floats(N, 128, 128)) if self.wg_ordered else 0
             if self.wg_lane:
                 # nothing but the optimiser waits for them: the whole group goes to the weight-gradient lane, and lane 0's join
                 # below only waits for the seven thin border classes' dgrads

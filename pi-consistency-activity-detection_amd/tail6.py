@@ -45,14 +45,16 @@ def dgrad_descs(N, thw, Ci, lddx, accum):
     return [(z, _sub(base, s, e)) for z, s, e in classes(thw)]
 
 
-def wgrad_descs(N, thw, Ci, ldx):
+def wgrad_descs(N, thw, Ci, ldx, compact=False):
     """dW5[n][z][ci][slot] += sum over the class's positions of x[n][i][ci] * dcols[n][i][slot]: one launch per class with the
-    N clip-passes as batched problems; gradient at dW5 + z*Ci*SP, per-sample stride 8*Ci*SP."""
+    N clip-passes as batched problems; gradient at dW5 + z*Ci*SP, per-sample stride 8*Ci*SP.
+    compact: every class has a gradient buffer of its own, [n][ci][slot] (per-sample stride Ci*SP) -- the form whose K-slice images
+    (pc_wgrad_desc.ws_slices) pc_tail6_wgrad_map_slices adds in slice order."""
     per = thw[0] * thw[1] * thw[2]
     out = []
     for z, s, e in classes(thw):
         d = D.wgrad(1, e, Ci, ldx, thw, SP, SP, (1, 1, 1), (1, 1, 1), (0, 0, 0))
         d.update(ioff0=list(s), Td=thw[0], Hd=thw[1], Wd=thw[2], doff=list(s),
-                 nbatch=N, dbstride=per * ldx, sbstride=per * SP, gbstride=8 * Ci * SP, Cs_real=NSLOT)
+                 nbatch=N, dbstride=per * ldx, sbstride=per * SP, gbstride=(1 if compact else 8) * Ci * SP, Cs_real=NSLOT)
         out.append((z, d))
     return out

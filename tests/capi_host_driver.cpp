@@ -76,6 +76,17 @@ int main() {
         EXPECT(pc_transpose_multi(&tj, 1, nullptr) == PC_E_ARG);
     }
 
+    // the merged tail's ordered reductions: workspace sizing and argument checks (host arithmetic, refused before any launch)
+    EXPECT(pc_tail6_bias_sums_ws_floats(16, 4, 112, 112) == 16 * 98 * 32 && pc_tail6_bias_sums_ws_floats(0, 4, 112, 112) == -1);
+    EXPECT(pc_tail6_bias_sums_ws_floats(2, 1, 3, 3) == 2 * 32);                        // small frames: one block per clip-pass
+    {
+        int32_t ns8[8] = {4, 1, 1, 1, 2, 1, 1, -1};
+        EXPECT(pc_tail6_wgrad_map_slices(fp, nullptr, 2, 8, fp, nullptr) == PC_E_ARG);
+        EXPECT(pc_tail6_wgrad_map_slices(fp, ns8, 2, 8, fp, nullptr) == PC_E_ARG);      // a negative slice count
+        EXPECT(pc_tail6_bias_sums_ws(nullptr, 2, 1, 3, 3, fp, fp, nullptr) == PC_E_ARG);
+        EXPECT(pc_tail_grads_ws_floats(16, 128, 128) == 16 * 16 * 128 * 32 && pc_tail_grads_ws_floats(16, 12, 128) == -1);
+    }
+
     // workspace sizing: host arithmetic
     EXPECT(pc_bn_bwd_ws_floats(802816, 64, 2) > 0);
     EXPECT(pc_act_bwd_ws_floats(802816, 64) > 0);

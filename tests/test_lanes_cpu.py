@@ -16,8 +16,8 @@ WRITES = {capi.OP_CONV: (4, 5), capi.OP_WGRAD: (2,), capi.OP_BN_FINALIZE: (3, 4,
           capi.OP_BN_BWD: (3, 4, 5, 6), capi.OP_POOL_FWD: (1, 2), capi.OP_POOL_BWD: (2,), capi.OP_CHSCALE: (2,), capi.OP_ACT_BWD: (2, 3, 4),
           capi.OP_TO_NDHWC: (1,), capi.OP_TRANSPOSE: (1,), capi.OP_FILL: (0,), capi.OP_EM_FWD: (4, 5), capi.OP_EM_BWD: (5, 6, 7, 8, 9),
           capi.OP_CMASK_FWD: (3, 4, 5), capi.OP_CMASK_BWD: (3,), capi.OP_TAIL_COMBINE: (4, 5, 6), capi.OP_TAIL6_WEIGHTS: (1, 2),
-          capi.OP_TAIL6_GATHER: (3,), capi.OP_TAIL6_SCATTER: (1,), capi.OP_TAIL6_BIAS_SUMS: (1,), capi.OP_TAIL6_WGRAD_MAP: (1,),
-          capi.OP_TAIL_GRADS: (6, 7, 8, 9), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
+          capi.OP_TAIL6_GATHER: (3,), capi.OP_TAIL6_SCATTER: (1,), capi.OP_TAIL6_BIAS_SUMS: (1, 2), capi.OP_TAIL6_WGRAD_MAP: (1,),
+          capi.OP_TAIL_GRADS: (6, 7, 8, 9, 10), capi.OP_AXIS: (3,), capi.OP_WSPEC_FWD: (2,), capi.OP_WSPEC_BWD: (2,), capi.OP_WSPEC_MASTER_FWD: (2, 3),
           capi.OP_WSPEC_MASTER_BWD: (2,), capi.OP_LOSS: (4, 5, 6, 7, 8, 9), capi.OP_SPREAD: (3, 4), capi.OP_ADAM: (0, 2, 3), capi.OP_COL2IM: (1,),
           capi.OP_TAPSUM_FWD: (2,), capi.OP_TAPSUM_BWD: (1,), capi.OP_TAIL_COLSUM: (1,), capi.OP_WINO_CONV: (3, 4), capi.OP_WINO_WEIGHTS: (1,),
           capi.OP_CONV_X6: (4, 5, 6), capi.OP_SPLIT_PLANES: (1,), capi.OP_WSPEC_MASTER_PLANES: (2, 3), capi.OP_WGRAD_FOLD: (0,)}

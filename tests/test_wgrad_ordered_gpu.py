@@ -158,3 +158,127 @@ def test_wino_f2_conv_from_an_idle_chip_is_bit_identical():
         _cold(junk, it)
         ops.wino_conv(d, x, U, out)
         assert torch.equal(out, first), "F(2x2, 3x3) launch %d from an idle chip differs" % it
+
+
+# ---- the merged decoder tail's gradients (capsules_ucf101.py:504-509 under loss.backward()): the last four tensors that used fp32 atomics
+def test_merged_tail_gradients_carry_no_atomics():
+    """Per-class weight gradients into K-slice workspaces + pc_tail6_wgrad_map_slices, pc_tail6_bias_sums_ws, pc_tail_grads: equal to the atomic
+    forms to fp32 rounding, equal to an emulation of their summation order bit for bit, and bit-identical from an idle chip."""
+    from picons_amd import tail6
+    g = torch.Generator().manual_seed(61)
+    N, Ci, I = 4, 128, (3, 30, 28)
+    SP = tail6.SP
+    x = torch.relu(torch.randn(N, *I, Ci, generator=g)).to(DEV)
+    dout = torch.randn(N, *[2 * v for v in I], generator=g).to(DEV)
+    dcols = torch.empty(N, *I, SP, device=DEV)
+    ops.tail6_scatter(dout, N, *I, dcols)
+    # atomic form
+    dW5 = torch.zeros(N, 8, Ci, SP, device=DEV)
+    for z, d in tail6.wgrad_descs(N, I, Ci, Ci):
+        ops.conv_wgrad(dict(d, flags=capi.WG_X6), x, dcols, dW5.view(-1)[z * Ci * SP:])
+    Gc_atomic = ops.tail6_wgrad_map(dW5, N, Ci, torch.empty(N, Ci, 27, 32, device=DEV))
+    # ordered form
+    wds = [(z, dict(d, flags=capi.WG_X6)) for z, d in tail6.wgrad_descs(N, I, Ci, Ci, compact=True)]
+    ns8 = [0] * 8
+    for z, d in wds:
+        ns8[z] = ops.wgrad_slices(d)
+    assert max(ns8) > 1, ns8
+    image = N * Ci * SP
+    ws = torch.zeros(sum(ns8) * image, device=DEV)
+    zoff = np.concatenate([[0], np.cumsum(ns8)[:-1]]) * image
+
+    def run(junk=None, it=0):
+        for z, d in wds:
+            if junk is not None:
+                _cold(junk, it)
+            ops.conv_wgrad(dict(d, ws_slices=ns8[z]), x, dcols, ws[int(zoff[z]):])
+        return ops.tail6_wgrad_map_slices(ws, ns8, N, Ci, torch.full((N, Ci, 27, 32), float("nan"), device=DEV))
+    first_ws = None
+
+    def images():          # the K-slice images as the launches left them (the map folds a class's images into its image 0)
+        for z, d in wds:
+            ops.conv_wgrad(dict(d, ws_slices=ns8[z]), x, dcols, ws[int(zoff[z]):])
+        return ws.clone()
+    first_ws = images()
+    Gc = run()
+    err = ((Gc - Gc_atomic).norm() / Gc_atomic.norm()).item()
+    assert err <= 2e-6, err
+    assert torch.all(Gc[..., 27:] == 0)
+    # emulation of the order: a class's images in slice order, then the class sums in class order
+    tap, j = np.meshgrid(np.arange(27), np.arange(27), indexing="ij")
+    k4 = [tap // 9, (tap // 3) % 3, tap % 3]; ks = [j // 9, (j // 3) % 3, j % 3]
+    slot = torch.from_numpy(((k4[0] + ks[0]) * 5 + k4[1] + ks[1]) * 5 + k4[2] + ks[2]).to(DEV)
+    bad = [torch.from_numpy((k4[a] == 0) & (ks[a] == 2)).to(DEV) for a in range(3)]
+    acc = torch.zeros(N, Ci, 27, 27, device=DEV)
+    for z in range(8):
+        skip = torch.zeros(27, 27, dtype=torch.bool, device=DEV)
+        for a, bit in enumerate((4, 2, 1)):
+            if z & bit:
+                skip |= bad[a]
+        if not ns8[z]:
+            continue
+        cls = first_ws[int(zoff[z]):int(zoff[z]) + image].clone()
+        for k in range(1, ns8[z]):
+            cls += first_ws[int(zoff[z]) + k * image:int(zoff[z]) + (k + 1) * image]
+        assert torch.equal(ws[int(zoff[z]):int(zoff[z]) + image], cls), "class %d: image 0 is not the in-order sum of the class's slice images" % z
+        acc = torch.where(skip, acc, acc + cls.view(N, Ci, SP)[:, :, slot])
+    assert torch.equal(Gc[..., :27], acc), "pc_tail6_wgrad_map_slices is not the in-order sum of the class sums"
+    first_Gc = Gc.clone()
+    junk = torch.empty(96 << 20, device=DEV)
+    for it in range(4):
+        assert torch.equal(run(junk, it), first_Gc), "tail weight gradients, run %d differs" % it
+    assert torch.equal(images(), first_ws), "the K-slice images differ from the first run's"
+    # bias sums
+    sums_atomic = ops.tail6_bias_sums(dout, N, *I, torch.empty(N, 32, device=DEV))
+    part = torch.full((ops.tail6_bias_sums_ws_floats(N, *I),), float("nan"), device=DEV)        # needs no initialisation
+    sums = ops.tail6_bias_sums(dout, N, *I, torch.full((N, 32), float("nan"), device=DEV), ws=part)
+    assert torch.allclose(sums[:, :27], sums_atomic[:, :27], rtol=2e-5, atol=2e-4) and torch.all(sums[:, 27:] == 0)
+    nb = part.numel() // (N * 32)
+    emu = torch.zeros(N, 32, device=DEV)
+    for b in range(nb):
+        emu += torch.nan_to_num(part.view(N, nb, 32)[:, b])
+    assert torch.equal(sums[:, :27], emu[:, :27])
+    for it in range(4):
+        _cold(junk, it)
+        assert torch.equal(ops.tail6_bias_sums(dout, N, *I, torch.empty(N, 32, device=DEV), ws=part), sums)
+
+
+def test_tail_grads_are_bit_identical_and_match_fp64():
+    """pc_tail_grads_ws at the model's shape (N = 16 clip-passes, 128 -> 128 channels, 27 x 27 taps): the smooth-weight gradient's 256 block
+    partials are stored and added in block order (no atomics since round 6); the workspace needs no initialisation."""
+    g = torch.Generator().manual_seed(62)
+    N, Ci, Co, taps, J = 16, 128, 128, 27, 27
+    Gc = torch.randn(N, Ci, taps, 32, generator=g); Gc[..., 27:] = 0
+    sums = torch.randn(N, 32, generator=g); sums[:, 27:] = 0
+    W4 = torch.randn(Ci, Co, taps, generator=g) * 0.1
+    b4 = torch.randn(Co, generator=g)
+    cs = (torch.rand(N, Co, generator=g) < 0.5).float() * 2
+    Wp = torch.randn(Co, J, generator=g) * 0.2
+    dv = [t.to(DEV).contiguous() for t in (Gc, sums, W4, b4, cs, Wp)]
+    outs = []
+    junk = torch.empty(96 << 20, device=DEV)
+    part = torch.full((int(capi.lib().pc_tail_grads_ws_floats(N, Ci, Co)),), float("nan"), device=DEV)
+    for it in range(5):
+        dW4 = torch.full((Ci, Co, taps), float("nan"), device=DEV); db4 = torch.full((Co,), float("nan"), device=DEV)
+        dWp = torch.full((Co, J), float("nan"), device=DEV); dbp = torch.full((1,), float("nan"), device=DEV)
+        _cold(junk, it)
+        capi.call("pc_tail_grads_ws", *[ops.ptr(t) for t in dv], N, Ci, Co, taps, J, 13, ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 0, ops.ptr(part),
+                  ops.stream())
+        outs.append([t.clone() for t in (dW4, db4, dWp, dbp)])
+        for a, b in zip(outs[0], outs[-1]):
+            assert torch.equal(a, b), "pc_tail_grads run %d differs" % it
+    G64, W64, cs64, Wp64, s64, b64 = Gc[..., :27].double(), W4.double(), cs.double(), Wp.double(), sums[:, :27].double(), b4.double()
+    ref_dWp = torch.einsum("nitj,iot,no->oj", G64, W64, cs64) + torch.einsum("o,no,nj->oj", b64, cs64, s64)
+    ref_dW4 = torch.einsum("nitj,no,oj->iot", G64, cs64, Wp64)
+    for name, got, ref in (("dWp", outs[0][2], ref_dWp), ("dW4", outs[0][0], ref_dW4)):
+        rel = ((got.cpu().double() - ref).norm() / ref.norm()).item()
+        assert rel < 3e-6, (name, rel)
+    # accumulate form: dWp += the same
+    dW4, db4, dWp, dbp = [t.clone() for t in outs[0]]
+    capi.call("pc_tail_grads_ws", *[ops.ptr(t) for t in dv], N, Ci, Co, taps, J, 13, ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 1, ops.ptr(part),
+              ops.stream())
+    assert torch.allclose(dWp, 2 * outs[0][2], rtol=1e-6, atol=1e-6)
+    # the atomic form (no workspace) agrees to fp32 rounding
+    dW4, db4, dWp, dbp = [torch.empty_like(t) for t in outs[0]]
+    capi.call("pc_tail_grads", *[ops.ptr(t) for t in dv], N, Ci, Co, taps, J, 13, ops.ptr(dW4), ops.ptr(db4), ops.ptr(dWp), ops.ptr(dbp), 0, ops.stream())
+    assert ((dWp - outs[0][2]).norm() / outs[0][2].norm()).item() < 2e-6 and torch.equal(dW4, outs[0][0])
