@@ -394,3 +394,44 @@ def test_early_adam_op_is_ordered_behind_every_other_gradient(lanes):
         for r in op[3]:
             if isinstance(r, tuple) and r[0] in ("P", "G", "M", "V"):
                 assert r[1] < 4 * n0, (op[0], r)
+
+
+@pytest.mark.parametrize("classes,bs,hw", [(24, 8, 224), (21, 8, 224), (24, 2, 112)])
+def test_no_weight_gradient_of_the_product_plan_is_summed_with_atomics(classes, bs, hw):
+    """Round 6: every gradient of the step is bit-identical from run to run because no launch adds fp32 partials in arrival order.  The GPU
+    determinism test runs at bs = 2, 112^2, where the K-slice counts differ from the benchmark's; this walks the plans themselves (host only):
+    every weight-gradient launch either makes ONE K slice per problem (each element written or added once), or stores plainly (splitk = -1), or
+    writes K-slice images (ws_slices >= the slices the launch makes); the tail's three reductions carry their workspaces; no grouped launch
+    (its epilogue is atomic) is left."""
+    from picons_amd import desc as D
+    from picons_amd.plan import _wdesc
+    args = pstep.default_args(bv=True, gv=True, n_frames=5)
+    p = Plan(classes, hw, n=bs, groups=2, lanes=4, early_adam=True, jhmdb=classes == 21)
+    p.build_forward(); p.build_loss(args); p.build_backward(); p.build_adam()
+    p.finalize()
+    vec3 = set(D.CONV_VEC3) | {"doff"}
+    seen = collections.Counter()
+    for op in p.lists["bwd"]:
+        kind, ints, ptrs = op[0], op[1], op[3]
+        assert kind != capi.OP_WGRAD_MULTI, "grouped weight-gradient launches add their K slices with atomics"
+        if kind == capi.OP_WGRAD:
+            d, q = {}, 0
+            for f in D.WGRAD_FIELDS:
+                n = 3 if f in vec3 else 1
+                d[f] = [int(v) for v in ints[q:q + 3]] if n == 3 else int(ints[q])
+                q += n
+            ns = capi.lib().pc_wgrad_slices(_wdesc(dict(d, ws_slices=0)))
+            assert ns >= 1, capi.lib().pc_last_error()
+            how = "stores" if d["splitk"] == -1 else ("one slice" if ns == 1 else "images")
+            assert how != "images" or d["ws_slices"] >= ns, ("split-K launch without K-slice images", d, ns)
+            seen[how] += 1
+        elif kind == capi.OP_TAIL6_WGRAD_MAP:
+            assert ints[2] == 1 and sum(ints[3:11]) >= 8, ints[:11]
+            seen["tail map"] += 1
+        elif kind == capi.OP_TAIL6_BIAS_SUMS:
+            assert ptrs[2], "pc_tail6_bias_sums without its partial rows"
+            seen["tail bias"] += 1
+        elif kind == capi.OP_TAIL_GRADS:
+            assert ptrs[10], "pc_tail_grads without its block partials"
+            seen["tail grads"] += 1
+    assert seen["images"] >= 30 and seen["tail map"] == seen["tail bias"] == seen["tail grads"] == 1, seen
