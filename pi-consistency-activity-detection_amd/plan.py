@@ -753,23 +753,36 @@ class Plan:
             wide = self.tensor(x.N, x.thw, e + c3 + oc[5], pre + ".out")
             out = wide.slice(e, c3 + oc[5])
             outer, self.tape = self.tape, []
-            self.unit3d([pre + ".b1a", pre + ".b2a", pre + ".b0"], x, [oc[1], oc[3], oc[0]], one, one, out=wide.slice(0, e + oc[0]))
             # the big 3x3x3 branch on lane 0, pool branch + the small 3x3x3 branch on lane 1 (measured best of four assignments);
             # in the forward the weight-gradient lane is idle and takes the small 3x3x3 branch (PICONS_FWD_BRANCH3=0: off)
             third = self.wg_lane if (self.wg_lane and sw.get("PICONS_FWD_BRANCH3", "1") != "0") else 0
             fmask = ((1 << self.branch_lanes) - 2) | (1 << third if third else 0)
-            self.fork(fmask)
+            # the pool branch needs nothing but x: it leaves at the module's head, beside the fused 1x1x1 unit (round 6: forked behind that
+            # unit it ended 40 - 60 us after lane 0 in every 14 x 14 module, the step's forward idling on the join)
+            early = sw.get("PICONS_POOL_BRANCH_EARLY", "1") != "0" and self.branch_lanes > 1
+            if early:
+                self.fork(1 << L(1))
+                self.lane = L(1)
+                t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
+                self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
+                self.lane = 0
+            self.unit3d([pre + ".b1a", pre + ".b2a", pre + ".b0"], x, [oc[1], oc[3], oc[0]], one, one, out=wide.slice(0, e + oc[0]))
+            self.fork((1 << third) if (early and third) else fmask)
             self.lane = L(0)
             self.unit3d(pre + ".b1b", wide.slice(0, oc[1]), oc[2], (3, 3, 3), one, out=out.slice(c1, oc[2]))
             self.lane = L(1)
-            t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
-            self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
+            if not early:
+                t3 = self.maxpool(x, (3, 3, 3), one, pre + ".pool")
+                self.unit3d(pre + ".b3b", t3, oc[5], one, one, out=out.slice(c3, oc[5]))
             if third:
                 self.lane = third
             self.unit3d(pre + ".b2b", wide.slice(oc[1], oc[3]), oc[4], (3, 3, 3), one, out=out.slice(c2, oc[4]))
             self.lane = 0
             self.join(fmask)
-            (fused, b1b, pool, b3b, b2b), self.tape = self.tape, outer
+            if early:
+                (pool, b3b, fused, b1b, b2b), self.tape = self.tape, outer
+            else:
+                (fused, b1b, pool, b3b, b2b), self.tape = self.tape, outer
 
             def bwd_fused():
                 self.wgrad_group_begin()  # the module's four weight gradients leave as one multi-problem launch

@@ -140,13 +140,16 @@ def test_lanes_are_ordered_wherever_they_share_a_buffer(lanes):
     if p.late_prep:
         assert len(p.lists["prep"]) < 12 < len(p.lists["prep_late"]) and all(op[5] != 0 for op in p.lists["prep_late"][1:])
     branch = (1 << p.branch_lanes) - 2
-    third = branch | (1 << p.wg_lane if p.wg_lane else 0)
-    # one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes; the forward's module
-    # forks include the weight-gradient lane (idle there: the third branch)
+    # backward: one FORK of the branch lanes per Inception module (Mixed_3b..4f) + the merged tail's position classes.  Forward (round 6): a
+    # module forks TWICE -- lane 1 at its head (the pool branch needs nothing but the module's input), then, behind the fused 1x1x1 unit, the
+    # weight-gradient lane (idle in the forward: the small 3x3x3 branch) or, without one, lane 1 again
     # ... and the forward deals the position classes of upsample2 / upsample3 to ALL lanes (one FORK of every side lane each)
     all_side = (1 << lanes) - 2
+    second = (1 << p.wg_lane) if p.wg_lane else branch
+    masks = {2, second, branch}
+    others = (2 if all_side in masks else 0) + (3 if p.skip_lane and (1 << p.skip_lane) in masks else 0)
     assert _forks(p, "bwd", branch) == 8
-    assert sum(_forks(p, "fwd", m) for m in {third, branch}) == 8 + (2 if all_side in (third, branch) else 0)
+    assert sum(_forks(p, "fwd", m) for m in masks) == 7 + 7 + 1 + others
     assert _forks(p, "fwd", all_side) >= 2
     if p.skip_lane and p.skip_lane != p.wg_lane:
         assert _forks(p, "fwd", 1 << p.skip_lane) == 3                   # conv56, conv112, conv28

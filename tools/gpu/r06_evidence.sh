@@ -23,7 +23,7 @@ PICONS_LANES=1 timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT
 PICONS_LANES=1 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_VALU_MFMA_MOPS_BF16 GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc_m -o m -- $B > $O/pmc_m.log 2>&1
 cd $R
 python3 tools/launch_table.py $O/prof_l1/l1_kernel_trace.csv 70 > $O/launch_table.txt 2>&1
-python3 tools/lane_timeline.py $O/prof/r06_kernel_trace.csv --window -1 --expect-ms $MS --by-lane 6 > $O/lane_timeline.txt 2>&1
+python3 tools/lane_timeline.py $O/prof/r06_kernel_trace.csv --window -1 --expect-ms $MS --by-lane 6 --gaps 30 > $O/lane_timeline.txt 2>&1
 python3 tools/summarize_pmc.py --stats $O/prof_l1/l1_kernel_stats.csv --fetch $O/pmc_f/f_counter_collection.csv --write $O/pmc_w/w_counter_collection.csv \
     --sq $O/pmc_sq/sq_counter_collection.csv --mfma $O/pmc_m/m_counter_collection.csv --steps 3 --tag r06 > $O/summarize.log 2>&1
 cp profiles/r06_traffic.json profiles/r06_hbm_table.md profiles/r06_pmc_sq_gemm.csv profiles/r06_mfma_counter_check.txt $O/ 2>/dev/null

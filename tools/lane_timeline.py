@@ -55,6 +55,10 @@ def main():
     ap.add_argument("--by-lane", type=int, default=0, help="also print, per stream, the N kernels with the largest summed duration in this step")
     ap.add_argument("--sequence", type=int, default=-1, help="print the dispatches of this stream id in order (start offset, duration, kernel, blocks, "
                     "kernels of other streams live at its start)")
+    ap.add_argument("--gaps", type=int, default=0, help="print the N longest intervals of the step in which NO kernel runs: offset, length, the kernel that ended "
+                    "last before it and the one that starts after it (with their streams), and a histogram of all such intervals by length")
+    ap.add_argument("--lane-gaps", type=int, default=-1, help="print the longest idle intervals of this stream id between two of its kernels and which other "
+                    "stream's kernel ended last inside each (the dependency it most likely waited for)")
     a = ap.parse_args()
     rows = [r for r in csv.DictReader(open(a.trace)) if r["Kind"] == "KERNEL_DISPATCH"]
     for r in rows:
@@ -129,6 +133,39 @@ def main():
             out.append("\nstream %s: kernel, dispatches, summed ms" % (k,))
             for n, (c, d) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:a.by_lane]:
                 out.append("  %8.3f %4d  %s" % (d / 1e6, c, n))
+    if a.gaps:
+        gaps, live_n, prev_t, last_end = [], 0, t0, None
+        for t, kind, i in ev:
+            if live_n == 0 and t > prev_t and kind == 1:
+                gaps.append((t - prev_t, prev_t, last_end, i))
+            if kind:
+                live_n += 1
+            else:
+                live_n -= 1; last_end = i
+            prev_t = t
+        tot = sum(g[0] for g in gaps)
+        out.append("\nintervals with no kernel running: %d, %.3f ms in total; by length:" % (len(gaps), tot / 1e6))
+        for lo, hi in ((0, 2), (2, 5), (5, 10), (10, 20), (20, 50), (50, 100), (100, 1 << 30)):
+            sel = [g[0] for g in gaps if lo * 1000 <= g[0] < hi * 1000]
+            out.append("  %4s - %-5s us  %4d  %8.3f ms" % (lo, hi if hi < (1 << 30) else "", len(sel), sum(sel) / 1e6))
+        out.append("the %d longest: offset ms, length us, ended before (stream) -> starts after (stream)" % a.gaps)
+        for ln, at, le, nx in sorted(gaps, reverse=True)[:a.gaps]:
+            b = "(step start)" if le is None else "%s (%s)" % (clean(step[le]["Kernel_Name"])[:44], step[le]["Stream_Id"])
+            out.append("  %8.3f %7.1f  %s -> %s (%s)" % ((at - t0) / 1e6, ln / 1e3, b, clean(step[nx]["Kernel_Name"])[:44], step[nx]["Stream_Id"]))
+    if a.lane_gaps >= 0:
+        mine = sorted((r for r in step if int(r["Stream_Id"]) == a.lane_gaps), key=lambda r: r["s"])
+        gl = []
+        for u, v in zip(mine, mine[1:]):
+            if v["s"] - u["e"] > 4000:
+                gl.append((v["s"] - u["e"], u, v))
+        out.append("\nstream %d: %d intervals of more than 4 us between its kernels, %.3f ms in total (the stream waits for another lane, or the host)"
+                   % (a.lane_gaps, len(gl), sum(g[0] for g in gl) / 1e6))
+        out.append("the 40 longest: offset ms, length us, its kernel before -> after | the kernel of another stream that ended last inside the interval")
+        for ln, u, v in sorted(gl, key=lambda g: -g[0])[:40]:
+            ended = [o for o in step if o["Stream_Id"] != u["Stream_Id"] and u["e"] <= o["e"] <= v["s"]]
+            w = max(ended, key=lambda o: o["e"]) if ended else None
+            out.append("  %8.3f %7.1f  %s -> %s | %s" % ((u["e"] - t0) / 1e6, ln / 1e3, clean(u["Kernel_Name"])[:36], clean(v["Kernel_Name"])[:36],
+                                                     "-" if w is None else "%s (%s), %.1f us before" % (clean(w["Kernel_Name"])[:36], w["Stream_Id"], (v["s"] - w["e"]) / 1e3)))
     if a.sequence >= 0:
         out.append("\nstream %d in order: start ms, duration ms, blocks, kernel | live on other streams at its start" % a.sequence)
         for r in sorted(step, key=lambda r: r["s"]):
