@@ -85,6 +85,7 @@ class Plan:
         self.skip_bwd = {}
         self.final_lane = {}      # param name -> lane of the op that finalises its gradient
         self.deferred = None      # build_backward: side-lane closures held back until the EM backward is enqueued
+        self.after_bn_bwd = None   # build_backward: emitted once, right behind the next BatchNorm backward op
         self.wgrad_collect = None  # inside a wgrad group: [(descriptor, pointer refs)] collected for one pc_conv_wgrad_multi op
         # Ordered split-K (round 6): the K slices of a weight gradient leave their partial sums as images in a workspace (plain stores) and
         # the gradient re-layout adds the images in slice order -- no fp32 atomics, no zero fill of the kernel-layout gradient, and every
@@ -705,6 +706,9 @@ class Plan:
                 fused_bwd = 2 if sw.exp("PICONS_BN_FUSED", "0", self.exp) != "0" else 0       # the planner's decision travels in the op (bit 1 of `relu`)
                 self.emit(capi.OP_BN_BWD, i=[dy.ld, z.ld, cout, self.groups, 1 | fused_bwd, dz.ld, self.acc], l=[z.rows],
                           p=[dy.ref, z.ref, stat, dz.ref, self.G(pre + ".bn.weight"), self.G(pre + ".bn.bias"), ws])
+                if self.after_bn_bwd is not None:          # build_backward: the early Adam op leaves behind the stem's BatchNorm backward
+                    hook, self.after_bn_bwd = self.after_bn_bwd, None
+                    hook()
                 wd = D.trim_wgrad(D.wgrad(x.N, othw, cout, dz.ld, x.thw, Ci, x.ld, k, stride, pf))
                 wd["Cs_real"] = Ci_real
                 wd["flags"] = capi.WG_CS3 if ci3 else 0
@@ -1403,13 +1407,31 @@ class Plan:
             self.deferred = []
         for idx, fn in enumerate(reversed(self.tape)):
             if self.early_adam and idx == len(self.tape) - 1:
-                self._emit_early_adam()
+                # The early Adam op (HBM-bound, 0.1 - 0.2 ms alone) used to leave IN FRONT of the stem's backward and ran beside its BatchNorm
+                # backward, HBM-bound too: 0.39 ms for the pair, on the step's serial tail.  Behind the BatchNorm backward it runs beside the stem's
+                # weight gradient instead, which is bound by the matrix cores (PICONS_EARLY_ADAM_BEHIND_BN=0: in front, as rounds 3 - 5).
+                if sw.get("PICONS_EARLY_ADAM_BEHIND_BN", "1") != "0":
+                    self.after_bn_bwd = self._emit_early_adam
+                else:
+                    self._emit_early_adam()
             fn()
+            assert self.after_bn_bwd is None, "the last backward closure has no BatchNorm backward to hang the early Adam op behind"
             self.flush_unprep()
         self.release_deferred()
         self.flush_unprep()
         if self.wg_lane or self.skip_lane:
             self.join((1 << self.wg_lane | 1 << self.skip_lane) & ~1)
+
+    def _emit_adam_op(self, n_lo):
+        lane = self.skip_lane or 1
+        for src in range(self.lanes):
+            if src != lane:
+                self.fork(1 << lane, src=src)
+        at = len(self.lists["bwd"])
+        self.emit(capi.OP_ADAM, i=[1], f=[1e-4, 0.9, 0.999, 1e-6, 1.0], l=[0], p=[("P", 4 * n_lo), ("G", 4 * n_lo), ("M", 4 * n_lo), ("V", 4 * n_lo)], lane=lane)
+        if lane != (self.skip_lane or self.wg_lane):
+            self.join(1 << lane)
+        return at
 
     def _emit_early_adam(self):
         """In front of the LAST backward closure (the stem unit: the first three tensors of the flat parameter buffer): every other
@@ -1420,15 +1442,8 @@ class Plan:
         assert names[:len(stem)] == stem and len(stem) == 3, "the stem's parameters lead the flat buffer"
         assert all(nm in self.final_at for nm in names[len(stem):]), "a gradient outside the stem is finalised by the stem's backward"
         n0 = self.poff[names[len(stem)]]
-        lane = self.skip_lane or 1
-        for src in range(self.lanes):
-            if src != lane:
-                self.fork(1 << lane, src=src)
         self.adam_split = n0
-        self.op_adam_early = len(self.lists["bwd"])
-        self.emit(capi.OP_ADAM, i=[1], f=[1e-4, 0.9, 0.999, 1e-6, 1.0], l=[0], p=[("P", 4 * n0), ("G", 4 * n0), ("M", 4 * n0), ("V", 4 * n0)], lane=lane)
-        if lane != (self.skip_lane or self.wg_lane):
-            self.join(1 << lane)
+        self.op_adam_early = self._emit_adam_op(n0)
 
     def grad_buckets(self, target_floats=12_000_000, joined=False):
         """Gradient all-reduce schedule for data parallelism: contiguous ranges of the flat G buffer in the
