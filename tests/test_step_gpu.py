@@ -446,6 +446,32 @@ def test_step_is_deterministic_run_to_run():
             assert torch.equal(runs[0][3][o:o + n], other[3][o:o + n]), name
 
 
+def test_step_is_deterministic_at_the_benchmark_size():
+    """The same check on bench.py's workload (bs = 8, 8 x 224 x 224, both consistency losses): the K-slice counts, the folds of launches with more than
+    128 slices and the merged tail's class sums are those of the measured step, not of the 112 x 112 case above.  Every output, scalar, running
+    statistic and gradient of three runs from the same state is compared with torch.equal."""
+    args = pstep.default_args(bv=True, gv=True, n_frames=5, wt_cons=0.1)
+    eng = pstep.StepEngine(args, bs=8, hw=224)
+    lab, unl, perm, drops = synthetic.make_step_inputs(8, step=3, hw=224)
+    first = None
+    for it in range(3):
+        eng.load_state(synthetic.init_state(47, 24))
+        eng.stage(lab, unl, perm, drops)
+        eng.forward_backward(1, 0.01)
+        torch.cuda.synchronize()
+        got = [t.clone() for t in eng.outputs()] + [eng.aview(eng.plan.scalars, 20).clone(), eng.R.clone(), eng.G.clone()]
+        if first is None:
+            first = got
+            assert torch.isfinite(first[-1]).all() and float(first[-1].abs().max()) > 0
+            continue
+        for q, (a, b) in enumerate(zip(first, got)):
+            if not torch.equal(a, b):
+                bad = [nm for nm in eng.plan.pshape
+                       if not torch.equal(a[eng.plan.poff[nm]:eng.plan.poff[nm] + int(np.prod(eng.plan.pshape[nm]))],
+                                          b[eng.plan.poff[nm]:eng.plan.poff[nm] + int(np.prod(eng.plan.pshape[nm]))])] if q == len(first) - 1 else []
+                raise AssertionError("run %d differs from the first in item %d %s" % (it, q, bad[:6]))
+
+
 def test_thread_events_can_be_released_between_steps():
     """pc_release_thread_events gives back the FORK / JOIN, fan-in and timing events of the calling thread; the next replay creates
     new ones and gives the same results."""
