@@ -162,6 +162,9 @@ __global__ __launch_bounds__(128) void wspec_master_fwd_kernel(const float* __re
     const int fast = blockIdx.x * 128 + threadIdx.x, slow = blockIdx.y;
     const int a = ALONG_A ? fast : slow, b = ALONG_A ? slow : fast;
     if (a >= Acnt || b >= B) return;
+    // (ALONG_A: consecutive threads are B * KY * KX floats apart in w -- 3.97 TB/s against the forward layout's 4.67.  Staging the block's 128 rows
+    // through LDS made the loads contiguous and the launch SLOWER, 0.289 -> 0.369 ms: 41 KB of LDS per 128 threads leaves 1.5 waves per SIMD for
+    // an HBM-bound kernel.  profiles/r06_wspec_master.txt)
     float v[KY][KX];
     const float* src = w + ((size_t)a * B + b) * (KY * KX);
 #pragma unroll
@@ -194,35 +197,38 @@ __global__ __launch_bounds__(128) void wspec_master_fwd_kernel(const float* __re
 }
 
 // dV planes in the forward layout [g][Atot][KY][B] -> dw[A][B][KY][KX] (+)= ...
+// Block = (a, 64 consecutive b), wave = one ky: a wave-load is 256 contiguous bytes of one plane row; a thread holds KX accumulators.  The block's
+// results are one CONTIGUOUS piece of dw (64 x KY x KX floats): they meet in LDS ([b][ky][kx], written at a stride of 81 floats: conflict-free) and
+// leave as coalesced stores.  (Rounds 2 - 5: thread = (a, b) with all 81 accumulators, every store instruction 64 scattered 4-byte writes 324 bytes
+// apart: 2.45 TB/s.)  Same sums in the same order: bit-identical.
 template <int KX, int KY>
-__global__ __launch_bounds__(128) void wspec_master_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ tw, int Acnt, int a0, int Atot,
-                                                                int B, int U, int Ur, float* __restrict__ dw, int accum) {
-    const int b = blockIdx.x * 128 + threadIdx.x, a = blockIdx.y;
-    if (a >= Acnt || b >= B) return;
-    float acc[KY][KX];
+__global__ __launch_bounds__(64 * KY) void wspec_master_bwd_kernel(const float* __restrict__ dV, const float* __restrict__ tw, int Acnt, int a0, int Atot,
+                                                                    int B, int U, int Ur, float* __restrict__ dw, int accum) {
+    __shared__ float tile[64 * KY * KX];
+    const int bl = threadIdx.x & 63, ky = threadIdx.x >> 6;
+    const int b0 = blockIdx.x * 64, a = blockIdx.y, b = b0 + bl;
+    if (b < B) {
+        float acc[KX];
 #pragma unroll
-    for (int ky = 0; ky < KY; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KX; ++kx) acc[ky][kx] = 0.f;
-    const int64_t plane = (int64_t)Atot * KY * B;
-    const float* d = dV + ((int64_t)(a0 + a) * KY) * B + b;
-    for (int u = 0; u < U; ++u) {
-        const bool real = u >= U - Ur;
-        const int64_t g0 = real ? 3 * (U - Ur) + (u - (U - Ur)) : 3 * u;
-#pragma unroll
-        for (int ky = 0; ky < KY; ++ky) {
-            const float* du = d + g0 * plane + (int64_t)ky * B;
+        for (int kx = 0; kx < KX; ++kx) acc[kx] = 0.f;
+        const int64_t plane = (int64_t)Atot * KY * B;
+        const float* d = dV + ((int64_t)(a0 + a) * KY + ky) * B + b;
+        for (int u = 0; u < U; ++u) {
+            const bool real = u >= U - Ur;
+            const int64_t g0 = real ? 3 * (U - Ur) + (u - (U - Ur)) : 3 * u;
+            const float* du = d + g0 * plane;
             const float d0 = du[0], d1 = real ? 0.f : du[plane], d2 = real ? 0.f : du[2 * plane];
             const float gr = d0 + d1 + d2, gi = d2 - d1;
 #pragma unroll
-            for (int kx = 0; kx < KX; ++kx) acc[ky][kx] += tw[(u * KX + kx) * 2] * gr + tw[(u * KX + kx) * 2 + 1] * gi;
+            for (int kx = 0; kx < KX; ++kx) acc[kx] += tw[(u * KX + kx) * 2] * gr + tw[(u * KX + kx) * 2 + 1] * gi;
         }
+#pragma unroll
+        for (int kx = 0; kx < KX; ++kx) tile[bl * (KY * KX) + ky * KX + kx] = acc[kx];
     }
-    float* dst = dw + ((size_t)a * B + b) * (KY * KX);
-#pragma unroll
-    for (int ky = 0; ky < KY; ++ky)
-#pragma unroll
-        for (int kx = 0; kx < KX; ++kx) dst[ky * KX + kx] = (accum ? dst[ky * KX + kx] : 0.f) + acc[ky][kx];
+    __syncthreads();
+    const int n = min(64, B - b0) * (KY * KX);
+    float* dst = dw + ((size_t)a * B + b0) * (KY * KX);
+    for (int e = threadIdx.x; e < n; e += 64 * KY) dst[e] = (accum ? dst[e] : 0.f) + tile[e];
 }
 
 }  // namespace
@@ -307,7 +313,7 @@ extern "C" int pc_wspec_master_bwd(const float* dV, const float* tw, int Acnt, i
                                    float* dw, int accum, pc_stream s_) {
     PC_CHECK_ARG(dV && tw && dw && Acnt > 0 && a0 >= 0 && a0 + Acnt <= Atot && B > 0 && U > 0 && Ur >= 0 && Ur <= U, "pc_wspec_master_bwd: bad args");
     PC_CHECK_ARG(KY == 9 && KX == 9, "pc_wspec_master_bwd: only the 9x9 PrimaryCaps kernel is instantiated (KY=%d KX=%d)", KY, KX);
-    hipLaunchKernelGGL((wspec_master_bwd_kernel<9, 9>), dim3(cdiv(B, 128), Acnt), dim3(128), 0, (hipStream_t)s_, dV, tw, Acnt, a0, Atot, B, U, Ur, dw, accum);
+    hipLaunchKernelGGL((wspec_master_bwd_kernel<9, 9>), dim3(cdiv(B, 64), Acnt), dim3(64 * 9), 0, (hipStream_t)s_, dV, tw, Acnt, a0, Atot, B, U, Ur, dw, accum);
     PC_CHECK_LAUNCH("wspec_master_bwd_kernel");
     return PC_OK;
 }
